@@ -1,0 +1,108 @@
+/* libleaf_hip.so -- C ABI of the MI355X-native LEAF text hot path.
+ *
+ * The reference (LIONS-EPFL/LEAF) has no FFI: its seams are Python call signatures.
+ * Each entry point below names the reference call site it replaces.  Conventions:
+ *   - plain C symbols, `int` status (0 = ok), message via leaf_last_error(); no exceptions cross the ABI;
+ *   - the library allocates NO caller-visible device memory: the caller (PyTorch) owns parameters,
+ *     gradients, optimizer state, activations and workspace and passes raw device pointers + a hipStream_t;
+ *   - every call is asynchronous on the given stream; a handle is host-only state, not thread-safe;
+ *   - tokens are int32 [n_seq, ctx] row-major, pad id 0, EOT = row maximum (open_clip tokenizer.py:256-263).
+ *
+ * Parameter buffer: ONE flat fp32 array (leaf_text_param_count floats).  Tensors that receive weight
+ * decay (train_AT_text_only.py:323-331: ndim >= 2 and no "bn"/"ln"/"bias"/"logit_scale" in the name) come
+ * first (leaf_text_decay_count floats), the rest after; leaf_text_param_info enumerates
+ * (open_clip state_dict key, offset, shape).  Gradients and AdamW moments use the same layout, so data
+ * parallelism is a single flat all-reduce.
+ */
+#ifndef LEAF_HIP_H
+#define LEAF_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct leaf_text_cfg {
+    int32_t layers, width, heads, embed_dim; /* src/open_clip/model_configs/ViT-*.json text_cfg + embed_dim */
+    int32_t context_length;                  /* 77 */
+    int32_t vocab_size;                      /* 49408 */
+    int32_t activation;                      /* 0 = nn.GELU (erf), 1 = QuickGELU (transformer.py:33-36) */
+    float ln_eps;                            /* 1e-5 */
+} leaf_text_cfg;
+
+typedef struct leaf_text* leaf_text_t;
+typedef void* leaf_stream_t; /* hipStream_t */
+
+enum { LEAF_DTYPE_BF16 = 0, LEAF_DTYPE_FP16 = 1 };                               /* MFMA operand type */
+enum { LEAF_OBJ_L2 = 0, LEAF_OBJ_NEGL2 = 1, LEAF_OBJ_DISSIM = 2, LEAF_OBJ_SIM = 3 }; /* utils_attacks.py:332-346 */
+
+const char* leaf_last_error(void);
+int leaf_version(void);
+
+/* handle: replaces open_clip.factory.create_model's text tower construction (model.py:173-217) */
+int leaf_text_create(const leaf_text_cfg* cfg, int fwd_dtype, leaf_text_t* out);
+void leaf_text_destroy(leaf_text_t h);
+int leaf_text_set_chunk(leaf_text_t h, int seqs_per_chunk); /* sequences processed per pass through the layers */
+
+/* flat parameter layout */
+size_t leaf_text_param_count(leaf_text_t h);
+size_t leaf_text_decay_count(leaf_text_t h);
+int leaf_text_num_tensors(leaf_text_t h);
+int leaf_text_param_info(leaf_text_t h, int index, char* name, size_t name_len, size_t* offset, int64_t* rows,
+                         int64_t* cols); /* cols = 0 for 1-D tensors */
+
+/* 16-bit operand copies of the GEMM weights.  w16_fwd: [N,K] as stored, forward dtype.  w16_bwd (may be
+ * NULL): transposed [K,N] bf16 copies for the data-gradient GEMMs.  Call after every optimizer step. */
+size_t leaf_text_w16_bytes(leaf_text_t h);
+int leaf_text_pack_weights(leaf_text_t h, const float* params, void* w16_fwd, void* w16_bwd, leaf_stream_t s);
+
+/* workspace sizes (bytes): mode 0 = forward, 1 = score_candidates, 2 = train backward */
+size_t leaf_text_workspace_bytes(leaf_text_t h, int n_seq, int mode);
+size_t leaf_text_stash_bytes(leaf_text_t h, int n_seq);
+
+/* CLIP.encode_text (src/open_clip/model.py:269-284): tokens [n_seq,ctx] -> out fp32 [n_seq,embed_dim] */
+int leaf_text_forward(leaf_text_t h, const float* params, const void* w16_fwd, const int32_t* tokens, int n_seq,
+                      float* out, int normalize, void* ws, size_t ws_bytes, leaf_stream_t s);
+
+/* one search stage of attack_text_leaf (utils_attacks.py:330-348 / 368-386,393): forward of B*rho candidates,
+ * loss per objective against anchor [B,embed_dim], first-index arg-max over rho, gather of the winning rows.
+ * loss (fp32 [B,rho]) and best_feat (fp32 [B,embed_dim]) may be NULL. */
+int leaf_score_candidates(leaf_text_t h, const float* params, const void* w16_fwd, const int32_t* tokens,
+                          const float* anchor, int B, int rho, int objective, int32_t* best_idx, float* best_feat,
+                          float* loss, void* ws, size_t ws_bytes, leaf_stream_t s);
+
+/* training forward (utils_AT.py:317-319) keeping activations in `stash` for the backward pass */
+int leaf_text_forward_train(leaf_text_t h, const float* params, const void* w16_fwd, const int32_t* tokens, int n_seq,
+                            float* out, void* stash, size_t stash_bytes, void* ws, size_t ws_bytes, leaf_stream_t s);
+
+/* TextFARE loss + backward (utils_AT.py:321-337): loss = mean_b sum_j (anchor - feat)^2; back-propagates
+ * loss * accum_scale (= 1/accum_freq) and ACCUMULATES (+=) into grads (flat fp32, parameter layout).
+ * loss_out: one device float (unscaled loss). */
+int leaf_textfare_backward(leaf_text_t h, const float* params, const void* w16_bwd, const int32_t* tokens, int n_seq,
+                           const float* feat, const float* anchor, float accum_scale, const void* stash,
+                           float* grads, float* loss_out, void* ws, size_t ws_bytes, leaf_stream_t s);
+
+/* torch.optim.AdamW step over the flat buffers (train_AT_text_only.py:326-341): decoupled weight decay `wd`
+ * on the first n_decay elements, 0 on the rest; step counts from 1; grads are multiplied by grad_scale first
+ * (1/world_size after a sum all-reduce). */
+int leaf_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, size_t n_decay,
+                    float lr, float beta1, float beta2, float eps, float wd, int step, float grad_scale,
+                    leaf_stream_t s);
+
+/* ---- single-kernel hooks (used by the parity tests to check each HIP kernel against the oracle) ---- */
+/* C[M,N] = epilogue(A[M,K] * B[N,K]^T): epi 0 store16(+bias), 1 act16(+bias, aux = pre-activation), 2 fp32 += ,
+ * 3 fp32 = beta*C + acc, 4 store16(acc * act'(aux)).  A, B 16-bit of `dtype`, contiguous. */
+int leaf_op_gemm(int dtype, int epi, const void* A, const void* B, void* C, const float* bias, void* aux, int M, int N,
+                 int K, int act, float beta, int aux_f16, leaf_stream_t s);
+int leaf_op_attention_fwd(const void* qkv, void* out, int n_seq, int ctx, int heads, int width, int dtype,
+                          leaf_stream_t s);
+int leaf_op_layernorm(const float* x, const float* g, const float* b, float eps, void* out16, int rows, int width,
+                      int dtype, leaf_stream_t s);
+int leaf_op_attention_bwd(const void* qkv, int qkv_dtype, const void* dout_bf16, void* dqkv_bf16, int n_seq, int ctx,
+                          int heads, int width, leaf_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,79 @@
+"""ctypes binding of libleaf_hip.so (the C ABI in include/leaf_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C leaf_amd/csrc``.  There is no
+fallback: if the shared object is missing, every product entry point raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libleaf_hip.so")
+
+
+class TextCfgC(C.Structure):
+    _fields_ = [("layers", C.c_int32), ("width", C.c_int32), ("heads", C.c_int32), ("embed_dim", C.c_int32),
+                ("context_length", C.c_int32), ("vocab_size", C.c_int32), ("activation", C.c_int32),
+                ("ln_eps", C.c_float)]
+
+
+_SIGS = {
+    "leaf_last_error": (C.c_char_p, []),
+    "leaf_version": (C.c_int, []),
+    "leaf_text_create": (C.c_int, [C.POINTER(TextCfgC), C.c_int, C.POINTER(C.c_void_p)]),
+    "leaf_text_destroy": (None, [C.c_void_p]),
+    "leaf_text_set_chunk": (C.c_int, [C.c_void_p, C.c_int]),
+    "leaf_text_param_count": (C.c_size_t, [C.c_void_p]),
+    "leaf_text_decay_count": (C.c_size_t, [C.c_void_p]),
+    "leaf_text_num_tensors": (C.c_int, [C.c_void_p]),
+    "leaf_text_param_info": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t),
+                                       C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "leaf_text_w16_bytes": (C.c_size_t, [C.c_void_p]),
+    "leaf_text_pack_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "leaf_text_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    "leaf_text_stash_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
+    "leaf_text_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                    C.c_void_p, C.c_size_t, C.c_void_p]),
+    "leaf_score_candidates": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                        C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                        C.c_void_p]),
+    "leaf_text_forward_train": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                          C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "leaf_textfare_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                         C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_size_t, C.c_void_p]),
+    "leaf_adamw_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_float,
+                                  C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_void_p]),
+    "leaf_op_gemm": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                               C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
+    "leaf_op_attention_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "leaf_op_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int,
+                                    C.c_int, C.c_void_p]),
+    "leaf_op_attention_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p]),
+}
+
+EXPORTS = tuple(_SIGS)
+_lib = None
+
+
+class LeafHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libleaf_hip.so once; raise loudly when it is missing (no CPU fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LeafHipError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+                               f"g.build()'` or `make -C leaf_amd/csrc` (the HIP extension is mandatory)")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise LeafHipError(f"{what} failed: {lib().leaf_last_error().decode()}")

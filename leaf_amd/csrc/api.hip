@@ -1,0 +1,257 @@
+// C ABI (include/leaf_hip.h): handle + flat parameter layout + weight packing + encode_text +
+// score_candidates.  Host orchestration only -- every device operation is a launch on the caller's stream.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "engine.h"
+
+static thread_local char g_err[512] = "";
+
+void leaf_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+int leaf_check(hipError_t e, const char* what) {
+    if (e == hipSuccess) return 0;
+    leaf_set_error("%s: %s", what, hipGetErrorString(e));
+    return 1;
+}
+
+extern "C" const char* leaf_last_error(void) { return g_err; }
+extern "C" int leaf_version(void) { return 1; }
+
+extern "C" int leaf_text_create(const leaf_text_cfg* cfg, int fwd_dtype, leaf_text_t* out) {
+    if (!cfg || !out) { leaf_set_error("null argument"); return 1; }
+    const int d = cfg->width;
+    if (cfg->layers < 1 || d < 128 || d % 128 || cfg->heads * 64 != d || cfg->embed_dim < 4 || cfg->embed_dim % 4 ||
+        cfg->embed_dim > 2048 || d > 2048 || cfg->context_length < 1 || cfg->context_length > 96 ||
+        cfg->vocab_size < 2 || (cfg->activation != 0 && cfg->activation != 1) ||
+        (fwd_dtype != LEAF_DTYPE_BF16 && fwd_dtype != LEAF_DTYPE_FP16)) {
+        leaf_set_error("unsupported text config (need width %% 128 == 0, head_dim 64, ctx <= 96, embed_dim %% 4 == 0)");
+        return 1;
+    }
+    leaf_text* h = new leaf_text();
+    h->cfg = *cfg;
+    h->fwd_dtype = fwd_dtype;
+    h->chunk = 1024;
+    const int L = cfg->layers, D = cfg->embed_dim;
+    size_t off = 0;
+    auto add = [&](const std::string& name, int64_t rows, int64_t cols) {
+        TensorInfo t{name, off, rows, cols};
+        off += t.numel();
+        h->tensors.push_back(t);
+        return t.offset;
+    };
+    h->layer.resize(L);
+    // ---- weight-decay group (train_AT_text_only.py:323-331)
+    h->tok_emb = add("token_embedding.weight", cfg->vocab_size, d);
+    h->pos_emb = add("positional_embedding", cfg->context_length, d);
+    h->text_proj = add("text_projection", d, D);
+    for (int l = 0; l < L; ++l) {
+        std::string p = "transformer.resblocks." + std::to_string(l) + ".";
+        h->layer[l].qkv_w = add(p + "attn.in_proj_weight", 3 * d, d);
+        h->layer[l].out_w = add(p + "attn.out_proj.weight", d, d);
+        h->layer[l].fc_w = add(p + "mlp.c_fc.weight", 4 * d, d);
+        h->layer[l].proj_w = add(p + "mlp.c_proj.weight", d, 4 * d);
+    }
+    h->n_decay = off;
+    // ---- no-decay group
+    for (int l = 0; l < L; ++l) {
+        std::string p = "transformer.resblocks." + std::to_string(l) + ".";
+        h->layer[l].ln1_w = add(p + "ln_1.weight", d, 0);
+        h->layer[l].ln1_b = add(p + "ln_1.bias", d, 0);
+        h->layer[l].qkv_b = add(p + "attn.in_proj_bias", 3 * d, 0);
+        h->layer[l].out_b = add(p + "attn.out_proj.bias", d, 0);
+        h->layer[l].ln2_w = add(p + "ln_2.weight", d, 0);
+        h->layer[l].ln2_b = add(p + "ln_2.bias", d, 0);
+        h->layer[l].fc_b = add(p + "mlp.c_fc.bias", 4 * d, 0);
+        h->layer[l].proj_b = add(p + "mlp.c_proj.bias", d, 0);
+    }
+    h->lnf_w = add("ln_final.weight", d, 0);
+    h->lnf_b = add("ln_final.bias", d, 0);
+    h->n_params = off;
+    *out = h;
+    return 0;
+}
+
+extern "C" void leaf_text_destroy(leaf_text_t h) { delete h; }
+
+extern "C" int leaf_text_set_chunk(leaf_text_t h, int seqs) {
+    if (!h || seqs < 1) { leaf_set_error("bad chunk"); return 1; }
+    h->chunk = seqs;
+    return 0;
+}
+
+extern "C" size_t leaf_text_param_count(leaf_text_t h) { return h->n_params; }
+extern "C" size_t leaf_text_decay_count(leaf_text_t h) { return h->n_decay; }
+extern "C" int leaf_text_num_tensors(leaf_text_t h) { return (int)h->tensors.size(); }
+extern "C" int leaf_text_param_info(leaf_text_t h, int index, char* name, size_t name_len, size_t* offset,
+                                    int64_t* rows, int64_t* cols) {
+    if (!h || index < 0 || index >= (int)h->tensors.size()) { leaf_set_error("tensor index out of range"); return 1; }
+    const TensorInfo& t = h->tensors[index];
+    if (name && name_len) { strncpy(name, t.name.c_str(), name_len - 1); name[name_len - 1] = 0; }
+    if (offset) *offset = t.offset;
+    if (rows) *rows = t.rows;
+    if (cols) *cols = t.cols;
+    return 0;
+}
+
+extern "C" size_t leaf_text_w16_bytes(leaf_text_t h) { return h->w16_layer_elems() * h->cfg.layers * 2; }
+
+extern "C" int leaf_text_pack_weights(leaf_text_t h, const float* params, void* w16_fwd, void* w16_bwd,
+                                      leaf_stream_t s_) {
+    hipStream_t s = (hipStream_t)s_;
+    const int d = h->cfg.width;
+    for (int l = 0; l < h->cfg.layers; ++l) {
+        const LayerOff& o = h->layer[l];
+        struct { size_t src, dst; int rows, cols; } m[4] = {
+            {o.qkv_w, h->w16_qkv(l), 3 * d, d}, {o.out_w, h->w16_out(l), d, d},
+            {o.fc_w, h->w16_fc(l), 4 * d, d},   {o.proj_w, h->w16_proj(l), d, 4 * d}};
+        for (auto& t : m) {
+            if (w16_fwd)
+                LEAF_TRY(leaf_launch_cast(params + t.src, (uint16_t*)w16_fwd + t.dst, (size_t)t.rows * t.cols,
+                                          h->fwd_dtype, s));
+            if (w16_bwd)  // [rows,cols] fp32 -> [cols,rows] bf16
+                LEAF_TRY(leaf_launch_transpose_bf16(params + t.src, 2, (uint16_t*)w16_bwd + t.dst, t.rows, t.cols,
+                                                    t.cols, t.rows, s));
+        }
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------ forward
+namespace {
+
+struct FwdBuf {
+    float* x;      // [rows,d] fp32 residual stream
+    uint16_t* a;   // [rows,d]   LN output / attention output (aliased)
+    uint16_t* qkv; // [rows,3d]
+    uint16_t* hh;  // [rows,4d]
+};
+
+size_t fwd_chunk_bytes(const leaf_text* h, int cs) {
+    const size_t rows = (size_t)cs * h->cfg.context_length, d = h->cfg.width;
+    Carver c(nullptr, 0);
+    c.take(rows * d * 4); c.take(rows * d * 2); c.take(rows * 3 * d * 2); c.take(rows * 4 * d * 2);
+    return align_up(c.off, 256);
+}
+
+FwdBuf carve_fwd(const leaf_text* h, Carver& c, int cs) {
+    const size_t rows = (size_t)cs * h->cfg.context_length, d = h->cfg.width;
+    FwdBuf b;
+    b.x = (float*)c.take(rows * d * 4);
+    b.a = (uint16_t*)c.take(rows * d * 2);
+    b.qkv = (uint16_t*)c.take(rows * 3 * d * 2);
+    b.hh = (uint16_t*)c.take(rows * 4 * d * 2);
+    return b;
+}
+
+int gemm(int dtype, int epi, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias,
+         void* aux, int M, int N, int K, int act, hipStream_t s, float beta = 0.f, int aux_f16 = 0) {
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C; g.bias = bias; g.aux = aux;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.act = act; g.aux_f16 = aux_f16; g.beta = beta;
+    return leaf_check(leaf_launch_gemm(g, dtype, epi, s), "gemm");
+}
+
+// run the layer stack on `cs` sequences; features -> out [cs, D]
+int forward_chunk(const leaf_text* h, const float* P, const uint16_t* W, const int32_t* tokens, int cs, float* out,
+                  int normalize, const FwdBuf& b, hipStream_t s) {
+    const leaf_text_cfg& c = h->cfg;
+    const int d = c.width, rows = cs * c.context_length, dt = h->fwd_dtype;
+    const LayerOff& o0 = h->layer[0];
+    LEAF_TRY(leaf_launch_embed_ln(tokens, P + h->tok_emb, P + h->pos_emb, P + o0.ln1_w, P + o0.ln1_b, c.ln_eps, b.x,
+                                  b.a, rows, c.context_length, d, c.vocab_size, dt, s));
+    for (int l = 0; l < c.layers; ++l) {
+        const LayerOff& o = h->layer[l];
+        if (l > 0) LEAF_TRY(leaf_launch_layernorm(b.x, P + o.ln1_w, P + o.ln1_b, c.ln_eps, b.a, rows, d, dt, s));
+        if (gemm(dt, EPI_STORE_T, b.a, d, W + h->w16_qkv(l), d, b.qkv, 3 * d, P + o.qkv_b, nullptr, rows, 3 * d, d, 0, s))
+            return 1;
+        LEAF_TRY(leaf_launch_attention_fwd(b.qkv, b.a, cs, c.context_length, c.heads, d, dt, s));
+        if (gemm(dt, EPI_RESID_F32, b.a, d, W + h->w16_out(l), d, b.x, d, P + o.out_b, nullptr, rows, d, d, 0, s))
+            return 1;
+        LEAF_TRY(leaf_launch_layernorm(b.x, P + o.ln2_w, P + o.ln2_b, c.ln_eps, b.a, rows, d, dt, s));
+        if (gemm(dt, EPI_ACT_T, b.a, d, W + h->w16_fc(l), d, b.hh, 4 * d, P + o.fc_b, nullptr, rows, 4 * d, d,
+                 c.activation, s))
+            return 1;
+        if (gemm(dt, EPI_RESID_F32, b.hh, 4 * d, W + h->w16_proj(l), 4 * d, b.x, d, P + o.proj_b, nullptr, rows, d,
+                 4 * d, 0, s))
+            return 1;
+    }
+    LEAF_TRY(leaf_launch_pool_project(b.x, tokens, P + h->lnf_w, P + h->lnf_b, c.ln_eps, P + h->text_proj, out, nullptr,
+                                      nullptr, cs, c.context_length, d, c.embed_dim, normalize, s));
+    return 0;
+}
+
+int forward_all(const leaf_text* h, const float* P, const void* W, const int32_t* tokens, int n_seq, float* out,
+                int normalize, Carver& c, hipStream_t s) {
+    const int cs = n_seq < h->chunk ? n_seq : h->chunk;
+    FwdBuf b = carve_fwd(h, c, cs);
+    if (!c.ok()) { leaf_set_error("workspace too small: need %zu bytes, have %zu", c.off, c.cap); return 1; }
+    for (int s0 = 0; s0 < n_seq; s0 += cs) {
+        const int n = n_seq - s0 < cs ? n_seq - s0 : cs;
+        if (forward_chunk(h, P, (const uint16_t*)W, tokens + (size_t)s0 * h->cfg.context_length, n,
+                          out + (size_t)s0 * h->cfg.embed_dim, normalize, b, s))
+            return 1;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" size_t leaf_text_workspace_bytes(leaf_text_t h, int n_seq, int mode) {
+    if (!h || n_seq < 1) return 0;
+    const int cs = n_seq < h->chunk ? n_seq : h->chunk;
+    size_t b = fwd_chunk_bytes(h, cs) + 256;
+    if (mode == 1) b += align_up((size_t)n_seq * h->cfg.embed_dim * 4, 256) + 256;
+    if (mode == 2) return leaf_train_ws_bytes(h, n_seq);
+    return b;
+}
+
+extern "C" int leaf_text_forward(leaf_text_t h, const float* params, const void* w16_fwd, const int32_t* tokens,
+                                 int n_seq, float* out, int normalize, void* ws, size_t ws_bytes, leaf_stream_t s) {
+    if (!h || !params || !w16_fwd || !tokens || !out || !ws || n_seq < 1) { leaf_set_error("null/invalid argument"); return 1; }
+    Carver c(ws, ws_bytes);
+    return forward_all(h, params, w16_fwd, tokens, n_seq, out, normalize, c, (hipStream_t)s);
+}
+
+extern "C" int leaf_score_candidates(leaf_text_t h, const float* params, const void* w16_fwd, const int32_t* tokens,
+                                     const float* anchor, int B, int rho, int objective, int32_t* best_idx,
+                                     float* best_feat, float* loss, void* ws, size_t ws_bytes, leaf_stream_t s) {
+    if (!h || !params || !w16_fwd || !tokens || !anchor || !best_idx || !ws || B < 1 || rho < 1) {
+        leaf_set_error("null/invalid argument");
+        return 1;
+    }
+    if (objective < 0 || objective > 3) { leaf_set_error("unknown objective %d", objective); return 1; }
+    Carver c(ws, ws_bytes);
+    const int n_seq = B * rho;
+    float* feat = (float*)c.take((size_t)n_seq * h->cfg.embed_dim * 4);
+    const int normalize = (objective == LEAF_OBJ_SIM || objective == LEAF_OBJ_DISSIM);
+    if (forward_all(h, params, w16_fwd, tokens, n_seq, feat, normalize, c, (hipStream_t)s)) return 1;
+    LEAF_TRY(leaf_launch_score(feat, anchor, B, rho, h->cfg.embed_dim, objective, best_idx, best_feat, loss,
+                               (hipStream_t)s));
+    return 0;
+}
+
+// ------------------------------------------------------------------ single-kernel hooks for the parity tests
+extern "C" int leaf_op_gemm(int dtype, int epi, const void* A, const void* B, void* C, const float* bias, void* aux,
+                            int M, int N, int K, int act, float beta, int aux_f16, leaf_stream_t s) {
+    return gemm(dtype, epi, A, K, B, K, C, N, bias, aux, M, N, K, act, (hipStream_t)s, beta, aux_f16);
+}
+extern "C" int leaf_op_attention_fwd(const void* qkv, void* out, int n_seq, int ctx, int heads, int width, int dtype,
+                                     leaf_stream_t s) {
+    return leaf_check(leaf_launch_attention_fwd(qkv, out, n_seq, ctx, heads, width, dtype, (hipStream_t)s), "attention_fwd");
+}
+extern "C" int leaf_op_layernorm(const float* x, const float* g, const float* b, float eps, void* out16, int rows,
+                                 int width, int dtype, leaf_stream_t s) {
+    return leaf_check(leaf_launch_layernorm(x, g, b, eps, out16, rows, width, dtype, (hipStream_t)s), "layernorm");
+}
+extern "C" int leaf_op_attention_bwd(const void* qkv, int qkv_dtype, const void* dout_bf16, void* dqkv_bf16, int n_seq,
+                                     int ctx, int heads, int width, leaf_stream_t s) {
+    return leaf_check(leaf_launch_attention_bwd(qkv, qkv_dtype, dout_bf16, dqkv_bf16, n_seq, ctx, heads, width,
+                                                (hipStream_t)s), "attention_bwd");
+}

@@ -1,0 +1,198 @@
+// C ABI, training half: forward with activation stash, TextFARE loss + backward into the flat gradient
+// buffer, fused AdamW.  Host orchestration only; see include/leaf_hip.h for the contract.
+#include "engine.h"
+
+namespace {
+
+struct Stash {
+    float* xin;      // [(L+1)][rows,d]  layer inputs; xin[L] = final residual stream
+    float* x1;       // [L][rows,d]      after the attention residual
+    uint16_t* xn1;   // [L][rows,d]
+    uint16_t* qkv;   // [L][rows,3d]
+    uint16_t* ao;    // [L][rows,d]
+    uint16_t* xn2;   // [L][rows,d]
+    uint16_t* pre;   // [L][rows,4d]
+    uint16_t* hh;    // [L][rows,4d]
+    float* pooled;   // [n,d]
+    int32_t* eot;    // [n]
+};
+
+Stash carve_stash(const leaf_text* h, Carver& c, int n_seq) {
+    const size_t rows = (size_t)n_seq * h->cfg.context_length, d = h->cfg.width, L = h->cfg.layers;
+    Stash s;
+    s.xin = (float*)c.take((L + 1) * rows * d * 4);
+    s.x1 = (float*)c.take(L * rows * d * 4);
+    s.xn1 = (uint16_t*)c.take(L * rows * d * 2);
+    s.qkv = (uint16_t*)c.take(L * rows * 3 * d * 2);
+    s.ao = (uint16_t*)c.take(L * rows * d * 2);
+    s.xn2 = (uint16_t*)c.take(L * rows * d * 2);
+    s.pre = (uint16_t*)c.take(L * rows * 4 * d * 2);
+    s.hh = (uint16_t*)c.take(L * rows * 4 * d * 2);
+    s.pooled = (float*)c.take((size_t)n_seq * d * 4);
+    s.eot = (int32_t*)c.take((size_t)n_seq * 4);
+    return s;
+}
+
+struct BwdBuf {
+    float* dx;        // [rows,d]
+    uint16_t* dx16;   // [rows,d] bf16
+    float* dxn;       // [rows,d]
+    uint16_t* big16;  // [rows,4d] bf16
+    uint16_t* dqkv;   // [rows,3d] bf16
+    uint16_t* do16;   // [rows,d] bf16
+    uint16_t* tA;     // [4d,rpad] bf16
+    uint16_t* tB;     // [4d,rpad] bf16
+    float* dout;      // [n,D]
+};
+
+BwdBuf carve_bwd(const leaf_text* h, Carver& c, int n_seq) {
+    const size_t rows = (size_t)n_seq * h->cfg.context_length, d = h->cfg.width;
+    const size_t rpad = align_up(rows, 64);
+    BwdBuf b;
+    b.dx = (float*)c.take(rows * d * 4);
+    b.dx16 = (uint16_t*)c.take(rows * d * 2);
+    b.dxn = (float*)c.take(rows * d * 4);
+    b.big16 = (uint16_t*)c.take(rows * 4 * d * 2);
+    b.dqkv = (uint16_t*)c.take(rows * 3 * d * 2);
+    b.do16 = (uint16_t*)c.take(rows * d * 2);
+    b.tA = (uint16_t*)c.take(4 * d * rpad * 2);
+    b.tB = (uint16_t*)c.take(4 * d * rpad * 2);
+    b.dout = (float*)c.take((size_t)n_seq * h->cfg.embed_dim * 4);
+    return b;
+}
+
+int gemm(int dtype, int epi, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias,
+         void* aux, int M, int N, int K, int act, hipStream_t s, float beta = 0.f, int aux_f16 = 0) {
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C; g.bias = bias; g.aux = aux;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.act = act; g.aux_f16 = aux_f16; g.beta = beta;
+    return leaf_check(leaf_launch_gemm(g, dtype, epi, s), "gemm");
+}
+
+}  // namespace
+
+size_t leaf_train_ws_bytes(const leaf_text* h, int n_seq) {
+    Carver c(nullptr, 0);
+    carve_bwd(h, c, n_seq);
+    return align_up(c.off, 256) + 256;
+}
+
+extern "C" size_t leaf_text_stash_bytes(leaf_text_t h, int n_seq) {
+    if (!h || n_seq < 1) return 0;
+    Carver c(nullptr, 0);
+    carve_stash(h, c, n_seq);
+    return align_up(c.off, 256) + 256;
+}
+
+extern "C" int leaf_text_forward_train(leaf_text_t h, const float* P, const void* w16_fwd, const int32_t* tokens,
+                                       int n_seq, float* out, void* stash, size_t stash_bytes, void* ws,
+                                       size_t ws_bytes, leaf_stream_t s_) {
+    (void)ws; (void)ws_bytes;
+    if (!h || !P || !w16_fwd || !tokens || !out || !stash || n_seq < 1) { leaf_set_error("null/invalid argument"); return 1; }
+    hipStream_t s = (hipStream_t)s_;
+    Carver c(stash, stash_bytes);
+    Stash st = carve_stash(h, c, n_seq);
+    if (!c.ok()) { leaf_set_error("stash too small: need %zu bytes, have %zu", c.off, c.cap); return 1; }
+    const leaf_text_cfg& cf = h->cfg;
+    const int d = cf.width, rows = n_seq * cf.context_length, dt = h->fwd_dtype, L = cf.layers;
+    const size_t rd = (size_t)rows * d;
+    const uint16_t* W = (const uint16_t*)w16_fwd;
+    LEAF_TRY(leaf_launch_embed_ln(tokens, P + h->tok_emb, P + h->pos_emb, P + h->layer[0].ln1_w, P + h->layer[0].ln1_b,
+                                  cf.ln_eps, st.xin, st.xn1, rows, cf.context_length, d, cf.vocab_size, dt, s));
+    for (int l = 0; l < L; ++l) {
+        const LayerOff& o = h->layer[l];
+        float* xin = st.xin + l * rd; float* x1 = st.x1 + l * rd; float* xout = st.xin + (l + 1) * rd;
+        uint16_t* xn1 = st.xn1 + l * rd; uint16_t* qkv = st.qkv + 3 * l * rd; uint16_t* ao = st.ao + l * rd;
+        uint16_t* xn2 = st.xn2 + l * rd; uint16_t* pre = st.pre + 4 * l * rd; uint16_t* hh = st.hh + 4 * l * rd;
+        if (l > 0) LEAF_TRY(leaf_launch_layernorm(xin, P + o.ln1_w, P + o.ln1_b, cf.ln_eps, xn1, rows, d, dt, s));
+        if (gemm(dt, EPI_STORE_T, xn1, d, W + h->w16_qkv(l), d, qkv, 3 * d, P + o.qkv_b, nullptr, rows, 3 * d, d, 0, s)) return 1;
+        LEAF_TRY(leaf_launch_attention_fwd(qkv, ao, n_seq, cf.context_length, cf.heads, d, dt, s));
+        LEAF_TRY(hipMemcpyAsync(x1, xin, rd * 4, hipMemcpyDeviceToDevice, s));
+        if (gemm(dt, EPI_RESID_F32, ao, d, W + h->w16_out(l), d, x1, d, P + o.out_b, nullptr, rows, d, d, 0, s)) return 1;
+        LEAF_TRY(leaf_launch_layernorm(x1, P + o.ln2_w, P + o.ln2_b, cf.ln_eps, xn2, rows, d, dt, s));
+        if (gemm(dt, EPI_ACT_T, xn2, d, W + h->w16_fc(l), d, hh, 4 * d, P + o.fc_b, pre, rows, 4 * d, d, cf.activation, s)) return 1;
+        LEAF_TRY(hipMemcpyAsync(xout, x1, rd * 4, hipMemcpyDeviceToDevice, s));
+        if (gemm(dt, EPI_RESID_F32, hh, 4 * d, W + h->w16_proj(l), 4 * d, xout, d, P + o.proj_b, nullptr, rows, d, 4 * d, 0, s)) return 1;
+    }
+    LEAF_TRY(leaf_launch_pool_project(st.xin + (size_t)L * rd, tokens, P + h->lnf_w, P + h->lnf_b, cf.ln_eps,
+                                      P + h->text_proj, out, st.pooled, st.eot, n_seq, cf.context_length, d,
+                                      cf.embed_dim, 0, s));
+    return 0;
+}
+
+extern "C" int leaf_textfare_backward(leaf_text_t h, const float* P, const void* w16_bwd, const int32_t* tokens,
+                                      int n_seq, const float* feat, const float* anchor, float accum_scale,
+                                      const void* stash, float* G, float* loss_out, void* ws, size_t ws_bytes,
+                                      leaf_stream_t s_) {
+    if (!h || !P || !w16_bwd || !tokens || !feat || !anchor || !stash || !G || !ws || n_seq < 1) {
+        leaf_set_error("null/invalid argument");
+        return 1;
+    }
+    hipStream_t s = (hipStream_t)s_;
+    Carver cs((void*)stash, (size_t)-1);
+    Stash st = carve_stash(h, cs, n_seq);
+    Carver cw(ws, ws_bytes);
+    BwdBuf b = carve_bwd(h, cw, n_seq);
+    if (!cw.ok()) { leaf_set_error("workspace too small: need %zu bytes, have %zu", cw.off, cw.cap); return 1; }
+    const leaf_text_cfg& cf = h->cfg;
+    const int d = cf.width, rows = n_seq * cf.context_length, L = cf.layers, D = cf.embed_dim;
+    const int rpad = (int)align_up((size_t)rows, 64);
+    const size_t rd = (size_t)rows * d;
+    const int fk = h->fwd_dtype == LEAF_DTYPE_FP16 ? 1 : 0;  // source kind of stashed activations
+    const uint16_t* WT = (const uint16_t*)w16_bwd;
+
+    // dW[Nw,Kw] += dY^T X  via  NT GEMM on transposed bf16 copies
+    auto wgrad = [&](const uint16_t* dY, int Nw, const void* X, int xkind, int Kw, float* dW) -> int {
+        LEAF_TRY(leaf_launch_transpose_bf16(dY, 0, b.tA, rows, Nw, Nw, rpad, s));
+        LEAF_TRY(leaf_launch_transpose_bf16(X, xkind, b.tB, rows, Kw, Kw, rpad, s));
+        return gemm(LEAF_BF16, EPI_STORE_F32, b.tA, rpad, b.tB, rpad, dW, Kw, nullptr, nullptr, Nw, Kw, rpad, 0, s, 1.0f);
+    };
+
+    LEAF_TRY(leaf_launch_fare_loss(feat, anchor, n_seq, D, accum_scale, loss_out, b.dout, s));
+    LEAF_TRY(hipMemsetAsync(b.dx, 0, rd * 4, s));
+    LEAF_TRY(leaf_launch_pool_project_bwd(b.dout, st.pooled, st.xin + (size_t)L * rd, st.eot, P + h->lnf_w, P + h->lnf_b,
+                                          cf.ln_eps, P + h->text_proj, b.dx, G + h->text_proj, G + h->lnf_w,
+                                          G + h->lnf_b, n_seq, cf.context_length, d, D, s));
+    LEAF_TRY(leaf_launch_f32_to_bf16_rows(b.dx, b.dx16, rd, s));
+
+    for (int l = L - 1; l >= 0; --l) {
+        const LayerOff& o = h->layer[l];
+        const float* xin = st.xin + l * rd; const float* x1 = st.x1 + l * rd;
+        const uint16_t* xn1 = st.xn1 + l * rd; const uint16_t* qkv = st.qkv + 3 * l * rd; const uint16_t* ao = st.ao + l * rd;
+        const uint16_t* xn2 = st.xn2 + l * rd; const uint16_t* pre = st.pre + 4 * l * rd; const uint16_t* hh = st.hh + 4 * l * rd;
+        // ---- MLP
+        if (wgrad(b.dx16, d, hh, fk, 4 * d, G + o.proj_w)) return 1;
+        LEAF_TRY(leaf_launch_colsum(b.dx16, d, rows, d, G + o.proj_b, s));
+        if (gemm(LEAF_BF16, EPI_ACTGRAD_T, b.dx16, d, WT + h->w16_proj(l), d, b.big16, 4 * d, nullptr, (void*)pre, rows,
+                 4 * d, d, cf.activation, s, 0.f, fk)) return 1;
+        if (wgrad(b.big16, 4 * d, xn2, fk, d, G + o.fc_w)) return 1;
+        LEAF_TRY(leaf_launch_colsum(b.big16, 4 * d, rows, 4 * d, G + o.fc_b, s));
+        if (gemm(LEAF_BF16, EPI_STORE_F32, b.big16, 4 * d, WT + h->w16_fc(l), 4 * d, b.dxn, d, nullptr, nullptr, rows, d,
+                 4 * d, 0, s)) return 1;
+        LEAF_TRY(leaf_launch_layernorm_bwd(b.dxn, x1, P + o.ln2_w, cf.ln_eps, b.dx, b.dx16, G + o.ln2_w, G + o.ln2_b,
+                                           rows, d, s));
+        // ---- attention
+        if (wgrad(b.dx16, d, ao, fk, d, G + o.out_w)) return 1;
+        LEAF_TRY(leaf_launch_colsum(b.dx16, d, rows, d, G + o.out_b, s));
+        if (gemm(LEAF_BF16, EPI_STORE_T, b.dx16, d, WT + h->w16_out(l), d, b.do16, d, nullptr, nullptr, rows, d, d, 0, s)) return 1;
+        LEAF_TRY(leaf_launch_attention_bwd(qkv, h->fwd_dtype, b.do16, b.dqkv, n_seq, cf.context_length, cf.heads, d, s));
+        if (wgrad(b.dqkv, 3 * d, xn1, fk, d, G + o.qkv_w)) return 1;
+        LEAF_TRY(leaf_launch_colsum(b.dqkv, 3 * d, rows, 3 * d, G + o.qkv_b, s));
+        if (gemm(LEAF_BF16, EPI_STORE_F32, b.dqkv, 3 * d, WT + h->w16_qkv(l), 3 * d, b.dxn, d, nullptr, nullptr, rows, d,
+                 3 * d, 0, s)) return 1;
+        LEAF_TRY(leaf_launch_layernorm_bwd(b.dxn, xin, P + o.ln1_w, cf.ln_eps, b.dx, b.dx16, G + o.ln1_w, G + o.ln1_b,
+                                           rows, d, s));
+    }
+    LEAF_TRY(leaf_launch_embed_bwd(b.dx, tokens, G + h->tok_emb, G + h->pos_emb, rows, cf.context_length, d,
+                                   cf.vocab_size, s));
+    return 0;
+}
+
+extern "C" int leaf_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n,
+                               size_t n_decay, float lr, float beta1, float beta2, float eps, float wd, int step,
+                               float grad_scale, leaf_stream_t s) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq) { leaf_set_error("null argument"); return 1; }
+    return leaf_check(leaf_launch_adamw(params, grads, exp_avg, exp_avg_sq, n, n_decay, lr, beta1, beta2, eps, wd, step,
+                                        grad_scale, (hipStream_t)s), "adamw");
+}

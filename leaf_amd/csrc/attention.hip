@@ -1,0 +1,195 @@
+// Causal multi-head self-attention for context <= 96 (CLIP text: 77), head_dim 64, forward only.
+//
+// Reference: nn.MultiheadAttention(batch_first) with an additive causal mask
+// (src/open_clip/transformer.py:225,239-252,758-764): softmax(q k^T / sqrt(64) + mask) v per head.
+//
+// One WAVE owns one (sequence, head).  Everything stays on chip:
+//   * K fragments (<= 6 key tiles x 2 k-steps) are loaded straight from HBM into registers in MFMA
+//     fragment shape (16 B per lane); Q fragments likewise per 16-row query tile.
+//   * V is copied row-major into LDS once and consumed COLUMN-wise as the MFMA A operand through the
+//     gfx950 transposing read ds_read_b64_tr_b16 (no software transpose).
+//   * scores are computed TRANSPOSED (S^T = K Q^T, MFMA 16x16x32): a lane then holds 4 consecutive
+//     keys of ONE query per tile, so the row softmax is in-lane plus two wave shuffles (xor 16, 32).
+//   * P goes through a 3 KiB LDS tile as the B operand of O^T = V^T P^T; the accumulator then holds
+//     4 consecutive head dims of one query -> 8-byte stores.
+// Causality skips key tiles above the diagonal; rows >= ctx are clamped on load and never stored.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int HD = 64;          // head dim (all CLIP text towers)
+constexpr int MAXT = 6;         // 16-row tiles -> ctx <= 96
+constexpr int V_LD = 72;        // LDS V row stride (elements): 144 B, 16-B aligned
+constexpr int P_LD = 104;       // LDS P row stride (elements): 208 B, 16-B aligned
+constexpr int V_BYTES = 96 * V_LD * 2;
+constexpr int P_BYTES = 16 * P_LD * 2;
+constexpr int WAVE_LDS = V_BYTES + P_BYTES;  // 17,152 B
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+template <class TT, bool USE_TR>
+__device__ __forceinline__ typename TT::vec8 load_vt_frag(const char* vlds, int key0, int dim0, int lane) {
+    // A-operand fragment of V^T: lane holds V[key0 + 8*(lane>>4) + j][dim0 + (lane&15)], j = 0..7
+    const int g = lane >> 4, i = lane & 15;
+    if constexpr (USE_TR) {
+        // ds_read_b64_tr_b16: per 16-lane group a 4x16 block; lane 4q+p supplies row q, cols 4p..4p+3,
+        // lane i receives column i of the 4 rows.
+        const int q = i >> 2, p = i & 3;
+        const char* a0 = vlds + (key0 + 8 * g + q) * (V_LD * 2) + (dim0 + 4 * p) * 2;
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * V_LD * 2));
+        s16x8 r;
+        r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+        r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+        return __builtin_bit_cast(typename TT::vec8, r);
+    } else {
+        s16x8 r;
+        const short* base = (const short*)vlds + (key0 + 8 * g) * V_LD + dim0 + i;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = base[j * V_LD];
+        return __builtin_bit_cast(typename TT::vec8, r);
+    }
+}
+
+template <class TT, bool USE_TR>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const u16* __restrict__ qkv, u16* __restrict__ out, int n_items,
+                                                       int ctx, int heads, int d) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int item = blockIdx.x * 4 + wid;
+    if (item >= n_items) return;   // whole wave exits together (item is wave-uniform)
+    char* vlds = smem + wid * WAVE_LDS;
+    char* plds = vlds + V_BYTES;
+    const int n = item / heads, h = item % heads;
+    const int ld = 3 * d;
+    const u16* base = qkv + (size_t)n * ctx * ld + h * HD;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int nt = (ctx + 15) >> 4;
+
+    // ---- V rows -> LDS (row-major), rows ctx..95 zero
+    for (int idx = lane; idx < 96 * 8; idx += 64) {
+        const int key = idx >> 3, ch = idx & 7;
+        uint4 v = uint4{0u, 0u, 0u, 0u};
+        if (key < ctx) v = *(const uint4*)(base + (size_t)key * ld + 2 * d + ch * 8);
+        *(uint4*)(vlds + key * (V_LD * 2) + ch * 16) = v;
+    }
+    // ---- K fragments -> registers
+    typename TT::vec8 kf[MAXT][2];
+#pragma unroll
+    for (int kt = 0; kt < MAXT; ++kt) {
+        if (kt < nt) {
+            int row = kt * 16 + r16; row = row < ctx ? row : ctx - 1;
+            const u16* kp = base + (size_t)row * ld + d + g * 8;
+            kf[kt][0] = __builtin_bit_cast(typename TT::vec8, *(const uint4*)(kp));
+            kf[kt][1] = __builtin_bit_cast(typename TT::vec8, *(const uint4*)(kp + 32));
+        }
+    }
+
+#pragma unroll
+    for (int qt = 0; qt < MAXT; ++qt) {
+        if (qt < nt) {
+            const int qidx = qt * 16 + r16;
+            const int qv = qidx < ctx ? qidx : ctx - 1;
+            const u16* qp = base + (size_t)qv * ld + g * 8;
+            typename TT::vec8 qf0 = __builtin_bit_cast(typename TT::vec8, *(const uint4*)(qp));
+            typename TT::vec8 qf1 = __builtin_bit_cast(typename TT::vec8, *(const uint4*)(qp + 32));
+            // S^T tiles for key tiles 0..qt
+            f32x4 sc[MAXT];
+            float m = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt <= qt; ++kt) {
+                f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+                a = TT::mfma(kf[kt][0], qf0, a);
+                a = TT::mfma(kf[kt][1], qf1, a);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int kidx = kt * 16 + 4 * g + e;
+                    float s = a[e] * 0.125f;
+                    s = kidx > qv ? -INFINITY : s;
+                    a[e] = s;
+                    m = __builtin_fmaxf(m, s);
+                }
+                sc[kt] = a;
+            }
+            m = __builtin_fmaxf(m, __shfl_xor(m, 16, 64));
+            m = __builtin_fmaxf(m, __shfl_xor(m, 32, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt <= qt; ++kt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float p = __expf(sc[kt][e] - m);
+                    sc[kt][e] = p;
+                    sum += p;
+                }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = 1.0f / sum;
+            // P -> LDS [16 q][keys], zero-filled up to the k-step boundary
+            constexpr int dummy = 0; (void)dummy;
+            const int nks = (qt + 2) >> 1;
+#pragma unroll
+            for (int kt = 0; kt < MAXT; ++kt) {
+                if (kt < 2 * nks) {
+                    uint2 pk = uint2{0u, 0u};
+                    if (kt <= qt) pk = pack4<TT>(sc[kt][0] * inv, sc[kt][1] * inv, sc[kt][2] * inv, sc[kt][3] * inv);
+                    *(uint2*)(plds + r16 * (P_LD * 2) + (kt * 16 + 4 * g) * 2) = pk;
+                }
+            }
+            // O^T[dim][q] = sum_k V^T[dim][k] P^T[k][q]
+            f32x4 o[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                if (ks < nks) {
+                    typename TT::vec8 pf =
+                        *(const typename TT::vec8*)(plds + r16 * (P_LD * 2) + (ks * 32 + 8 * g) * 2);
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        typename TT::vec8 vf = load_vt_frag<TT, USE_TR>(vlds, ks * 32, dt * 16, lane);
+                        o[dt] = TT::mfma(vf, pf, o[dt]);
+                    }
+                }
+            }
+            if (qidx < ctx) {
+                u16* op = out + ((size_t)n * ctx + qidx) * d + h * HD + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    *(uint2*)(op + dt * 16) = pack4<TT>(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t leaf_launch_attention_fwd(const void* qkv, void* out, int n_seq, int ctx, int heads, int d, int dtype,
+                                     hipStream_t s) {
+    if (d != heads * HD || ctx > 16 * MAXT || ctx < 1) return hipErrorInvalidValue;
+    static int use_tr = -1;
+    if (use_tr < 0) {
+        const char* e = getenv("LEAF_ATTN_TR");
+        use_tr = (e && e[0] == '0') ? 0 : 1;
+    }
+    const int items = n_seq * heads;
+    const dim3 grid((items + 3) / 4), blk(256);
+    const size_t lds = 4 * WAVE_LDS;
+#define LEAF_ATTN(TT, TR)                                                                                   \
+    do {                                                                                                    \
+        static bool attr = false;                                                                           \
+        if (!attr) {                                                                                        \
+            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<TT, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)lds);                                                                  \
+            attr = true;                                                                                    \
+        }                                                                                                   \
+        hipLaunchKernelGGL((attn_fwd_kernel<TT, TR>), grid, blk, lds, s, (const u16*)qkv, (u16*)out, items, ctx, heads, d); \
+    } while (0)
+    if (dtype == LEAF_F16) { if (use_tr) LEAF_ATTN(F16, true); else LEAF_ATTN(F16, false); }
+    else                   { if (use_tr) LEAF_ATTN(BF16, true); else LEAF_ATTN(BF16, false); }
+#undef LEAF_ATTN
+    return hipGetLastError();
+}

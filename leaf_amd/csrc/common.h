@@ -1,0 +1,84 @@
+// Shared device helpers for the LEAF text-path kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint16_t u16;
+
+// 16-bit MFMA operand traits.  Both run v_mfma_f32_16x16x32_* at the same rate; F16 carries
+// 11 significand bits (forward / scoring path), BF16 carries fp32's exponent (gradient path).
+struct F16 {
+    using elem = _Float16;
+    using vec8 = f16x8;
+    using vec4 = f16x4;
+    static __device__ __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ elem from_f32(float x) {
+        x = __builtin_fminf(__builtin_fmaxf(x, -65504.f), 65504.f);  // saturate, never inf
+        return (_Float16)x;                                           // v_cvt_f16_f32, RTN-even
+    }
+    static __device__ __forceinline__ float to_f32(elem x) { return (float)x; }
+};
+struct BF16 {
+    using elem = __bf16;
+    using vec8 = bf16x8;
+    using vec4 = bf16x4;
+    static __device__ __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ elem from_f32(float x) { return (__bf16)x; }  // RTN-even, NaN kept
+    static __device__ __forceinline__ float to_f32(elem x) { return (float)x; }
+};
+
+template <class TT>
+__device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
+    typename TT::vec4 v;
+    v[0] = TT::from_f32(a); v[1] = TT::from_f32(b); v[2] = TT::from_f32(c); v[3] = TT::from_f32(d);
+    return __builtin_bit_cast(uint2, v);
+}
+template <class TT>
+__device__ __forceinline__ void unpack4(uint2 u, float (&o)[4]) {
+    typename TT::vec4 v = __builtin_bit_cast(typename TT::vec4, u);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = TT::to_f32(v[i]);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = __builtin_fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+enum { ACT_GELU = 0, ACT_QUICKGELU = 1 };
+
+__device__ __forceinline__ float act_fwd(float x, int act) {
+    if (act == ACT_QUICKGELU) return x / (1.f + __expf(-1.702f * x));
+    return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+}
+__device__ __forceinline__ float act_bwd(float x, int act) {
+    if (act == ACT_QUICKGELU) {
+        float s = 1.f / (1.f + __expf(-1.702f * x));
+        return s * (1.f + 1.702f * x * (1.f - s));
+    }
+    float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+    float pdf = __expf(-0.5f * x * x) * 0.3989422804014327f;
+    return cdf + x * pdf;
+}
+
+// XCD-aware bijective remap of a 1-D grid: blocks that share an XCD (bid % 8) get a contiguous
+// range of logical ids, so neighbouring tiles (same A panel) hit one XCD's L2.  Speed only.
+__device__ __forceinline__ int xcd_remap(int bid, int nb) {
+    int q = nb >> 3, r = nb & 7, x = bid & 7, slot = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + slot;
+}

@@ -1,0 +1,316 @@
+// HBM-bound forward kernels of the text path: token gather + positional add + LayerNorm, LayerNorm,
+// EOT pooling + final LayerNorm + projection, and the LEAF selection arithmetic (squared-L2 / cosine
+// loss per candidate + first-index arg-max over rho + winner gather).
+//
+// Reference semantics: src/open_clip/model.py:269-284 (encode_text), transformer.py:15-30 (LayerNorm,
+// eps 1e-5, fp32 statistics), transformer.py:653-665 (argmax pooling), utils_attacks.py:332-348.
+// All rows are handled by ONE wave (64 lanes x float4), so every reduction is a wave shuffle and
+// every global access is a coalesced 16-B-per-lane load/store.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int MAXCH = 8;  // float4 chunks per lane -> d <= 2048
+
+template <class TT>
+__device__ __forceinline__ void ln_row_store(const float4 (&v)[MAXCH], int nq, int lane, const float* __restrict__ g,
+                                             const float* __restrict__ b, float eps, int d, u16* __restrict__ xn_row) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        int c = lane + 64 * i;
+        if (c < nq) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mu = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        int c = lane + 64 * i;
+        if (c < nq) {
+            float a0 = v[i].x - mu, a1 = v[i].y - mu, a2 = v[i].z - mu, a3 = v[i].w - mu;
+            q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        int c = lane + 64 * i;
+        if (c < nq) {
+            float4 gg = *(const float4*)(g + 4 * c), bb = *(const float4*)(b + 4 * c);
+            *(uint2*)(xn_row + 4 * c) = pack4<TT>((v[i].x - mu) * rstd * gg.x + bb.x, (v[i].y - mu) * rstd * gg.y + bb.y,
+                                                  (v[i].z - mu) * rstd * gg.z + bb.z, (v[i].w - mu) * rstd * gg.w + bb.w);
+        }
+    }
+}
+
+template <class TT, bool EMBED>
+__global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x_in, const int32_t* __restrict__ tokens,
+                                                 const float* __restrict__ tok_emb, const float* __restrict__ pos_emb,
+                                                 const float* __restrict__ g, const float* __restrict__ b, float eps,
+                                                 float* __restrict__ x_out, u16* __restrict__ xn, int rows, int ctx, int d,
+                                                 int vocab) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nq = d >> 2;
+    float4 v[MAXCH];
+    if constexpr (EMBED) {
+        int tok = tokens[row];
+        tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
+        const float* te = tok_emb + (size_t)tok * d;
+        const float* pe = pos_emb + (size_t)(row % ctx) * d;
+        float* xo = x_out + (size_t)row * d;
+#pragma unroll
+        for (int i = 0; i < MAXCH; ++i) {
+            int c = lane + 64 * i;
+            if (c < nq) {
+                float4 a = *(const float4*)(te + 4 * c), p = *(const float4*)(pe + 4 * c);
+                v[i] = float4{a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w};
+                *(float4*)(xo + 4 * c) = v[i];
+            }
+        }
+    } else {
+        const float* xi = x_in + (size_t)row * d;
+#pragma unroll
+        for (int i = 0; i < MAXCH; ++i) {
+            int c = lane + 64 * i;
+            if (c < nq) v[i] = *(const float4*)(xi + 4 * c);
+        }
+    }
+    ln_row_store<TT>(v, nq, lane, g, b, eps, d, xn + (size_t)row * d);
+}
+
+// ---------------------------------------------------------------- pooling + final LN + projection
+constexpr int PR = 8;      // sequences per block
+constexpr int JJMAX = 8;   // output columns per thread -> D <= 2048
+
+__global__ __launch_bounds__(256) void pool_project_kernel(const float* __restrict__ x, const int32_t* __restrict__ tokens,
+                                                           const float* __restrict__ g, const float* __restrict__ b,
+                                                           float eps, const float* __restrict__ proj,
+                                                           float* __restrict__ out, float* __restrict__ pooled,
+                                                           int32_t* __restrict__ eot_idx, int n_seq, int ctx, int d, int D,
+                                                           int normalize) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* xs = (float*)smem;               // [PR][d]
+    float* red = xs + PR * d;               // [4][PR]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int s0 = blockIdx.x * PR;
+    const int nq = d >> 2;
+    // phase 1: each wave pools + normalises two sequences
+    for (int rr = wid; rr < PR; rr += 4) {
+        const int n = s0 + rr;
+        float* xr = xs + rr * d;
+        if (n >= n_seq) {
+            for (int c = lane; c < d; c += 64) xr[c] = 0.f;
+            continue;
+        }
+        // first index of the maximum token id (torch argmax)
+        int bv = -2147483647 - 1, bi = 0;
+        for (int p = lane; p < ctx; p += 64) {
+            int t = tokens[(size_t)n * ctx + p];
+            if (t > bv) { bv = t; bi = p; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            int ov = __shfl_xor(bv, o, 64), oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (eot_idx && lane == 0) eot_idx[n] = bi;
+        const float* xi = x + ((size_t)n * ctx + bi) * d;
+        float4 v[MAXCH];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXCH; ++i) {
+            int c = lane + 64 * i;
+            if (c < nq) { v[i] = *(const float4*)(xi + 4 * c); s += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
+        }
+        const float mu = wave_sum(s) / (float)d;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXCH; ++i) {
+            int c = lane + 64 * i;
+            if (c < nq) {
+                float a0 = v[i].x - mu, a1 = v[i].y - mu, a2 = v[i].z - mu, a3 = v[i].w - mu;
+                q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
+#pragma unroll
+        for (int i = 0; i < MAXCH; ++i) {
+            int c = lane + 64 * i;
+            if (c < nq) {
+                float4 gg = *(const float4*)(g + 4 * c), bb = *(const float4*)(b + 4 * c);
+                float4 y = float4{(v[i].x - mu) * rstd * gg.x + bb.x, (v[i].y - mu) * rstd * gg.y + bb.y,
+                                  (v[i].z - mu) * rstd * gg.z + bb.z, (v[i].w - mu) * rstd * gg.w + bb.w};
+                *(float4*)(xr + 4 * c) = y;
+                if (pooled) *(float4*)(pooled + (size_t)n * d + 4 * c) = y;
+            }
+        }
+    }
+    __syncthreads();
+    // phase 2: out[r][j] = sum_k xs[r][k] * proj[k][j]; thread owns columns tid + 256*jj
+    float acc[JJMAX][PR];
+#pragma unroll
+    for (int jj = 0; jj < JJMAX; ++jj)
+#pragma unroll
+        for (int r = 0; r < PR; ++r) acc[jj][r] = 0.f;
+    for (int k = 0; k < d; ++k) {
+        float xv[PR];
+#pragma unroll
+        for (int r = 0; r < PR; ++r) xv[r] = xs[r * d + k];
+#pragma unroll
+        for (int jj = 0; jj < JJMAX; ++jj) {
+            int j = tid + 256 * jj;
+            if (j < D) {
+                float pv = proj[(size_t)k * D + j];
+#pragma unroll
+                for (int r = 0; r < PR; ++r) acc[jj][r] = fmaf(xv[r], pv, acc[jj][r]);
+            }
+        }
+    }
+    if (normalize) {
+        float ss[PR];
+#pragma unroll
+        for (int r = 0; r < PR; ++r) {
+            float s = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < JJMAX; ++jj) s += acc[jj][r] * acc[jj][r];
+            ss[r] = wave_sum(s);
+        }
+        if (lane == 0)
+#pragma unroll
+            for (int r = 0; r < PR; ++r) red[wid * PR + r] = ss[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < PR; ++r) {
+            float tot = red[r] + red[PR + r] + red[2 * PR + r] + red[3 * PR + r];
+            float inv = 1.0f / fmaxf(sqrtf(tot), 1e-12f);   // F.normalize eps
+#pragma unroll
+            for (int jj = 0; jj < JJMAX; ++jj) acc[jj][r] *= inv;
+        }
+    }
+#pragma unroll
+    for (int jj = 0; jj < JJMAX; ++jj) {
+        int j = tid + 256 * jj;
+        if (j < D)
+#pragma unroll
+            for (int r = 0; r < PR; ++r)
+                if (s0 + r < n_seq) out[(size_t)(s0 + r) * D + j] = acc[jj][r];
+    }
+}
+
+// ---------------------------------------------------------------- candidate loss + arg-max
+__global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ feat, const float* __restrict__ anchor,
+                                                    int rho, int D, int objective, int32_t* __restrict__ best_idx,
+                                                    float* __restrict__ best_feat, float* __restrict__ loss_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ls = (float*)smem;  // [rho]
+    __shared__ int s_best;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const float* a = anchor + (size_t)b * D;
+    for (int r = wid; r < rho; r += 4) {
+        const float* f = feat + ((size_t)b * rho + r) * D;
+        float s = 0.f;
+        if (objective <= 1) {
+            for (int j = lane; j < D; j += 64) { float t = f[j] - a[j]; s = fmaf(t, t, s); }
+        } else {
+            for (int j = lane; j < D; j += 64) s = fmaf(f[j], a[j], s);
+        }
+        s = wave_sum(s);
+        if (objective == 1 || objective == 2) s = -s;  // 0 l2, 1 negl2, 2 dissim, 3 sim
+        if (lane == 0) { ls[r] = s; if (loss_out) loss_out[(size_t)b * rho + r] = s; }
+    }
+    __syncthreads();
+    if (wid == 0) {
+        float bv = -INFINITY; int bi = 0x7fffffff;
+        for (int r = lane; r < rho; r += 64) {
+            float v = ls[r];
+            if (v > bv || bi == 0x7fffffff) { if (v > bv || bi == 0x7fffffff) { bv = v; bi = r; } }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            float ov = __shfl_xor(bv, o, 64); int oi = __shfl_xor(bi, o, 64);
+            if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { s_best = bi; best_idx[b] = bi; }
+    }
+    __syncthreads();
+    const float* f = feat + ((size_t)b * rho + s_best) * D;
+    if (best_feat)
+        for (int j = tid; j < D; j += 256) best_feat[(size_t)b * D + j] = f[j];
+}
+
+template <class TT>
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, u16* __restrict__ dst, size_t n4) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < n4; i += stride) {
+        float4 v = *(const float4*)(src + 4 * i);
+        *(uint2*)(dst + 4 * i) = pack4<TT>(v.x, v.y, v.z, v.w);
+    }
+}
+
+}  // namespace
+
+hipError_t leaf_launch_embed_ln(const int32_t* tokens, const float* tok_emb, const float* pos_emb, const float* g,
+                                const float* b, float eps, float* x, void* xn, int rows, int ctx, int d, int vocab,
+                                int dtype, hipStream_t s) {
+    if (d % 4 || d > 256 * MAXCH) return hipErrorInvalidValue;
+    dim3 grid((rows + 3) / 4), blk(256);
+    if (dtype == LEAF_F16)
+        hipLaunchKernelGGL((ln_kernel<F16, true>), grid, blk, 0, s, nullptr, tokens, tok_emb, pos_emb, g, b, eps, x,
+                           (u16*)xn, rows, ctx, d, vocab);
+    else
+        hipLaunchKernelGGL((ln_kernel<BF16, true>), grid, blk, 0, s, nullptr, tokens, tok_emb, pos_emb, g, b, eps, x,
+                           (u16*)xn, rows, ctx, d, vocab);
+    return hipGetLastError();
+}
+
+hipError_t leaf_launch_layernorm(const float* x, const float* g, const float* b, float eps, void* xn, int rows, int d,
+                                 int dtype, hipStream_t s) {
+    if (d % 4 || d > 256 * MAXCH) return hipErrorInvalidValue;
+    dim3 grid((rows + 3) / 4), blk(256);
+    if (dtype == LEAF_F16)
+        hipLaunchKernelGGL((ln_kernel<F16, false>), grid, blk, 0, s, x, nullptr, nullptr, nullptr, g, b, eps, nullptr,
+                           (u16*)xn, rows, 1, d, 0);
+    else
+        hipLaunchKernelGGL((ln_kernel<BF16, false>), grid, blk, 0, s, x, nullptr, nullptr, nullptr, g, b, eps, nullptr,
+                           (u16*)xn, rows, 1, d, 0);
+    return hipGetLastError();
+}
+
+hipError_t leaf_launch_pool_project(const float* x, const int32_t* tokens, const float* g, const float* b, float eps,
+                                    const float* proj, float* out, float* pooled, int32_t* eot_idx, int n_seq, int ctx,
+                                    int d, int D, int normalize, hipStream_t s) {
+    if (d % 4 || d > 256 * MAXCH || D > 256 * JJMAX) return hipErrorInvalidValue;
+    size_t lds = (size_t)(PR * d + 4 * PR) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)pool_project_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL(pool_project_kernel, dim3((n_seq + PR - 1) / PR), dim3(256), lds, s, x, tokens, g, b, eps, proj,
+                       out, pooled, eot_idx, n_seq, ctx, d, D, normalize);
+    return hipGetLastError();
+}
+
+hipError_t leaf_launch_score(const float* feat, const float* anchor, int B, int rho, int D, int objective,
+                             int32_t* best_idx, float* best_feat, float* loss, hipStream_t s) {
+    if (rho <= 0 || rho > 8192 || objective < 0 || objective > 3) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(score_kernel, dim3(B), dim3(256), rho * sizeof(float), s, feat, anchor, rho, D, objective,
+                       best_idx, best_feat, loss);
+    return hipGetLastError();
+}
+
+hipError_t leaf_launch_cast(const float* src, void* dst, size_t n, int dtype, hipStream_t s) {
+    if (n % 4) return hipErrorInvalidValue;
+    size_t n4 = n / 4;
+    int grid = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    if (grid == 0) return hipSuccess;
+    if (dtype == LEAF_F16)
+        hipLaunchKernelGGL((cast_kernel<F16>), dim3(grid), dim3(256), 0, s, src, (u16*)dst, n4);
+    else
+        hipLaunchKernelGGL((cast_kernel<BF16>), dim3(grid), dim3(256), 0, s, src, (u16*)dst, n4);
+    return hipGetLastError();
+}

@@ -1,0 +1,59 @@
+// Host-side handle shared by api.hip (inference / scoring) and api_train.hip (training step).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/leaf_hip.h"
+#include "kernels.h"
+
+struct TensorInfo {
+    std::string name;
+    size_t offset;
+    int64_t rows, cols;  // cols == 0 -> 1-D
+    size_t numel() const { return (size_t)rows * (cols ? cols : 1); }
+};
+
+struct LayerOff {  // offsets (floats) into the flat parameter buffer
+    size_t ln1_w, ln1_b, qkv_w, qkv_b, out_w, out_b, ln2_w, ln2_b, fc_w, fc_b, proj_w, proj_b;
+};
+
+struct leaf_text {
+    leaf_text_cfg cfg;
+    int fwd_dtype;
+    int chunk;  // sequences per pass
+    std::vector<TensorInfo> tensors;
+    std::vector<LayerOff> layer;
+    size_t tok_emb, pos_emb, text_proj, lnf_w, lnf_b;
+    size_t n_params, n_decay;
+    // element offsets into the 16-bit weight pack, per layer: qkv, out, fc, proj (12 d^2 per layer)
+    size_t w16_layer_elems() const { return (size_t)12 * cfg.width * cfg.width; }
+    size_t w16_qkv(int l) const { return l * w16_layer_elems(); }
+    size_t w16_out(int l) const { return w16_qkv(l) + (size_t)3 * cfg.width * cfg.width; }
+    size_t w16_fc(int l) const { return w16_out(l) + (size_t)cfg.width * cfg.width; }
+    size_t w16_proj(int l) const { return w16_fc(l) + (size_t)4 * cfg.width * cfg.width; }
+};
+
+size_t leaf_train_ws_bytes(const leaf_text* h, int n_seq);  // api_train.hip
+void leaf_set_error(const char* fmt, ...);
+int leaf_check(hipError_t e, const char* what);
+
+#define LEAF_TRY(expr)                                   \
+    do {                                                 \
+        int _rc = leaf_check((expr), #expr);             \
+        if (_rc) return _rc;                             \
+    } while (0)
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// bump allocator over a caller-provided workspace
+struct Carver {
+    char* base;
+    size_t off, cap;
+    Carver(void* p, size_t bytes) : base((char*)p), off(0), cap(bytes) {}
+    void* take(size_t bytes) {
+        size_t o = align_up(off, 256);
+        off = o + bytes;
+        return base ? base + o : nullptr;
+    }
+    bool ok() const { return off <= cap; }
+};

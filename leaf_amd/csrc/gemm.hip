@@ -1,0 +1,178 @@
+// NT GEMM on MFMA for the text tower:  C[M,N] (+)= A[M,K] * B[N,K]^T, 16-bit operands, fp32 accumulate.
+//
+// Both operands are K-contiguous (nn.Linear weight layout [N,K]; activations [rows,K]), which is the
+// natural fragment shape of v_mfma_f32_16x16x32_{f16,bf16}: lane l holds 8 consecutive k of row l&15.
+// Tile 128x128x64, 256 threads = 4 waves (2x2, 64x64 each), LDS double buffer (2 x 32 KiB), register-
+// staged prefetch of tile t+1 issued before the MFMAs of tile t and written to LDS after them
+// (one barrier per K-tile).  LDS rows are 128 B with a 16-B-chunk XOR swizzle (chunk ^ (row&7)) so both
+// the ds_write_b128 staging stores and the ds_read_b128 fragment loads are bank-conflict free.
+// The MFMA is issued as D = Wfrag * Xfrag^T so the accumulator holds 4 CONSECUTIVE n of one row m:
+// epilogues then move 8 B (16-bit) or 16 B (fp32) per lane.  Grid is 1-D with an XCD-aware remap so
+// the tiles that share an A panel run on one XCD's L2.
+//
+// Requirements checked on the host: N % 128 == 0, K % 64 == 0, row strides % 8 == 0; M is arbitrary
+// (load rows are clamped, stores masked).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
+
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+template <class TT, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int tiles_n = p.N / BN;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (logical / tiles_n) * BM, n0 = (logical % tiles_n) * BN;
+
+    // ---- staging assignment: thread -> (row r0 + 32 i, 16-B chunk c)
+    const int c = tid & 7, r0 = tid >> 3;
+    const u16* __restrict__ A = (const u16*)p.A;
+    const u16* __restrict__ B = (const u16*)p.B;
+    const u16* a_ptr[4];
+    const u16* b_ptr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int ra = m0 + r0 + 32 * i; ra = ra < p.M ? ra : p.M - 1;
+        int rb = n0 + r0 + 32 * i;
+        a_ptr[i] = A + (size_t)ra * p.lda + 8 * c;
+        b_ptr[i] = B + (size_t)rb * p.ldb + 8 * c;
+    }
+    uint4 sa[4], sb[4];
+    auto g_load = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sa[i] = *(const uint4*)(a_ptr[i] + k0);
+            sb[i] = *(const uint4*)(b_ptr[i] + k0);
+        }
+    };
+    auto s_store = [&](int buf) {
+        char* base = smem + buf * 2 * TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int off = lds_off(r0 + 32 * i, c);
+            *(uint4*)(base + off) = sa[i];
+            *(uint4*)(base + TILE_BYTES + off) = sb[i];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nt = p.K / BK;
+    g_load(0);
+    s_store(0);
+    __syncthreads();
+
+    const int frow = lane & 15, fkc = lane >> 4;
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nt) g_load((t + 1) * BK);
+        const char* sA = smem + cur * 2 * TILE_BYTES;
+        const char* sB = sA + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            typename TT::vec8 xa[4], wb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                xa[i] = *(const typename TT::vec8*)(sA + lds_off(wm * 64 + i * 16 + frow, ks * 4 + fkc));
+                wb[i] = *(const typename TT::vec8*)(sB + lds_off(wn * 64 + i * 16 + frow, ks * 4 + fkc));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = TT::mfma(wb[j], xa[i], acc[i][j]);
+        }
+        if (t + 1 < nt) s_store(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds C[m][n..n+3], m = .. + (lane&15), n = .. + 4*(lane>>4)
+    const int fq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + frow;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + 4 * fq;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (p.bias) {
+                float4 b = *(const float4*)(p.bias + n);
+                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+            }
+            const size_t o = (size_t)m * p.ldc + n;
+            if constexpr (EPI == EPI_STORE_T) {
+                *(uint2*)((u16*)p.C + o) = pack4<TT>(v[0], v[1], v[2], v[3]);
+            } else if constexpr (EPI == EPI_ACT_T) {
+                if (p.aux) *(uint2*)((u16*)p.aux + o) = pack4<TT>(v[0], v[1], v[2], v[3]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], p.act);
+                *(uint2*)((u16*)p.C + o) = pack4<TT>(v[0], v[1], v[2], v[3]);
+            } else if constexpr (EPI == EPI_RESID_F32) {
+                float4* x = (float4*)((float*)p.C + o);
+                float4 r = *x;
+                r.x += v[0]; r.y += v[1]; r.z += v[2]; r.w += v[3];
+                *x = r;
+            } else if constexpr (EPI == EPI_STORE_F32) {
+                float4* x = (float4*)((float*)p.C + o);
+                float4 r = p.beta != 0.f ? *x : float4{0.f, 0.f, 0.f, 0.f};
+                r.x = r.x * p.beta + v[0]; r.y = r.y * p.beta + v[1];
+                r.z = r.z * p.beta + v[2]; r.w = r.w * p.beta + v[3];
+                *x = r;
+            } else if constexpr (EPI == EPI_ACTGRAD_T) {
+                // aux holds the stashed pre-activation in the FORWARD operand type (aux_f16 tells which)
+                uint2 u = *(const uint2*)((const u16*)p.aux + o);
+                float pre[4];
+                if (p.aux_f16) unpack4<F16>(u, pre); else unpack4<BF16>(u, pre);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= act_bwd(pre[e], p.act);
+                *(uint2*)((u16*)p.C + o) = pack4<TT>(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+}
+
+template <class TT>
+hipError_t launch_t(const GemmArgs& p, int epi, hipStream_t s) {
+    const int grid = ((p.M + BM - 1) / BM) * (p.N / BN);
+    const size_t lds = 4 * TILE_BYTES;
+#define LEAF_GEMM_CASE(E)                                                                    \
+    case E: {                                                                                \
+        static bool attr_done = false;                                                       \
+        if (!attr_done) {                                                                    \
+            (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<TT, E>,                          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
+            attr_done = true;                                                                \
+        }                                                                                    \
+        hipLaunchKernelGGL((gemm_nt_kernel<TT, E>), dim3(grid), dim3(256), lds, s, p);       \
+        break;                                                                               \
+    }
+    switch (epi) {
+        LEAF_GEMM_CASE(EPI_STORE_T)
+        LEAF_GEMM_CASE(EPI_ACT_T)
+        LEAF_GEMM_CASE(EPI_RESID_F32)
+        LEAF_GEMM_CASE(EPI_STORE_F32)
+        LEAF_GEMM_CASE(EPI_ACTGRAD_T)
+        default: return hipErrorInvalidValue;
+    }
+#undef LEAF_GEMM_CASE
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t leaf_launch_gemm(const GemmArgs& p, int dtype, int epi, hipStream_t s) {
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.N % BN || p.K % BK || p.lda % 8 || p.ldb % 8 || p.ldc % 4)
+        return hipErrorInvalidValue;
+    return dtype == LEAF_F16 ? launch_t<F16>(p, epi, s) : launch_t<BF16>(p, epi, s);
+}

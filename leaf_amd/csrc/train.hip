@@ -1,0 +1,445 @@
+// Training-step kernels (TextFARE loss + backward + AdamW).  These run on B sequences once per outer
+// step (about 3/(2*rho*k+4) of the step's FLOPs -- SURVEY.md 8a row a8), so they are written for clarity
+// and coalesced access, with the heavy contractions (data/weight gradients) routed through the MFMA
+// GEMM in gemm.hip.  Gradient-side tensors are bf16 (fp32 exponent range, no loss scaling needed).
+//
+// Reference: utils_AT.py:317-337 (loss, backward), train_AT_text_only.py:326-341 (AdamW groups).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+__device__ __forceinline__ float load_as_f32(const void* p, int kind, size_t i) {
+    if (kind == 0) return BF16::to_f32(((const __bf16*)p)[i]);
+    if (kind == 1) return F16::to_f32(((const _Float16*)p)[i]);
+    return ((const float*)p)[i];
+}
+
+// dst[c][r] = bf16(src[r][c]), r >= rows -> 0
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const void* __restrict__ src, int kind,
+                                                             __bf16* __restrict__ dst, int rows, int cols, int ld_src,
+                                                             int rpad) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int r = r0 + ty + 8 * i, c = c0 + tx;
+        tile[ty + 8 * i][tx] = (r < rows && c < cols) ? load_as_f32(src, kind, (size_t)r * ld_src + c) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int c = c0 + ty + 8 * i, r = r0 + tx;
+        if (c < cols && r < rpad) dst[(size_t)c * rpad + r] = BF16::from_f32(tile[tx][ty + 8 * i]);
+    }
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const void* __restrict__ src, int kind, __bf16* __restrict__ dst,
+                                                        size_t n) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < n; i += stride) dst[i] = BF16::from_f32(load_as_f32(src, kind, i));
+}
+
+// single block: loss = mean_b sum_j (a-f)^2 ; dout = 2 (f-a)/B * scale
+__global__ __launch_bounds__(256) void fare_loss_kernel(const float* __restrict__ feat, const float* __restrict__ anchor,
+                                                        int B, int D, float scale, float* __restrict__ loss,
+                                                        float* __restrict__ dout) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    const size_t n = (size_t)B * D;
+    float s = 0.f;
+    const float k = 2.0f / (float)B * scale;
+    for (size_t i = tid; i < n; i += 256) {
+        float df = feat[i] - anchor[i];
+        s = fmaf(df, df, s);
+        if (dout) dout[i] = k * df;
+    }
+    s = wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0 && loss) *loss = (red[0] + red[1] + red[2] + red[3]) / (float)B;
+}
+
+// dproj[k][j] += sum_b pooled[b][k] * dout[b][j]      grid = d blocks
+__global__ __launch_bounds__(256) void proj_wgrad_kernel(const float* __restrict__ pooled, const float* __restrict__ dout,
+                                                         float* __restrict__ dproj, int B, int d, int D) {
+    const int k = blockIdx.x;
+    for (int j = threadIdx.x; j < D; j += 256) {
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b) acc = fmaf(pooled[(size_t)b * d + k], dout[(size_t)b * D + j], acc);
+        dproj[(size_t)k * D + j] += acc;
+    }
+}
+
+// per sequence: dpooled = dout @ proj^T ; LN_final backward on the EOT row -> dx row, dg/db atomics
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ x,
+                                                       const int32_t* __restrict__ eot_idx, const float* __restrict__ g,
+                                                       float eps, const float* __restrict__ proj, float* __restrict__ dx,
+                                                       float* __restrict__ dg, float* __restrict__ db, int ctx, int d,
+                                                       int D) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sdo = (float*)smem;   // [D]
+    float* sdp = sdo + D;        // [d] dpooled
+    float* red = sdp + d;        // [8]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int j = tid; j < D; j += 256) sdo[j] = dout[(size_t)b * D + j];
+    __syncthreads();
+    for (int k = wid; k < d; k += 4) {
+        const float* pr = proj + (size_t)k * D;
+        float s = 0.f;
+        for (int j = lane; j < D; j += 64) s = fmaf(sdo[j], pr[j], s);
+        s = wave_sum(s);
+        if (lane == 0) sdp[k] = s;
+    }
+    __syncthreads();
+    const size_t row = (size_t)b * ctx + eot_idx[b];
+    const float* xr = x + row * d;
+    // block-wide LN backward for one row
+    float s1 = 0.f;
+    for (int c = tid; c < d; c += 256) s1 += xr[c];
+    s1 = wave_sum(s1);
+    if (lane == 0) red[wid] = s1;
+    __syncthreads();
+    const float mu = (red[0] + red[1] + red[2] + red[3]) / (float)d;
+    __syncthreads();
+    float s2 = 0.f;
+    for (int c = tid; c < d; c += 256) { float a = xr[c] - mu; s2 = fmaf(a, a, s2); }
+    s2 = wave_sum(s2);
+    if (lane == 0) red[wid] = s2;
+    __syncthreads();
+    const float rstd = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)d + eps);
+    __syncthreads();
+    float m1 = 0.f, m2 = 0.f;
+    for (int c = tid; c < d; c += 256) {
+        float xh = (xr[c] - mu) * rstd, dxh = sdp[c] * g[c];
+        m1 += dxh; m2 = fmaf(dxh, xh, m2);
+    }
+    m1 = wave_sum(m1); m2 = wave_sum(m2);
+    if (lane == 0) { red[wid] = m1; red[4 + wid] = m2; }
+    __syncthreads();
+    const float mean1 = (red[0] + red[1] + red[2] + red[3]) / (float)d;
+    const float mean2 = (red[4] + red[5] + red[6] + red[7]) / (float)d;
+    for (int c = tid; c < d; c += 256) {
+        float xh = (xr[c] - mu) * rstd, dy = sdp[c], dxh = dy * g[c];
+        dx[row * d + c] = rstd * (dxh - mean1 - xh * mean2);
+        atomicAdd(dg + c, dy * xh);
+        atomicAdd(db + c, dy);
+    }
+}
+
+constexpr int MAXCH = 8;
+
+// grid-stride over rows, one wave per row; per-lane column partials for dg/db reduced at the end
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ g, float eps, float* __restrict__ dx,
+                                                     __bf16* __restrict__ dx16, float* __restrict__ dg,
+                                                     float* __restrict__ db, int rows, int d) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int nq = d >> 2;
+    float4 pg[MAXCH], pb[MAXCH], gg[MAXCH];
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        pg[i] = float4{0.f, 0.f, 0.f, 0.f}; pb[i] = pg[i];
+        int c = lane + 64 * i;
+        gg[i] = c < nq ? *(const float4*)(g + 4 * c) : float4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int row = blockIdx.x * 4 + wid; row < rows; row += gridDim.x * 4) {
+        const float* xr = x + (size_t)row * d;
+        const float* dyr = dy + (size_t)row * d;
+        float4 xv[MAXCH], dv[MAXCH];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXCH; ++i) {
+            int c = lane + 64 * i;
+            if (c < nq) {
+                xv[i] = *(const float4*)(xr + 4 * c); dv[i] = *(const float4*)(dyr + 4 * c);
+                s += (xv[i].x + xv[i].y) + (xv[i].z + xv[i].w);
+            }
+        }
+        const float mu = wave_sum(s) / (float)d;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXCH; ++i) {
+            int c = lane + 64 * i;
+            if (c < nq) {
+                xv[i].x -= mu; xv[i].y -= mu; xv[i].z -= mu; xv[i].w -= mu;
+                q += (xv[i].x * xv[i].x + xv[i].y * xv[i].y) + (xv[i].z * xv[i].z + xv[i].w * xv[i].w);
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXCH; ++i) {
+            int c = lane + 64 * i;
+            if (c < nq) {
+                xv[i].x *= rstd; xv[i].y *= rstd; xv[i].z *= rstd; xv[i].w *= rstd;   // xhat
+                pg[i].x = fmaf(dv[i].x, xv[i].x, pg[i].x); pg[i].y = fmaf(dv[i].y, xv[i].y, pg[i].y);
+                pg[i].z = fmaf(dv[i].z, xv[i].z, pg[i].z); pg[i].w = fmaf(dv[i].w, xv[i].w, pg[i].w);
+                pb[i].x += dv[i].x; pb[i].y += dv[i].y; pb[i].z += dv[i].z; pb[i].w += dv[i].w;
+                dv[i].x *= gg[i].x; dv[i].y *= gg[i].y; dv[i].z *= gg[i].z; dv[i].w *= gg[i].w;  // dxhat
+                m1 += (dv[i].x + dv[i].y) + (dv[i].z + dv[i].w);
+                m2 += (dv[i].x * xv[i].x + dv[i].y * xv[i].y) + (dv[i].z * xv[i].z + dv[i].w * xv[i].w);
+            }
+        }
+        m1 = wave_sum(m1) / (float)d;
+        m2 = wave_sum(m2) / (float)d;
+        float* dxr = dx + (size_t)row * d;
+#pragma unroll
+        for (int i = 0; i < MAXCH; ++i) {
+            int c = lane + 64 * i;
+            if (c < nq) {
+                float4 o = *(float4*)(dxr + 4 * c);
+                o.x += rstd * (dv[i].x - m1 - xv[i].x * m2); o.y += rstd * (dv[i].y - m1 - xv[i].y * m2);
+                o.z += rstd * (dv[i].z - m1 - xv[i].z * m2); o.w += rstd * (dv[i].w - m1 - xv[i].w * m2);
+                *(float4*)(dxr + 4 * c) = o;
+                if (dx16) *(uint2*)((u16*)dx16 + (size_t)row * d + 4 * c) = pack4<BF16>(o.x, o.y, o.z, o.w);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        int c = lane + 64 * i;
+        if (c < nq) {
+            atomicAdd(dg + 4 * c + 0, pg[i].x); atomicAdd(dg + 4 * c + 1, pg[i].y);
+            atomicAdd(dg + 4 * c + 2, pg[i].z); atomicAdd(dg + 4 * c + 3, pg[i].w);
+            atomicAdd(db + 4 * c + 0, pb[i].x); atomicAdd(db + 4 * c + 1, pb[i].y);
+            atomicAdd(db + 4 * c + 2, pb[i].z); atomicAdd(db + 4 * c + 3, pb[i].w);
+        }
+    }
+}
+
+// dbias[n] += sum_r dy[r][n]; thread owns 4 columns, waves/blocks split rows
+__global__ __launch_bounds__(256) void colsum_kernel(const u16* __restrict__ dy, int ld, int rows, int n,
+                                                     float* __restrict__ dbias) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + lane) * 4;
+    if (c >= n) return;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = blockIdx.y * 4 + wid; r < rows; r += gridDim.y * 4) {
+        float v[4];
+        unpack4<BF16>(*(const uint2*)(dy + (size_t)r * ld + c), v);
+        a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(dbias + c + e, a[e]);
+}
+
+// ---------------------------------------------------------------- attention backward (one block per seq x head)
+constexpr int HD = 64, HP = 65;
+
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const u16* __restrict__ qkv, int qkv_f16,
+                                                       const u16* __restrict__ dO, u16* __restrict__ dqkv, int ctx,
+                                                       int heads, int d) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sq = (float*)smem;            // [ctx][HP]
+    float* sk = sq + ctx * HP;
+    float* sv = sk + ctx * HP;
+    float* sdo = sv + ctx * HP;
+    float* sp = sdo + ctx * HP;          // [ctx][ctx+1]  P
+    float* sds = sp + ctx * (ctx + 1);   // [ctx][ctx+1]  dS
+    const int n = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int ld = 3 * d, PS = ctx + 1;
+    const size_t row0 = (size_t)n * ctx;
+    for (int idx = tid; idx < ctx * HD; idx += 256) {
+        const int r = idx >> 6, c = idx & 63;
+        const size_t o = (row0 + r) * ld + h * HD + c;
+        sq[r * HP + c] = load_as_f32(qkv, qkv_f16 ? 1 : 0, o);
+        sk[r * HP + c] = load_as_f32(qkv, qkv_f16 ? 1 : 0, o + d);
+        sv[r * HP + c] = load_as_f32(qkv, qkv_f16 ? 1 : 0, o + 2 * d);
+        sdo[r * HP + c] = load_as_f32(dO, 0, (row0 + r) * d + h * HD + c);
+    }
+    __syncthreads();
+    // P rows (softmax of causal scores) and dS rows, one wave per query row
+    for (int i = wid; i < ctx; i += 4) {
+        float sc[2], dp[2];
+        float m = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int j = lane + 64 * t;
+            float s = -INFINITY, dpv = 0.f;
+            if (j <= i && j < ctx) {
+                s = 0.f;
+                for (int c = 0; c < HD; ++c) {
+                    s = fmaf(sq[i * HP + c], sk[j * HP + c], s);
+                    dpv = fmaf(sdo[i * HP + c], sv[j * HP + c], dpv);
+                }
+                s *= 0.125f;
+            }
+            sc[t] = s; dp[t] = dpv;
+            m = fmaxf(m, s);
+        }
+        m = wave_max(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { sc[t] = __expf(sc[t] - m); sum += sc[t]; }
+        sum = wave_sum(sum);
+        const float inv = 1.0f / sum;
+        float rd = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { sc[t] *= inv; rd = fmaf(sc[t], dp[t], rd); }
+        rd = wave_sum(rd);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int j = lane + 64 * t;
+            if (j < ctx) {
+                sp[i * PS + j] = sc[t];
+                sds[i * PS + j] = sc[t] * (dp[t] - rd) * 0.125f;
+            }
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < ctx * HD; idx += 256) {
+        const int r = idx >> 6, c = idx & 63;
+        float dq = 0.f, dk = 0.f, dv = 0.f;
+        for (int j = 0; j <= r; ++j) dq = fmaf(sds[r * PS + j], sk[j * HP + c], dq);
+        for (int i = r; i < ctx; ++i) {
+            dk = fmaf(sds[i * PS + r], sq[i * HP + c], dk);
+            dv = fmaf(sp[i * PS + r], sdo[i * HP + c], dv);
+        }
+        const size_t o = (row0 + r) * ld + h * HD + c;
+        ((__bf16*)dqkv)[o] = BF16::from_f32(dq);
+        ((__bf16*)dqkv)[o + d] = BF16::from_f32(dk);
+        ((__bf16*)dqkv)[o + 2 * d] = BF16::from_f32(dv);
+    }
+}
+
+// dpos[p][:] += sum_n dx[n*ctx+p][:]   (grid = ctx) ; dtok via atomics (grid-stride over rows)
+__global__ __launch_bounds__(256) void pos_bwd_kernel(const float* __restrict__ dx, float* __restrict__ dpos, int n_seq,
+                                                      int ctx, int d) {
+    const int p = blockIdx.x;
+    for (int c = threadIdx.x; c < d; c += 256) {
+        float s = 0.f;
+        for (int n = 0; n < n_seq; ++n) s += dx[((size_t)n * ctx + p) * d + c];
+        dpos[(size_t)p * d + c] += s;
+    }
+}
+__global__ __launch_bounds__(256) void tok_bwd_kernel(const float* __restrict__ dx, const int32_t* __restrict__ tokens,
+                                                      float* __restrict__ dtok, int rows, int d, int vocab) {
+    const int row = blockIdx.x;
+    int tok = tokens[row];
+    tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
+    for (int c = threadIdx.x; c < d; c += 256) atomicAdd(dtok + (size_t)tok * d + c, dx[(size_t)row * d + c]);
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, size_t n4,
+                                                    size_t n_decay, float lr, float b1, float b2, float eps, float wd,
+                                                    float bc1, float sqrt_bc2, float gscale) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < n4; i += stride) {
+        float4 pp = ((float4*)p)[i], gg = ((const float4*)g)[i], mm = ((float4*)m)[i], vv = ((float4*)v)[i];
+        float* P = (float*)&pp; float* G = (float*)&gg; float* M = (float*)&mm; float* V = (float*)&vv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float decay = (4 * i + e) < n_decay ? wd : 0.f;
+            const float gr = G[e] * gscale;
+            P[e] *= 1.0f - lr * decay;
+            M[e] = b1 * M[e] + (1.0f - b1) * gr;
+            V[e] = b2 * V[e] + (1.0f - b2) * gr * gr;
+            const float denom = sqrtf(V[e]) / sqrt_bc2 + eps;
+            P[e] -= (lr / bc1) * (M[e] / denom);
+        }
+        ((float4*)p)[i] = pp; ((float4*)m)[i] = mm; ((float4*)v)[i] = vv;
+    }
+}
+
+}  // namespace
+
+hipError_t leaf_launch_transpose_bf16(const void* src, int src_kind, void* dst, int rows, int cols, int ld_src,
+                                      int rpad, hipStream_t s) {
+    dim3 grid((cols + 31) / 32, (rpad + 31) / 32);
+    hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, s, src, src_kind, (__bf16*)dst, rows, cols, ld_src,
+                       rpad);
+    return hipGetLastError();
+}
+
+hipError_t leaf_launch_cast_bf16(const void* src, int src_kind, void* dst, size_t n, hipStream_t s) {
+    if (!n) return hipSuccess;
+    size_t nb = (n + 255) / 256;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), 0, s, src, src_kind,
+                       (__bf16*)dst, n);
+    return hipGetLastError();
+}
+
+hipError_t leaf_launch_f32_to_bf16_rows(const float* src, void* dst, size_t n, hipStream_t s) {
+    return leaf_launch_cast_bf16(src, 2, dst, n, s);
+}
+
+hipError_t leaf_launch_fare_loss(const float* feat, const float* anchor, int B, int D, float scale, float* loss,
+                                 float* dout, hipStream_t s) {
+    hipLaunchKernelGGL(fare_loss_kernel, dim3(1), dim3(256), 0, s, feat, anchor, B, D, scale, loss, dout);
+    return hipGetLastError();
+}
+
+hipError_t leaf_launch_pool_project_bwd(const float* dout, const float* pooled, const float* x, const int32_t* eot_idx,
+                                        const float* g, const float* b, float eps, const float* proj, float* dx,
+                                        float* dproj, float* dg, float* db, int n_seq, int ctx, int d, int D,
+                                        hipStream_t s) {
+    (void)b;
+    hipLaunchKernelGGL(proj_wgrad_kernel, dim3(d), dim3(256), 0, s, pooled, dout, dproj, n_seq, d, D);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    size_t lds = (size_t)(D + d + 8) * sizeof(float);
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3(n_seq), dim3(256), lds, s, dout, x, eot_idx, g, eps, proj, dx, dg, db, ctx,
+                       d, D);
+    return hipGetLastError();
+}
+
+hipError_t leaf_launch_layernorm_bwd(const float* dy, const float* x, const float* g, float eps, float* dx_inout,
+                                     void* dx16, float* dg, float* db, int rows, int d, hipStream_t s) {
+    if (d % 4 || d > 256 * MAXCH) return hipErrorInvalidValue;
+    int grid = (rows + 3) / 4;
+    if (grid > 512) grid = 512;
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), 0, s, dy, x, g, eps, dx_inout, (__bf16*)dx16, dg, db, rows,
+                       d);
+    return hipGetLastError();
+}
+
+hipError_t leaf_launch_colsum(const void* dy_bf16, int ld, int rows, int n, float* dbias, hipStream_t s) {
+    if (n % 4 || ld % 4) return hipErrorInvalidValue;
+    int ry = (rows + 63) / 64;
+    if (ry > 64) ry = 64;
+    if (ry < 1) ry = 1;
+    hipLaunchKernelGGL(colsum_kernel, dim3((n + 255) / 256, ry), dim3(256), 0, s, (const u16*)dy_bf16, ld, rows, n,
+                       dbias);
+    return hipGetLastError();
+}
+
+hipError_t leaf_launch_attention_bwd(const void* qkv, int qkv_dtype, const void* dout_bf16, void* dqkv_bf16, int n_seq,
+                                     int ctx, int heads, int d, hipStream_t s) {
+    if (d != heads * HD || ctx > 128) return hipErrorInvalidValue;
+    size_t lds = ((size_t)4 * ctx * HP + (size_t)2 * ctx * (ctx + 1)) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(n_seq * heads), dim3(256), lds, s, (const u16*)qkv,
+                       qkv_dtype == LEAF_F16 ? 1 : 0, (const u16*)dout_bf16, (u16*)dqkv_bf16, ctx, heads, d);
+    return hipGetLastError();
+}
+
+hipError_t leaf_launch_embed_bwd(const float* dx, const int32_t* tokens, float* dtok, float* dpos, int rows, int ctx,
+                                 int d, int vocab, hipStream_t s) {
+    hipLaunchKernelGGL(pos_bwd_kernel, dim3(ctx), dim3(256), 0, s, dx, dpos, rows / ctx, ctx, d);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(tok_bwd_kernel, dim3(rows), dim3(256), 0, s, dx, tokens, dtok, rows, d, vocab);
+    return hipGetLastError();
+}
+
+hipError_t leaf_launch_adamw(float* p, const float* g, float* m, float* v, size_t n, size_t n_decay, float lr,
+                             float beta1, float beta2, float eps, float wd, int step, float grad_scale, hipStream_t s) {
+    if (n % 4 || step < 1) return hipErrorInvalidValue;
+    const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    const float bc2 = (float)(1.0 - pow((double)beta2, (double)step));
+    size_t n4 = n / 4, nb = (n4 + 255) / 256;
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)(nb < 16384 ? nb : 16384)), dim3(256), 0, s, p, g, m, v, n4, n_decay,
+                       lr, beta1, beta2, eps, wd, bc1, sqrtf(bc2), grad_scale);
+    return hipGetLastError();
+}

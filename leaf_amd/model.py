@@ -1,0 +1,329 @@
+"""Text tower of CLIP on the HIP engine, behind the reference's ``model.encode_text`` seam.
+
+``LeafCLIPText`` owns ONE flat fp32 parameter tensor on the GPU (layout defined by libleaf_hip, decay
+group first) plus 16-bit MFMA operand copies, and exposes
+
+* ``encode_text(text, normalize=False)``   -- src/open_clip/model.py:269-284
+* ``score_candidates(tokens, anchor, rho, objective)`` -- one stage of utils_attacks.py:297-393
+* ``forward_train`` / ``backward`` / ``adamw_step``    -- utils_AT.py:317-362
+* ``state_dict`` / ``load_state_dict`` with OpenCLIP keys and HF ``CLIPTextModel`` keys
+  (conversion/convert_2.py:37-99 key map).
+
+PyTorch is used for device memory and streams only; every computation is a call into the C ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+@dataclass(frozen=True)
+class TextConfig:
+    width: int = 768
+    heads: int = 12
+    layers: int = 12
+    embed_dim: int = 768
+    context_length: int = 77
+    vocab_size: int = 49408
+    quick_gelu: bool = False
+    ln_eps: float = 1e-5
+
+
+# src/open_clip/model_configs/ViT-{L,H,g,bigG}-14.json (text_cfg + embed_dim); the hf-hub ids are the ones the
+# reference's launch scripts pass as --model (scripts/train_leaf_vit*.sh)
+MODEL_CONFIGS: Dict[str, TextConfig] = {
+    "ViT-L-14": TextConfig(768, 12, 12, 768),
+    "ViT-L-14-quickgelu": TextConfig(768, 12, 12, 768, quick_gelu=True),
+    "ViT-H-14": TextConfig(1024, 16, 24, 1024),
+    "ViT-g-14": TextConfig(1024, 16, 24, 1024),
+    "ViT-bigG-14": TextConfig(1280, 20, 32, 1280),
+    "tiny-test": TextConfig(128, 2, 2, 64),
+    "tiny-test-quickgelu": TextConfig(128, 2, 2, 64, quick_gelu=True),
+}
+_HUB_ALIASES = {
+    "hf-hub:chs20/fare2-clip": "ViT-L-14-quickgelu",
+    "hf-hub:chs20/tecoa2-clip": "ViT-L-14-quickgelu",
+    "hf-hub:laion/CLIP-ViT-H-14-laion2B-s32B-b79K": "ViT-H-14",
+    "hf-hub:laion/CLIP-ViT-g-14-laion2B-s12B-b42K": "ViT-g-14",
+    "hf-hub:laion/CLIP-ViT-bigG-14-laion2B-39B-b160k": "ViT-bigG-14",
+}
+
+
+def get_config(name: str) -> TextConfig:
+    name = _HUB_ALIASES.get(name, name)
+    if name not in MODEL_CONFIGS:
+        raise KeyError(f"unknown text tower '{name}'; known: {sorted(MODEL_CONFIGS)}")
+    return MODEL_CONFIGS[name]
+
+
+_DTYPES = {"bf16": 0, "fp16": 1}
+_OBJ = {"l2": 0, "negl2": 1, "dissim": 2, "sim": 3}
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class LeafCLIPText:
+    """Text tower on the HIP engine.  Not an ``nn.Module``: parameters live in ``self.flat`` (fp32, CUDA);
+    ``self.params[name]`` are views into it with the OpenCLIP names."""
+
+    def __init__(self, cfg: TextConfig, device="cuda:0", dtype: str = None, chunk: int = None, trainable: bool = False):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.LeafHipError("LeafCLIPText needs a CUDA(HIP) device; there is no CPU path")
+        dtype = dtype or os.environ.get("LEAF_DTYPE", "fp16")
+        self.dtype_name = dtype
+        self._lib = _lib.lib()
+        c = _lib.TextCfgC(cfg.layers, cfg.width, cfg.heads, cfg.embed_dim, cfg.context_length, cfg.vocab_size,
+                          1 if cfg.quick_gelu else 0, cfg.ln_eps)
+        h = C.c_void_p()
+        _lib.check(self._lib.leaf_text_create(C.byref(c), _DTYPES[dtype], C.byref(h)), "leaf_text_create")
+        self._h = h
+        chunk = chunk or int(os.environ.get("LEAF_CHUNK", "1024"))
+        _lib.check(self._lib.leaf_text_set_chunk(h, chunk), "leaf_text_set_chunk")
+        self.n_params = self._lib.leaf_text_param_count(h)
+        self.n_decay = self._lib.leaf_text_decay_count(h)
+        with torch.cuda.device(self.device):
+            self.flat = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
+            self.w16 = torch.empty(self._lib.leaf_text_w16_bytes(h), dtype=torch.uint8, device=self.device)
+        self.layout: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
+        self.params: Dict[str, torch.Tensor] = {}
+        name = C.create_string_buffer(128)
+        off, rows, cols = C.c_size_t(), C.c_int64(), C.c_int64()
+        for i in range(self._lib.leaf_text_num_tensors(h)):
+            _lib.check(self._lib.leaf_text_param_info(h, i, name, 128, C.byref(off), C.byref(rows), C.byref(cols)), "param_info")
+            shape = (rows.value, cols.value) if cols.value else (rows.value,)
+            self.layout[name.value.decode()] = (off.value, shape)
+            self.params[name.value.decode()] = self.flat[off.value: off.value + int(np.prod(shape))].view(shape)
+        self.logit_scale = torch.tensor(math.log(1 / 0.07), device=self.device)  # carried for checkpoints only
+        self._ws: Dict[int, torch.Tensor] = {}
+        self._packed = False
+        self.training = False
+        # training state (allocated on demand)
+        self.grads = self.exp_avg = self.exp_avg_sq = self.w16_bwd = self._stash = None
+        self.opt_step = 0
+        if trainable:
+            self.enable_training()
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._lib.leaf_text_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ nn.Module look-alikes
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode: bool = True):
+        self.training = mode
+        return self
+
+    def named_parameters(self):
+        return list(self.params.items())
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _workspace(self, mode: int, n_seq: int) -> torch.Tensor:
+        need = self._lib.leaf_text_workspace_bytes(self._h, n_seq, mode)
+        ws = self._ws.get(mode)
+        if ws is None or ws.numel() < need:
+            ws = None
+            self._ws[mode] = None
+            with torch.cuda.device(self.device):
+                ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._ws[mode] = ws
+        return ws
+
+    # ------------------------------------------------------------------ weights
+    def init_random(self, seed: int = 1):
+        """Same generator and distributions as oracle.text_oracle.init_weights (numpy PCG64), restated here so
+        the product does not import the oracle: transformer.py:731-752 std's, perturbed LN affine / biases."""
+        cfg = self.cfg
+        rng = np.random.default_rng(seed)
+        d, L, D = cfg.width, cfg.layers, cfg.embed_dim
+        n = lambda shape, std: (rng.standard_normal(shape, dtype=np.float32) * np.float32(std)).astype(np.float32)
+        sd = {"token_embedding.weight": n((cfg.vocab_size, d), 0.02), "positional_embedding": n((cfg.context_length, d), 0.01)}
+        proj_std, attn_std, fc_std = (d ** -0.5) * ((2 * L) ** -0.5), d ** -0.5, (2 * d) ** -0.5
+        for i in range(L):
+            p = f"transformer.resblocks.{i}."
+            sd[p + "ln_1.weight"] = (1.0 + n((d,), 0.05)).astype(np.float32)
+            sd[p + "ln_1.bias"] = n((d,), 0.02)
+            sd[p + "attn.in_proj_weight"] = n((3 * d, d), attn_std)
+            sd[p + "attn.in_proj_bias"] = n((3 * d,), 0.02)
+            sd[p + "attn.out_proj.weight"] = n((d, d), proj_std)
+            sd[p + "attn.out_proj.bias"] = n((d,), 0.02)
+            sd[p + "ln_2.weight"] = (1.0 + n((d,), 0.05)).astype(np.float32)
+            sd[p + "ln_2.bias"] = n((d,), 0.02)
+            sd[p + "mlp.c_fc.weight"] = n((4 * d, d), fc_std)
+            sd[p + "mlp.c_fc.bias"] = n((4 * d,), 0.02)
+            sd[p + "mlp.c_proj.weight"] = n((d, 4 * d), proj_std)
+            sd[p + "mlp.c_proj.bias"] = n((d,), 0.02)
+        sd["ln_final.weight"] = (1.0 + n((d,), 0.05)).astype(np.float32)
+        sd["ln_final.bias"] = n((d,), 0.02)
+        sd["text_projection"] = n((d, D), d ** -0.5)
+        self.load_state_dict(sd)
+        return self
+
+    def load_state_dict(self, sd, strict: bool = True):
+        """OpenCLIP text-tower keys (a full CLIP state_dict is accepted: visual.* is ignored, 'module.' stripped,
+        factory.py:138-139) or HF CLIPTextModel / CLIPModel keys (conversion/convert_to_openclip.py:78-121)."""
+        from .checkpoint import to_openclip_text_keys
+        sd = to_openclip_text_keys(sd, self.cfg)
+        missing = [k for k in self.params if k not in sd]
+        if missing and strict:
+            raise KeyError(f"missing text-tower keys: {missing[:5]}{'...' if len(missing) > 5 else ''}")
+        for k, p in self.params.items():
+            if k in sd:
+                v = sd[k]
+                v = torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v
+                if tuple(v.shape) != tuple(p.shape):
+                    raise ValueError(f"{k}: shape {tuple(v.shape)} != {tuple(p.shape)}")
+                p.copy_(v.to(device=self.device, dtype=torch.float32))
+        if "logit_scale" in sd:
+            self.logit_scale = torch.as_tensor(sd["logit_scale"], dtype=torch.float32).to(self.device)
+        self._packed = False
+        return self
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        out = {k: v.detach().clone() for k, v in self.params.items()}
+        out["logit_scale"] = self.logit_scale.detach().clone()
+        return out
+
+    def copy_from(self, other: "LeafCLIPText"):
+        self.flat.copy_(other.flat)
+        self.logit_scale = other.logit_scale.clone()
+        self._packed = False
+        return self
+
+    def pack(self):
+        """fp32 masters -> 16-bit MFMA operand copies (forward dtype; + transposed bf16 when training)."""
+        _lib.check(self._lib.leaf_text_pack_weights(self._h, _ptr(self.flat), _ptr(self.w16), _ptr(self.w16_bwd),
+                                                    self._stream()), "leaf_text_pack_weights")
+        self._packed = True
+
+    # ------------------------------------------------------------------ inference
+    def _tokens(self, text) -> torch.Tensor:
+        if isinstance(text, np.ndarray):
+            text = torch.from_numpy(text)
+        t = text.to(device=self.device, dtype=torch.int32, non_blocking=True).contiguous()
+        if t.dim() != 2 or t.shape[1] != self.cfg.context_length:
+            raise ValueError(f"tokens must be [N,{self.cfg.context_length}], got {tuple(t.shape)}")
+        return t
+
+    def encode_text(self, text, normalize: bool = False) -> torch.Tensor:
+        if not self._packed:
+            self.pack()
+        t = self._tokens(text)
+        n = t.shape[0]
+        out = torch.empty(n, self.cfg.embed_dim, dtype=torch.float32, device=self.device)
+        ws = self._workspace(0, n)
+        _lib.check(self._lib.leaf_text_forward(self._h, _ptr(self.flat), _ptr(self.w16), _ptr(t), n, _ptr(out),
+                                               int(bool(normalize)), _ptr(ws), ws.numel(), self._stream()),
+                   "leaf_text_forward")
+        return out
+
+    def score_candidates(self, tokens, anchor: torch.Tensor, rho: int, objective: str = "l2", want_features=True,
+                         want_loss=False):
+        """tokens [B*rho, ctx] (or [B,rho,ctx]); anchor [B,D] fp32 CUDA.  Returns (best_idx int32[B],
+        best_feat [B,D] or None) (+ loss [B,rho] when want_loss)."""
+        if not self._packed:
+            self.pack()
+        if isinstance(tokens, np.ndarray):
+            tokens = torch.from_numpy(tokens)
+        t = self._tokens(tokens.reshape(-1, tokens.shape[-1]))
+        B = anchor.shape[0]
+        if t.shape[0] != B * rho:
+            raise ValueError(f"{t.shape[0]} candidate rows != B*rho = {B}*{rho}")
+        anchor = anchor.to(device=self.device, dtype=torch.float32).contiguous()
+        idx = torch.empty(B, dtype=torch.int32, device=self.device)
+        feat = torch.empty(B, self.cfg.embed_dim, dtype=torch.float32, device=self.device) if want_features else None
+        loss = torch.empty(B, rho, dtype=torch.float32, device=self.device) if want_loss else None
+        ws = self._workspace(1, B * rho)
+        _lib.check(self._lib.leaf_score_candidates(self._h, _ptr(self.flat), _ptr(self.w16), _ptr(t), _ptr(anchor), B,
+                                                   rho, _OBJ[objective], _ptr(idx), _ptr(feat), _ptr(loss), _ptr(ws),
+                                                   ws.numel(), self._stream()), "leaf_score_candidates")
+        return (idx, feat, loss) if want_loss else (idx, feat)
+
+    # ------------------------------------------------------------------ training
+    def enable_training(self):
+        if self.grads is None:
+            with torch.cuda.device(self.device):
+                self.grads = torch.zeros_like(self.flat)
+                self.exp_avg = torch.zeros_like(self.flat)
+                self.exp_avg_sq = torch.zeros_like(self.flat)
+                self.w16_bwd = torch.empty_like(self.w16)
+            self._packed = False
+        return self
+
+    def zero_grad(self):
+        self.grads.zero_()
+
+    def forward_train(self, text) -> torch.Tensor:
+        self.enable_training()
+        if not self._packed:
+            self.pack()
+        t = self._tokens(text)
+        n = t.shape[0]
+        need = self._lib.leaf_text_stash_bytes(self._h, n)
+        if self._stash is None or self._stash.numel() < need:
+            self._stash = None
+            with torch.cuda.device(self.device):
+                self._stash = torch.empty(need, dtype=torch.uint8, device=self.device)
+        out = torch.empty(n, self.cfg.embed_dim, dtype=torch.float32, device=self.device)
+        _lib.check(self._lib.leaf_text_forward_train(self._h, _ptr(self.flat), _ptr(self.w16), _ptr(t), n, _ptr(out),
+                                                     _ptr(self._stash), self._stash.numel(), C.c_void_p(0), 0,
+                                                     self._stream()), "leaf_text_forward_train")
+        self._train_tokens = t
+        return out
+
+    def backward(self, feat: torch.Tensor, anchor: torch.Tensor, accum_scale: float = 1.0) -> torch.Tensor:
+        """TextFARE loss of (anchor, feat) + backward through the stash of the last ``forward_train``.
+        Accumulates into ``self.grads``; returns the (unscaled) loss as a 0-d CUDA tensor."""
+        t = self._train_tokens
+        n = t.shape[0]
+        loss = torch.empty((), dtype=torch.float32, device=self.device)
+        anchor = anchor.to(device=self.device, dtype=torch.float32).contiguous()
+        ws = self._workspace(2, n)
+        _lib.check(self._lib.leaf_textfare_backward(self._h, _ptr(self.flat), _ptr(self.w16_bwd), _ptr(t), n,
+                                                    _ptr(feat.contiguous()), _ptr(anchor), float(accum_scale),
+                                                    _ptr(self._stash), _ptr(self.grads), _ptr(loss), _ptr(ws),
+                                                    ws.numel(), self._stream()), "leaf_textfare_backward")
+        return loss
+
+    def adamw_step(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+                   grad_scale: float = 1.0):
+        self.opt_step += 1
+        _lib.check(self._lib.leaf_adamw_step(_ptr(self.flat), _ptr(self.grads), _ptr(self.exp_avg),
+                                             _ptr(self.exp_avg_sq), self.n_params, self.n_decay, float(lr),
+                                             float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
+                                             self.opt_step, float(grad_scale), self._stream()), "leaf_adamw_step")
+        self._packed = False
+
+
+def create_model(name: str, device="cuda:0", dtype: str = None, pretrained: Optional[str] = None,
+                 trainable: bool = False, seed: int = 1) -> LeafCLIPText:
+    """open_clip.create_model equivalent for the text tower: random init (seeded) or a local checkpoint
+    (OpenCLIP .bin/.pt or HF safetensors / directory).  ``hf-hub:`` ids map to their architecture; weights must be
+    given as a local path (there is no network on the build or GPU boxes)."""
+    m = LeafCLIPText(get_config(name), device=device, dtype=dtype, trainable=trainable)
+    if pretrained:
+        from .checkpoint import load_checkpoint_file
+        m.load_state_dict(load_checkpoint_file(pretrained))
+    else:
+        m.init_random(seed)
+    return m

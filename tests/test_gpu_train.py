@@ -1,0 +1,96 @@
+"""Training half on the GPU: stash forward == inference forward, TextFARE loss, gradients, AdamW, one full step."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import text_oracle as O
+from tests.util import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+@pytest.mark.parametrize("name,seed,model,qg", [("tiny_gelu", 11, "tiny-test", False),
+                                                 ("tiny_quickgelu", 12, "tiny-test-quickgelu", True)])
+def test_loss_and_grads_vs_golden(torch_mod, golden_dir, name, seed, model, qg):
+    from leaf_amd.model import create_model
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    m = create_model(model, seed=seed, trainable=True)
+    toks = z["tokens"][:8]
+    feat = m.forward_train(toks)
+    assert np.array_equal(feat.cpu().numpy(), m.encode_text(toks).cpu().numpy()), "stash forward must equal inference forward"
+    m.zero_grad()
+    loss = m.backward(feat, torch_mod.from_numpy(z["anchor"]).cuda(), accum_scale=0.5)
+    torch_mod.cuda.synchronize()
+    assert abs(float(loss) - float(z["loss"])) < 2e-3 * abs(float(z["loss"]))     # P3
+    worst = {}
+    for k, (off, shape) in m.layout.items():
+        g = m.grads[off: off + int(np.prod(shape))].view(shape).cpu().numpy()
+        if k == "token_embedding.weight":
+            rows = z["tok_rows"]
+            r = rel_l2(g[rows], z["g_tok_rows"])
+            assert np.abs(np.delete(g, rows, axis=0)).sum() == 0.0
+        else:
+            r = rel_l2(g, z["g:" + k])
+        worst[k] = r
+    bad = {k: v for k, v in worst.items() if v > 2.5e-2}
+    print("max grad rel-L2", max(worst.values()))
+    # P4: bf16 gradient operands (8 significand bits): per-tensor rel-L2 <= 2.5e-2 vs the fp32 reference
+    assert not bad, bad
+    # accumulate: a second backward doubles the gradient
+    g1 = m.grads.clone()
+    m.backward(feat, torch_mod.from_numpy(z["anchor"]).cuda(), accum_scale=0.5)
+    assert rel_l2(m.grads.cpu().numpy(), 2 * g1.cpu().numpy()) < 1e-6
+
+
+def test_adamw_kernel_vs_oracle(torch_mod):
+    import ctypes as C
+    from leaf_amd import _lib
+    from tests.util import ptr, stream
+    lib = _lib.lib()
+    rng = np.random.default_rng(0)
+    n, nd = 4096, 1000
+    p = rng.standard_normal(n).astype(np.float32)
+    g = (rng.standard_normal(n) * 1e-3).astype(np.float32)
+    w = {"a.weight": p[:nd].reshape(10, 100).copy(), "b.bias": p[nd:].copy()}
+    gg = {"a.weight": g[:nd].reshape(10, 100).copy(), "b.bias": g[nd:].copy()}
+    mm = {k: np.zeros_like(v) for k, v in w.items()}
+    vv = {k: np.zeros_like(v) for k, v in w.items()}
+    tp, tg = torch_mod.from_numpy(p.copy()).cuda(), torch_mod.from_numpy(g).cuda()
+    tm, tv = torch_mod.zeros_like(tp), torch_mod.zeros_like(tp)
+    for step in (1, 2, 3):
+        O.adamw_step(w, gg, mm, vv, step, lr=1e-3, wd=0.1, beta1=0.9, beta2=0.98, eps=1e-6)
+        _lib.check(lib.leaf_adamw_step(ptr(tp), ptr(tg), ptr(tm), ptr(tv), n, nd, 1e-3, 0.9, 0.98, 1e-6, 0.1, step, 1.0, stream()), "adamw")
+    torch_mod.cuda.synchronize()
+    want = np.concatenate([w["a.weight"].ravel(), w["b.bias"]])
+    assert np.abs(tp.cpu().numpy() - want).max() < 1e-6
+
+
+def test_full_step_moves_loss_down(torch_mod):
+    """anchor -> search (k=1, rho=8) -> train fwd/bwd -> AdamW, three times on the tiny model: the TextFARE loss of
+    the same adversarial batch must drop after the updates (end-to-end plumbing of utils_AT.py:282-362)."""
+    from leaf_amd.model import LeafCLIPText, create_model, get_config
+    m = create_model("tiny-test-quickgelu", seed=12, trainable=True)
+    frozen = LeafCLIPText(get_config("tiny-test-quickgelu")).copy_from(m)
+    base = O.synthetic_tokens(16, seed=9)
+    cand = O.synthetic_candidates(base, 8, seed=10)
+    anchor = frozen.encode_text(base)
+    idx, _ = m.score_candidates(cand.reshape(-1, 77), anchor, 8, "l2", want_features=False)
+    adv = cand[np.arange(16), idx.cpu().numpy()]
+    losses = []
+    for _ in range(3):
+        feat = m.forward_train(adv)
+        m.zero_grad()
+        losses.append(float(m.backward(feat, anchor)))
+        m.adamw_step(lr=1e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=1e-4)
+    feat = m.encode_text(adv)
+    final = float(((feat - anchor) ** 2).sum(-1).mean())
+    assert np.isfinite(losses).all() and final < losses[0], (losses, final)

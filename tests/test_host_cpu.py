@@ -1,0 +1,108 @@
+"""CPU-only: tokenizer / mutation / constraint known answers from the reference, and the C-ABI loads with
+every symbol that include/leaf_hip.h declares."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_tokenizer_known_answers(golden_dir):
+    from leaf_amd.tokenizer import SimpleTokenizer
+    with open(os.path.join(golden_dir, "tokenizer_kat.json")) as f:
+        kat = json.load(f)
+    tok = SimpleTokenizer()
+    ids = tok.encode_batch(kat["texts"])
+    assert ids.dtype == np.int32 and ids.shape == (len(kat["texts"]), 77)
+    assert np.array_equal(ids, np.array(kat["ids"], dtype=np.int32))
+    t = tok(kat["texts"][:2])
+    assert str(t.dtype) == "torch.int64" and tuple(t.shape) == (2, 77)
+    assert tok.encode_batch("a photo of a cat")[0, :7].tolist() == [49406, 320, 1125, 539, 320, 2368, 49407]
+    assert tok.decode(tok.encode("a photo of a cat")).strip() == "a photo of a cat"
+
+
+def test_generate_sentence_known_answers(golden_dir):
+    from leaf_amd import attacks
+    with open(os.path.join(golden_dir, "mutation_kat.json")) as f:
+        kat = json.load(f)
+    assert kat["V"] == attacks.DEFAULT_V
+    for c in kat["generate_sentence"]:
+        assert attacks.generate_sentence(c["S"], c["z"], c["u"], kat["V"], 1, alternative=c["alt"]) == c["out"], c
+    for c in kat["space_all"]:
+        assert attacks.generate_all_sentences(c["S"], [ord(' ')], subset_z=None, alternative=-1) == c["out"]
+    np.random.seed(7)
+    for c in kat["random_at_z_seed7"]:
+        assert attacks.generate_random_sentences_at_z(c["S"], c["z"], kat["V"], c["n"], alternative=-1) == c["out"]
+
+
+def test_constraint_rule(golden_dir):
+    from leaf_amd import attacks
+    with open(os.path.join(golden_dir, "mutation_kat.json")) as f:
+        kat = json.load(f)
+    attacks.set_dictionary(attacks.Dictionary(kat["stub_words"]))
+    try:
+        got = attacks.valid_sentence_batched(
+            ["a photo of a cat", "the red car"],
+            [["a photo of a ca t", "a photo of acat", "a photo of a cat", "a phot o of a cat"],
+             ["thered car", "the red ca r", "the re d car", "the red car"]])
+        assert got == kat["valid_batched"]
+    finally:
+        attacks.set_dictionary(None)
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from leaf_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "leaf_hip.h")).read()
+    declared = set(re.findall(r"\b(leaf_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"leaf_text_cfg"}
+    l = _lib.lib()
+    for name in declared:
+        assert hasattr(l, name), f"{name} declared in include/leaf_hip.h but not exported"
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    assert l.leaf_version() >= 1
+
+
+def test_handle_layout_and_errors_without_gpu():
+    """Host-only parts of the ABI: config validation, flat layout (decay group first), sizes."""
+    import ctypes as C
+    from leaf_amd import _lib
+    l = _lib.lib()
+    h = C.c_void_p()
+    bad = _lib.TextCfgC(2, 100, 2, 64, 77, 49408, 0, 1e-5)
+    assert l.leaf_text_create(C.byref(bad), 1, C.byref(h)) != 0 and b"unsupported" in l.leaf_last_error()
+    cfg = _lib.TextCfgC(12, 768, 12, 768, 77, 49408, 1, 1e-5)
+    assert l.leaf_text_create(C.byref(cfg), 1, C.byref(h)) == 0
+    assert l.leaf_text_param_count(h) == 123650304           # ViT-L text tower parameters
+    name = C.create_string_buffer(128)
+    off, rows, cols = C.c_size_t(), C.c_int64(), C.c_int64()
+    seen, total = [], 0
+    for i in range(l.leaf_text_num_tensors(h)):
+        assert l.leaf_text_param_info(h, i, name, 128, C.byref(off), C.byref(rows), C.byref(cols)) == 0
+        assert off.value == total
+        n = name.value.decode()
+        numel = rows.value * (cols.value or 1)
+        excluded = cols.value == 0 or "bn" in n or "ln" in n or "bias" in n or "logit_scale" in n
+        assert excluded == (off.value >= l.leaf_text_decay_count(h)), n   # train_AT_text_only.py:323-331
+        total += numel
+        seen.append(n)
+    assert total == 123650304 and len(set(seen)) == len(seen) == 12 * 12 + 5
+    assert l.leaf_text_workspace_bytes(h, 6400, 1) > 6400 * 768 * 4
+    assert l.leaf_text_param_info(h, 999, name, 128, None, None, None) != 0
+    l.leaf_text_destroy(h)
+
+
+def test_product_has_no_oracle_or_cpu_fallback():
+    """The product package must not import the oracle, and must refuse to run without a GPU."""
+    import subprocess, sys
+    src = "\n".join(open(os.path.join(ROOT, "leaf_amd", f)).read() for f in os.listdir(os.path.join(ROOT, "leaf_amd"))
+                    if f.endswith(".py"))
+    assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M)
+    import torch
+    if not torch.cuda.is_available():
+        from leaf_amd import _lib
+        from leaf_amd.model import LeafCLIPText, get_config
+        with pytest.raises(_lib.LeafHipError):
+            LeafCLIPText(get_config("tiny-test"), device="cpu")

@@ -1,0 +1,102 @@
+"""Pin the CPU oracle (oracle/text_oracle.py) against fixtures produced by the reference
+itself (tests/golden/make_golden.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import text_oracle as O
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def _manifest(golden_dir):
+    with open(os.path.join(golden_dir, "manifest.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("name,seed,qg", [("tiny_gelu", 11, False), ("tiny_quickgelu", 12, True)])
+def test_encode_text_tiny(golden_dir, name, seed, qg):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    cfg = O.TextCfg(128, 2, 2, 64, quick_gelu=qg)
+    w = O.init_weights(cfg, seed=seed)
+    out = O.encode_text(w, cfg, z["tokens"])
+    assert np.abs(out - z["out"]).max() < 2e-5
+    assert rel_l2(out, z["out"]) < 2e-6
+    outn = O.encode_text(w, cfg, z["tokens"], normalize=True)
+    assert rel_l2(outn, z["out_norm"]) < 2e-6
+
+
+@pytest.mark.parametrize("name,seed,qg", [("tiny_gelu", 11, False), ("tiny_quickgelu", 12, True)])
+def test_loss_grads_adamw_tiny(golden_dir, name, seed, qg):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    hp = _manifest(golden_dir)["files"][name + ".npz"]["adamw"]
+    cfg = O.TextCfg(128, 2, 2, 64, quick_gelu=qg)
+    w = O.init_weights(cfg, seed=seed)
+    toks = z["tokens"][:8]
+    loss, feat, g = O.encode_text_backward(w, cfg, toks, z["anchor"], accum_scale=0.5)
+    assert abs(loss - float(z["loss"])) < 1e-5 * max(1.0, abs(float(z["loss"])))
+    for k in w:
+        if k == "token_embedding.weight":
+            rows = z["tok_rows"]
+            assert rel_l2(g[k][rows], z["g_tok_rows"]) < 1e-4
+            other = np.delete(g[k], rows, axis=0)
+            assert np.abs(other).sum() == 0.0 and float(z["g_tok_other_abs_sum"]) == 0.0
+        else:
+            assert rel_l2(g[k], z["g:" + k]) < 1e-4, k
+    m = {k: np.zeros_like(v) for k, v in w.items()}
+    v = {k: np.zeros_like(v_) for k, v_ in w.items()}
+    O.adamw_step(w, g, m, v, step=1, lr=hp["lr"], wd=hp["wd"], beta1=hp["betas"][0], beta2=hp["betas"][1], eps=hp["eps"])
+    for k in w:
+        if k == "token_embedding.weight":
+            d = np.abs(w[k][z["tok_rows"]] - z["after_tok_rows"])
+        else:
+            d = np.abs(w[k] - z["after:" + k])
+        # the first Adam step is lr*g/(|g|+eps): fp32 reorder noise in a gradient of size ~eps moves
+        # the update by a few % of lr, so bound the max by 50% of lr and the mean by 0.1% of lr
+        assert d.max() < 0.5 * hp["lr"] and d.mean() < 1e-3 * hp["lr"], (k, d.max(), d.mean())
+
+
+@pytest.mark.parametrize("fname,model", [("vitl_gelu", "ViT-L-14"), ("vitl_quickgelu", "ViT-L-14-quickgelu")])
+def test_encode_text_vitl(golden_dir, fname, model):
+    z = np.load(os.path.join(golden_dir, fname + ".npz"))
+    info = _manifest(golden_dir)["files"][fname + ".npz"]
+    cfg = O.CONFIGS[model]
+    w = O.init_weights(cfg, seed=info["weight_seed"])
+    for k, s in info["weight_abs_sums"].items():
+        assert abs(float(np.abs(w[k]).sum(dtype=np.float64)) - s) <= 1e-6 * s, "weight generator drifted"
+    out = O.encode_text(w, cfg, z["tokens"])
+    r = [rel_l2(out[i], z["out"][i]) for i in range(out.shape[0])]
+    assert max(r) < 5e-6, r
+
+
+def test_attack_selection_replay(golden_dir):
+    """Replay the reference's attack trace: oracle features of the logged candidate strings'
+    token ids must reproduce the logged winners (utils_attacks.py:332-348,370-393)."""
+    from leaf_amd.tokenizer import SimpleTokenizer
+    tok = SimpleTokenizer()
+    with open(os.path.join(golden_dir, "attack_trace.json")) as f:
+        trace = json.load(f)
+    cfg = O.TextCfg(128, 2, 2, 64, quick_gelu=True)
+    w = O.init_weights(cfg, seed=12)
+    for key, t in trace.items():
+        z = np.load(os.path.join(golden_dir, f"attack_{key}.npz"))
+        B, rho = len(t["sentences"]), t["rho"]
+        stages = t["stage_candidates"]
+        assert len(stages) == 2 * t["k"]
+        last = stages[-1]
+        ids = tok(last)
+        idx, best, loss = O.score_candidates(w, cfg, ids.reshape(B, rho, 77), z["anchor"])
+        assert [last[i * rho + int(idx[i])] for i in range(B)] == t["adv"]
+        assert rel_l2(best, z["feats"]) < 5e-6
+
+
+def test_cosine_lr(golden_dir):
+    c = _manifest(golden_dir)["cosine_lr"]
+    for s, v in c["values"].items():
+        assert abs(O.cosine_lr(c["base_lr"], c["warmup"], c["steps"], int(s)) - v) < 1e-12
