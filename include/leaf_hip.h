@@ -90,6 +90,11 @@ int leaf_adamw_step(float* params, const float* grads, float* exp_avg, float* ex
                     float lr, float beta1, float beta2, float eps, float wd, int step, float grad_scale,
                     leaf_stream_t s);
 
+/* ---- per-launch GEMM timing (bench.py roofline): between begin/end every GEMM launch is bracketed by HIP events on
+ * its stream; end() sums duration / algorithmic FLOPs / launches per key = operand_dtype*8 + epilogue id. */
+int leaf_prof_begin(void);
+int leaf_prof_end(double* ms, double* flops, int64_t* count, int n_keys);
+
 /* ---- single-kernel hooks (used by the parity tests to check each HIP kernel against the oracle) ---- */
 /* C[M,N] = epilogue(A[M,K] * B[N,K]^T): epi 0 store16(+bias), 1 act16(+bias, aux = pre-activation), 2 fp32 += ,
  * 3 fp32 = beta*C + acc, 4 store16(acc * act'(aux)).  A, B 16-bit of `dtype`, contiguous. */

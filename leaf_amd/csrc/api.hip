@@ -123,6 +123,55 @@ extern "C" int leaf_text_pack_weights(leaf_text_t h, const float* params, void* 
 }
 
 // ------------------------------------------------------------------ forward
+// ------------------------------------------------------------------ per-launch GEMM profiler (bench.py roofline)
+namespace {
+struct ProfRec { hipEvent_t a, b; int key; double flops; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+}  // namespace
+
+int leaf_gemm(int dtype, int epi, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias,
+              void* aux, int M, int N, int K, int act, hipStream_t s, float beta, int aux_f16) {
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C; g.bias = bias; g.aux = aux;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.act = act; g.aux_f16 = aux_f16; g.beta = beta;
+    if (!g_prof_on) return leaf_check(leaf_launch_gemm(g, dtype, epi, s), "gemm");
+    ProfRec r;
+    r.key = dtype * 8 + epi;
+    r.flops = 2.0 * (double)M * (double)N * (double)K;
+    LEAF_TRY(hipEventCreate(&r.a));
+    LEAF_TRY(hipEventCreate(&r.b));
+    LEAF_TRY(hipEventRecord(r.a, s));
+    int rc = leaf_check(leaf_launch_gemm(g, dtype, epi, s), "gemm");
+    LEAF_TRY(hipEventRecord(r.b, s));
+    g_prof.push_back(r);
+    return rc;
+}
+
+extern "C" int leaf_prof_begin(void) {
+    for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    g_prof.clear();
+    g_prof_on = true;
+    return 0;
+}
+
+// Stops recording, waits for the recorded events and sums per key (= dtype*8 + epilogue id, < 16):
+// ms[key], flops[key], count[key].
+extern "C" int leaf_prof_end(double* ms, double* flops, int64_t* count, int n_keys) {
+    g_prof_on = false;
+    for (int i = 0; i < n_keys; ++i) { ms[i] = 0; flops[i] = 0; count[i] = 0; }
+    for (auto& r : g_prof) {
+        LEAF_TRY(hipEventSynchronize(r.b));
+        float t = 0.f;
+        LEAF_TRY(hipEventElapsedTime(&t, r.a, r.b));
+        if (r.key >= 0 && r.key < n_keys) { ms[r.key] += t; flops[r.key] += r.flops; count[r.key] += 1; }
+        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    }
+    g_prof.clear();
+    return 0;
+}
+
 namespace {
 
 struct FwdBuf {
@@ -149,15 +198,6 @@ FwdBuf carve_fwd(const leaf_text* h, Carver& c, int cs) {
     return b;
 }
 
-int gemm(int dtype, int epi, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias,
-         void* aux, int M, int N, int K, int act, hipStream_t s, float beta = 0.f, int aux_f16 = 0) {
-    GemmArgs g;
-    g.A = A; g.B = B; g.C = C; g.bias = bias; g.aux = aux;
-    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
-    g.act = act; g.aux_f16 = aux_f16; g.beta = beta;
-    return leaf_check(leaf_launch_gemm(g, dtype, epi, s), "gemm");
-}
-
 // run the layer stack on `cs` sequences; features -> out [cs, D]
 int forward_chunk(const leaf_text* h, const float* P, const uint16_t* W, const int32_t* tokens, int cs, float* out,
                   int normalize, const FwdBuf& b, hipStream_t s) {
@@ -169,16 +209,16 @@ int forward_chunk(const leaf_text* h, const float* P, const uint16_t* W, const i
     for (int l = 0; l < c.layers; ++l) {
         const LayerOff& o = h->layer[l];
         if (l > 0) LEAF_TRY(leaf_launch_layernorm(b.x, P + o.ln1_w, P + o.ln1_b, c.ln_eps, b.a, rows, d, dt, s));
-        if (gemm(dt, EPI_STORE_T, b.a, d, W + h->w16_qkv(l), d, b.qkv, 3 * d, P + o.qkv_b, nullptr, rows, 3 * d, d, 0, s))
+        if (leaf_gemm(dt, EPI_STORE_T, b.a, d, W + h->w16_qkv(l), d, b.qkv, 3 * d, P + o.qkv_b, nullptr, rows, 3 * d, d, 0, s))
             return 1;
         LEAF_TRY(leaf_launch_attention_fwd(b.qkv, b.a, cs, c.context_length, c.heads, d, dt, s));
-        if (gemm(dt, EPI_RESID_F32, b.a, d, W + h->w16_out(l), d, b.x, d, P + o.out_b, nullptr, rows, d, d, 0, s))
+        if (leaf_gemm(dt, EPI_RESID_F32, b.a, d, W + h->w16_out(l), d, b.x, d, P + o.out_b, nullptr, rows, d, d, 0, s))
             return 1;
         LEAF_TRY(leaf_launch_layernorm(b.x, P + o.ln2_w, P + o.ln2_b, c.ln_eps, b.a, rows, d, dt, s));
-        if (gemm(dt, EPI_ACT_T, b.a, d, W + h->w16_fc(l), d, b.hh, 4 * d, P + o.fc_b, nullptr, rows, 4 * d, d,
+        if (leaf_gemm(dt, EPI_ACT_T, b.a, d, W + h->w16_fc(l), d, b.hh, 4 * d, P + o.fc_b, nullptr, rows, 4 * d, d,
                  c.activation, s))
             return 1;
-        if (gemm(dt, EPI_RESID_F32, b.hh, 4 * d, W + h->w16_proj(l), 4 * d, b.x, d, P + o.proj_b, nullptr, rows, d,
+        if (leaf_gemm(dt, EPI_RESID_F32, b.hh, 4 * d, W + h->w16_proj(l), 4 * d, b.x, d, P + o.proj_b, nullptr, rows, d,
                  4 * d, 0, s))
             return 1;
     }
@@ -240,7 +280,7 @@ extern "C" int leaf_score_candidates(leaf_text_t h, const float* params, const v
 // ------------------------------------------------------------------ single-kernel hooks for the parity tests
 extern "C" int leaf_op_gemm(int dtype, int epi, const void* A, const void* B, void* C, const float* bias, void* aux,
                             int M, int N, int K, int act, float beta, int aux_f16, leaf_stream_t s) {
-    return gemm(dtype, epi, A, K, B, K, C, N, bias, aux, M, N, K, act, (hipStream_t)s, beta, aux_f16);
+    return leaf_gemm(dtype, epi, A, K, B, K, C, N, bias, aux, M, N, K, act, (hipStream_t)s, beta, aux_f16);
 }
 extern "C" int leaf_op_attention_fwd(const void* qkv, void* out, int n_seq, int ctx, int heads, int width, int dtype,
                                      leaf_stream_t s) {

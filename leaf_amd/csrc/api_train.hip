@@ -61,15 +61,6 @@ BwdBuf carve_bwd(const leaf_text* h, Carver& c, int n_seq) {
     return b;
 }
 
-int gemm(int dtype, int epi, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias,
-         void* aux, int M, int N, int K, int act, hipStream_t s, float beta = 0.f, int aux_f16 = 0) {
-    GemmArgs g;
-    g.A = A; g.B = B; g.C = C; g.bias = bias; g.aux = aux;
-    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
-    g.act = act; g.aux_f16 = aux_f16; g.beta = beta;
-    return leaf_check(leaf_launch_gemm(g, dtype, epi, s), "gemm");
-}
-
 }  // namespace
 
 size_t leaf_train_ws_bytes(const leaf_text* h, int n_seq) {
@@ -106,14 +97,14 @@ extern "C" int leaf_text_forward_train(leaf_text_t h, const float* P, const void
         uint16_t* xn1 = st.xn1 + l * rd; uint16_t* qkv = st.qkv + 3 * l * rd; uint16_t* ao = st.ao + l * rd;
         uint16_t* xn2 = st.xn2 + l * rd; uint16_t* pre = st.pre + 4 * l * rd; uint16_t* hh = st.hh + 4 * l * rd;
         if (l > 0) LEAF_TRY(leaf_launch_layernorm(xin, P + o.ln1_w, P + o.ln1_b, cf.ln_eps, xn1, rows, d, dt, s));
-        if (gemm(dt, EPI_STORE_T, xn1, d, W + h->w16_qkv(l), d, qkv, 3 * d, P + o.qkv_b, nullptr, rows, 3 * d, d, 0, s)) return 1;
+        if (leaf_gemm(dt, EPI_STORE_T, xn1, d, W + h->w16_qkv(l), d, qkv, 3 * d, P + o.qkv_b, nullptr, rows, 3 * d, d, 0, s)) return 1;
         LEAF_TRY(leaf_launch_attention_fwd(qkv, ao, n_seq, cf.context_length, cf.heads, d, dt, s));
         LEAF_TRY(hipMemcpyAsync(x1, xin, rd * 4, hipMemcpyDeviceToDevice, s));
-        if (gemm(dt, EPI_RESID_F32, ao, d, W + h->w16_out(l), d, x1, d, P + o.out_b, nullptr, rows, d, d, 0, s)) return 1;
+        if (leaf_gemm(dt, EPI_RESID_F32, ao, d, W + h->w16_out(l), d, x1, d, P + o.out_b, nullptr, rows, d, d, 0, s)) return 1;
         LEAF_TRY(leaf_launch_layernorm(x1, P + o.ln2_w, P + o.ln2_b, cf.ln_eps, xn2, rows, d, dt, s));
-        if (gemm(dt, EPI_ACT_T, xn2, d, W + h->w16_fc(l), d, hh, 4 * d, P + o.fc_b, pre, rows, 4 * d, d, cf.activation, s)) return 1;
+        if (leaf_gemm(dt, EPI_ACT_T, xn2, d, W + h->w16_fc(l), d, hh, 4 * d, P + o.fc_b, pre, rows, 4 * d, d, cf.activation, s)) return 1;
         LEAF_TRY(hipMemcpyAsync(xout, x1, rd * 4, hipMemcpyDeviceToDevice, s));
-        if (gemm(dt, EPI_RESID_F32, hh, 4 * d, W + h->w16_proj(l), 4 * d, xout, d, P + o.proj_b, nullptr, rows, d, 4 * d, 0, s)) return 1;
+        if (leaf_gemm(dt, EPI_RESID_F32, hh, 4 * d, W + h->w16_proj(l), 4 * d, xout, d, P + o.proj_b, nullptr, rows, d, 4 * d, 0, s)) return 1;
     }
     LEAF_TRY(leaf_launch_pool_project(st.xin + (size_t)L * rd, tokens, P + h->lnf_w, P + h->lnf_b, cf.ln_eps,
                                       P + h->text_proj, out, st.pooled, st.eot, n_seq, cf.context_length, d,
@@ -146,7 +137,7 @@ extern "C" int leaf_textfare_backward(leaf_text_t h, const float* P, const void*
     auto wgrad = [&](const uint16_t* dY, int Nw, const void* X, int xkind, int Kw, float* dW) -> int {
         LEAF_TRY(leaf_launch_transpose_bf16(dY, 0, b.tA, rows, Nw, Nw, rpad, s));
         LEAF_TRY(leaf_launch_transpose_bf16(X, xkind, b.tB, rows, Kw, Kw, rpad, s));
-        return gemm(LEAF_BF16, EPI_STORE_F32, b.tA, rpad, b.tB, rpad, dW, Kw, nullptr, nullptr, Nw, Kw, rpad, 0, s, 1.0f);
+        return leaf_gemm(LEAF_BF16, EPI_STORE_F32, b.tA, rpad, b.tB, rpad, dW, Kw, nullptr, nullptr, Nw, Kw, rpad, 0, s, 1.0f);
     };
 
     LEAF_TRY(leaf_launch_fare_loss(feat, anchor, n_seq, D, accum_scale, loss_out, b.dout, s));
@@ -164,22 +155,22 @@ extern "C" int leaf_textfare_backward(leaf_text_t h, const float* P, const void*
         // ---- MLP
         if (wgrad(b.dx16, d, hh, fk, 4 * d, G + o.proj_w)) return 1;
         LEAF_TRY(leaf_launch_colsum(b.dx16, d, rows, d, G + o.proj_b, s));
-        if (gemm(LEAF_BF16, EPI_ACTGRAD_T, b.dx16, d, WT + h->w16_proj(l), d, b.big16, 4 * d, nullptr, (void*)pre, rows,
+        if (leaf_gemm(LEAF_BF16, EPI_ACTGRAD_T, b.dx16, d, WT + h->w16_proj(l), d, b.big16, 4 * d, nullptr, (void*)pre, rows,
                  4 * d, d, cf.activation, s, 0.f, fk)) return 1;
         if (wgrad(b.big16, 4 * d, xn2, fk, d, G + o.fc_w)) return 1;
         LEAF_TRY(leaf_launch_colsum(b.big16, 4 * d, rows, 4 * d, G + o.fc_b, s));
-        if (gemm(LEAF_BF16, EPI_STORE_F32, b.big16, 4 * d, WT + h->w16_fc(l), 4 * d, b.dxn, d, nullptr, nullptr, rows, d,
+        if (leaf_gemm(LEAF_BF16, EPI_STORE_F32, b.big16, 4 * d, WT + h->w16_fc(l), 4 * d, b.dxn, d, nullptr, nullptr, rows, d,
                  4 * d, 0, s)) return 1;
         LEAF_TRY(leaf_launch_layernorm_bwd(b.dxn, x1, P + o.ln2_w, cf.ln_eps, b.dx, b.dx16, G + o.ln2_w, G + o.ln2_b,
                                            rows, d, s));
         // ---- attention
         if (wgrad(b.dx16, d, ao, fk, d, G + o.out_w)) return 1;
         LEAF_TRY(leaf_launch_colsum(b.dx16, d, rows, d, G + o.out_b, s));
-        if (gemm(LEAF_BF16, EPI_STORE_T, b.dx16, d, WT + h->w16_out(l), d, b.do16, d, nullptr, nullptr, rows, d, d, 0, s)) return 1;
+        if (leaf_gemm(LEAF_BF16, EPI_STORE_T, b.dx16, d, WT + h->w16_out(l), d, b.do16, d, nullptr, nullptr, rows, d, d, 0, s)) return 1;
         LEAF_TRY(leaf_launch_attention_bwd(qkv, h->fwd_dtype, b.do16, b.dqkv, n_seq, cf.context_length, cf.heads, d, s));
         if (wgrad(b.dqkv, 3 * d, xn1, fk, d, G + o.qkv_w)) return 1;
         LEAF_TRY(leaf_launch_colsum(b.dqkv, 3 * d, rows, 3 * d, G + o.qkv_b, s));
-        if (gemm(LEAF_BF16, EPI_STORE_F32, b.dqkv, 3 * d, WT + h->w16_qkv(l), 3 * d, b.dxn, d, nullptr, nullptr, rows, d,
+        if (leaf_gemm(LEAF_BF16, EPI_STORE_F32, b.dqkv, 3 * d, WT + h->w16_qkv(l), 3 * d, b.dxn, d, nullptr, nullptr, rows, d,
                  3 * d, 0, s)) return 1;
         LEAF_TRY(leaf_launch_layernorm_bwd(b.dxn, xin, P + o.ln1_w, cf.ln_eps, b.dx, b.dx16, G + o.ln1_w, G + o.ln1_b,
                                            rows, d, s));

@@ -1,0 +1,110 @@
+"""One outer step of LEAF text-encoder adversarial fine-tuning on device tensors.
+
+The step of utils_AT.py:282-366 with the host string work replaced by token-id tensors (the benchmark's
+synthetic mode, SURVEY.md section 8d, and the inner engine of ``train_one_epoch_text_only``):
+
+    anchor = frozen.encode_text(base)                                   utils_AT.py:296
+    for _ in range(k):                                                  utils_attacks.py:310
+        stage 1: score rho candidates per caption (random positions)    :316-348
+        stage 2: score rho candidates at the winning position           :355-389
+    feat = model.encode_text(adv)  (train mode, stash)                  utils_AT.py:317-319
+    loss = mse(anchor, feat).sum(-1).mean(); backward                   :321-337
+    [one flat RCCL all-reduce of the gradient buffer]                   SURVEY.md section 8e
+    AdamW, zero_grad                                                    :339-362
+
+Data parallelism: every rank holds a full replica and its own B captions; the only exchange is ONE
+``all_reduce(SUM)`` over the flat fp32 gradient buffer per optimizer step (the 1/world factor is folded into
+the AdamW kernel's ``grad_scale``).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+
+@dataclass
+class StepConfig:
+    rho: int = 50
+    k_adv: int = 1
+    lr: float = 1e-5
+    wd: float = 1e-4
+    beta1: float = 0.9
+    beta2: float = 0.999
+    eps: float = 1e-8
+    accum_freq: int = 1
+
+
+class SyntheticCandidates:
+    """Device-side stand-in for the host string mutation: candidates are copies of the caption's token row with
+    one position resampled (stage 1: rho random positions; stage 2: rho random ids at the stage-1 winner's
+    position), generated with torch ops on the GPU so the step has the reference's data dependencies
+    (stage 2 depends on the stage-1 arg-max, the training batch on the stage-2 arg-max) without host syncs."""
+
+    def __init__(self, base: torch.Tensor, rho: int, vocab: int, seed: int):
+        self.base = base  # int32 [B, ctx]
+        self.rho, self.vocab = rho, vocab
+        self.gen = torch.Generator(device=base.device)
+        self.gen.manual_seed(seed)
+        self.B, self.ctx = base.shape
+        self.length = base.argmax(-1).to(torch.int64) - 1   # tokens between SOT and EOT
+
+    def stage1(self, cur: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        B, rho = self.B, self.rho
+        u = torch.rand(B, rho, device=cur.device, generator=self.gen)
+        pos = 1 + (u * self.length[:, None]).to(torch.int64).clamp_(max=self.ctx - 2)
+        ids = torch.randint(1, self.vocab - 2, (B, rho), device=cur.device, generator=self.gen, dtype=torch.int32)
+        cand = cur[:, None, :].repeat(1, rho, 1)
+        cand.scatter_(2, pos[:, :, None], ids[:, :, None])
+        return cand, pos
+
+    def stage2(self, cur: torch.Tensor, pos: torch.Tensor, best1: torch.Tensor) -> torch.Tensor:
+        B, rho = self.B, self.rho
+        p = pos.gather(1, best1.to(torch.int64)[:, None])                 # [B,1]
+        ids = torch.randint(1, self.vocab - 2, (B, rho), device=cur.device, generator=self.gen, dtype=torch.int32)
+        cand = cur[:, None, :].repeat(1, rho, 1)
+        cand.scatter_(2, p[:, :, None].expand(B, rho, 1), ids[:, :, None])
+        return cand
+
+
+def search_synthetic(model, anchor: torch.Tensor, base: torch.Tensor, cfg: StepConfig, seed: int) -> torch.Tensor:
+    """2k calls of score_candidates on [B*rho, ctx] synthetic candidates; returns the adversarial ids [B, ctx]."""
+    gen = SyntheticCandidates(base, cfg.rho, model.cfg.vocab_size, seed)
+    cur = base
+    B = base.shape[0]
+    ar = torch.arange(B, device=base.device)
+    for _ in range(cfg.k_adv):
+        cand, pos = gen.stage1(cur)
+        best1, _ = model.score_candidates(cand.view(B * cfg.rho, -1), anchor, cfg.rho, "l2", want_features=False)
+        cand = gen.stage2(cur, pos, best1)
+        best2, _ = model.score_candidates(cand.view(B * cfg.rho, -1), anchor, cfg.rho, "l2", want_features=False)
+        cur = cand[ar, best2.to(torch.int64)]
+    return cur
+
+
+def allreduce_grads(model) -> float:
+    """ONE flat all-reduce (sum) of the gradient buffer over RCCL; returns the factor AdamW must apply."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(model.grads, op=dist.ReduceOp.SUM)
+        return 1.0 / dist.get_world_size()
+    return 1.0
+
+
+def train_step_tokens(model, frozen, base: torch.Tensor, cfg: StepConfig, seed: int, lr: Optional[float] = None,
+                      micro_index: int = 0) -> torch.Tensor:
+    """Full outer step on token ids (int32 [B, ctx] on the model's device).  Returns the TextFARE loss (0-d)."""
+    model.eval()
+    anchor = frozen.encode_text(base)
+    adv = search_synthetic(model, anchor, base, cfg, seed)
+    model.train()
+    feat = model.forward_train(adv)
+    if micro_index % cfg.accum_freq == 0:
+        model.zero_grad()
+    loss = model.backward(feat, anchor, accum_scale=1.0 / cfg.accum_freq)
+    if (micro_index + 1) % cfg.accum_freq == 0:
+        scale = allreduce_grads(model)
+        model.adamw_step(lr if lr is not None else cfg.lr, (cfg.beta1, cfg.beta2), cfg.eps, cfg.wd, grad_scale=scale)
+        model.pack()
+    return loss

