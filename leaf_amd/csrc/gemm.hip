@@ -35,32 +35,33 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
     const int c = tid & 7, r0 = tid >> 3;
     const u16* __restrict__ A = (const u16*)p.A;
     const u16* __restrict__ B = (const u16*)p.B;
-    const u16* a_ptr[4];
-    const u16* b_ptr[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int ra = m0 + r0 + 32 * i; ra = ra < p.M ? ra : p.M - 1;
-        int rb = n0 + r0 + 32 * i;
-        a_ptr[i] = A + (size_t)ra * p.lda + 8 * c;
-        b_ptr[i] = B + (size_t)rb * p.ldb + 8 * c;
+    // rows r0 + 32 i share (row & 7) -> one swizzled LDS offset + i * 4096
+    const int soff = lds_off(r0, c);
+    auto arow = [&](int i) { int r = m0 + r0 + 32 * i; return r < p.M ? r : p.M - 1; };
+    const u16* a_ptr0 = A + (size_t)arow(0) * p.lda + 8 * c;
+    const u16* a_ptr1 = A + (size_t)arow(1) * p.lda + 8 * c;
+    const u16* a_ptr2 = A + (size_t)arow(2) * p.lda + 8 * c;
+    const u16* a_ptr3 = A + (size_t)arow(3) * p.lda + 8 * c;
+    const u16* b_ptr0 = B + (size_t)(n0 + r0) * p.ldb + 8 * c;
+    const u16* b_ptr1 = b_ptr0 + (size_t)32 * p.ldb;
+    const u16* b_ptr2 = b_ptr0 + (size_t)64 * p.ldb;
+    const u16* b_ptr3 = b_ptr0 + (size_t)96 * p.ldb;
+    // staging registers as first-class vector values (arrays of HIP's uint4 struct end up in scratch)
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3;
+#define G_LOAD(k0)                                                                                         \
+    sa0 = *(const u32x4*)(a_ptr0 + (k0)); sb0 = *(const u32x4*)(b_ptr0 + (k0));                            \
+    sa1 = *(const u32x4*)(a_ptr1 + (k0)); sb1 = *(const u32x4*)(b_ptr1 + (k0));                            \
+    sa2 = *(const u32x4*)(a_ptr2 + (k0)); sb2 = *(const u32x4*)(b_ptr2 + (k0));                            \
+    sa3 = *(const u32x4*)(a_ptr3 + (k0)); sb3 = *(const u32x4*)(b_ptr3 + (k0));
+#define S_STORE(buf)                                                                                       \
+    {                                                                                                      \
+        char* base_ = smem + (buf) * 2 * TILE_BYTES + soff;                                                \
+        *(u32x4*)(base_) = sa0;          *(u32x4*)(base_ + TILE_BYTES) = sb0;                              \
+        *(u32x4*)(base_ + 4096) = sa1;   *(u32x4*)(base_ + TILE_BYTES + 4096) = sb1;                       \
+        *(u32x4*)(base_ + 8192) = sa2;   *(u32x4*)(base_ + TILE_BYTES + 8192) = sb2;                       \
+        *(u32x4*)(base_ + 12288) = sa3;  *(u32x4*)(base_ + TILE_BYTES + 12288) = sb3;                      \
     }
-    uint4 sa[4], sb[4];
-    auto g_load = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            sa[i] = *(const uint4*)(a_ptr[i] + k0);
-            sb[i] = *(const uint4*)(b_ptr[i] + k0);
-        }
-    };
-    auto s_store = [&](int buf) {
-        char* base = smem + buf * 2 * TILE_BYTES;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int off = lds_off(r0 + 32 * i, c);
-            *(uint4*)(base + off) = sa[i];
-            *(uint4*)(base + TILE_BYTES + off) = sb[i];
-        }
-    };
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -68,33 +69,50 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nt = p.K / BK;
-    g_load(0);
-    s_store(0);
-    __syncthreads();
-
     const int frow = lane & 15, fkc = lane >> 4;
-    for (int t = 0; t < nt; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < nt) g_load((t + 1) * BK);
-        const char* sA = smem + cur * 2 * TILE_BYTES;
-        const char* sB = sA + TILE_BYTES;
+    // fragment byte offsets inside a tile (constant over the K loop)
+    int xo[2][4], wo[2][4];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            typename TT::vec8 xa[4], wb[4];
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                xa[i] = *(const typename TT::vec8*)(sA + lds_off(wm * 64 + i * 16 + frow, ks * 4 + fkc));
-                wb[i] = *(const typename TT::vec8*)(sB + lds_off(wn * 64 + i * 16 + frow, ks * 4 + fkc));
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = TT::mfma(wb[j], xa[i], acc[i][j]);
+        for (int i = 0; i < 4; ++i) {
+            xo[ks][i] = lds_off(wm * 64 + i * 16 + frow, ks * 4 + fkc);
+            wo[ks][i] = lds_off(wn * 64 + i * 16 + frow, ks * 4 + fkc);
         }
-        if (t + 1 < nt) s_store(cur ^ 1);
+#define COMPUTE(buf)                                                                              \
+    {                                                                                             \
+        const char* sA_ = smem + (buf) * 2 * TILE_BYTES;                                          \
+        const char* sB_ = sA_ + TILE_BYTES;                                                       \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                        \
+            typename TT::vec8 xa[4], wb[4];                                                       \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                       \
+                xa[i] = *(const typename TT::vec8*)(sA_ + xo[ks][i]);                             \
+                wb[i] = *(const typename TT::vec8*)(sB_ + wo[ks][i]);                             \
+            }                                                                                     \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                         \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                     \
+                    acc[i][j] = TT::mfma(wb[j], xa[i], acc[i][j]);                                \
+        }                                                                                         \
+    }
+
+    const int nt = p.K / BK;
+    G_LOAD(0)
+    S_STORE(0)
+    __syncthreads();
+    // steady state: prefetch tile t+1 into registers, MFMA on tile t, then park the prefetch in the other buffer
+    for (int t = 0; t < nt - 1; ++t) {
+        const int cur = t & 1;
+        G_LOAD((t + 1) * BK)
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch issue ABOVE the MFMAs (hipcc sinks it to its use)
+        COMPUTE(cur)
+        __builtin_amdgcn_sched_barrier(0);
+        S_STORE(cur ^ 1)
         __syncthreads();
     }
+    COMPUTE((nt - 1) & 1)
+#undef G_LOAD
+#undef S_STORE
+#undef COMPUTE
 
     // ---- epilogue: lane holds C[m][n..n+3], m = .. + (lane&15), n = .. + 4*(lane>>4)
     const int fq = lane >> 4;
