@@ -22,6 +22,44 @@ constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
+// one lane's 4 consecutive outputs C[m][n..n+3]
+template <class TT, int EPI>
+__device__ __forceinline__ void epilogue4(const GemmArgs& p, int m, int n, f32x4 a) {
+    float v[4] = {a[0], a[1], a[2], a[3]};
+    if (p.bias) {
+        float4 b = *(const float4*)(p.bias + n);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+    const size_t o = (size_t)m * p.ldc + n;
+    if constexpr (EPI == EPI_STORE_T) {
+        *(uint2*)((u16*)p.C + o) = pack4<TT>(v[0], v[1], v[2], v[3]);
+    } else if constexpr (EPI == EPI_ACT_T) {
+        if (p.aux) *(uint2*)((u16*)p.aux + o) = pack4<TT>(v[0], v[1], v[2], v[3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], p.act);
+        *(uint2*)((u16*)p.C + o) = pack4<TT>(v[0], v[1], v[2], v[3]);
+    } else if constexpr (EPI == EPI_RESID_F32) {
+        float4* x = (float4*)((float*)p.C + o);
+        float4 r = *x;
+        r.x += v[0]; r.y += v[1]; r.z += v[2]; r.w += v[3];
+        *x = r;
+    } else if constexpr (EPI == EPI_STORE_F32) {
+        float4* x = (float4*)((float*)p.C + o);
+        float4 r = p.beta != 0.f ? *x : float4{0.f, 0.f, 0.f, 0.f};
+        r.x = r.x * p.beta + v[0]; r.y = r.y * p.beta + v[1];
+        r.z = r.z * p.beta + v[2]; r.w = r.w * p.beta + v[3];
+        *x = r;
+    } else if constexpr (EPI == EPI_ACTGRAD_T) {
+        // aux holds the stashed pre-activation in the FORWARD operand type (aux_f16 tells which)
+        uint2 u = *(const uint2*)((const u16*)p.aux + o);
+        float pre[4];
+        if (p.aux_f16) unpack4<F16>(u, pre); else unpack4<BF16>(u, pre);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= act_bwd(pre[e], p.act);
+        *(uint2*)((u16*)p.C + o) = pack4<TT>(v[0], v[1], v[2], v[3]);
+    }
+}
+
 template <class TT, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -123,56 +161,131 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + wn * 64 + j * 16 + 4 * fq;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (p.bias) {
-                float4 b = *(const float4*)(p.bias + n);
-                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-            }
-            const size_t o = (size_t)m * p.ldc + n;
-            if constexpr (EPI == EPI_STORE_T) {
-                *(uint2*)((u16*)p.C + o) = pack4<TT>(v[0], v[1], v[2], v[3]);
-            } else if constexpr (EPI == EPI_ACT_T) {
-                if (p.aux) *(uint2*)((u16*)p.aux + o) = pack4<TT>(v[0], v[1], v[2], v[3]);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], p.act);
-                *(uint2*)((u16*)p.C + o) = pack4<TT>(v[0], v[1], v[2], v[3]);
-            } else if constexpr (EPI == EPI_RESID_F32) {
-                float4* x = (float4*)((float*)p.C + o);
-                float4 r = *x;
-                r.x += v[0]; r.y += v[1]; r.z += v[2]; r.w += v[3];
-                *x = r;
-            } else if constexpr (EPI == EPI_STORE_F32) {
-                float4* x = (float4*)((float*)p.C + o);
-                float4 r = p.beta != 0.f ? *x : float4{0.f, 0.f, 0.f, 0.f};
-                r.x = r.x * p.beta + v[0]; r.y = r.y * p.beta + v[1];
-                r.z = r.z * p.beta + v[2]; r.w = r.w * p.beta + v[3];
-                *x = r;
-            } else if constexpr (EPI == EPI_ACTGRAD_T) {
-                // aux holds the stashed pre-activation in the FORWARD operand type (aux_f16 tells which)
-                uint2 u = *(const uint2*)((const u16*)p.aux + o);
-                float pre[4];
-                if (p.aux_f16) unpack4<F16>(u, pre); else unpack4<BF16>(u, pre);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= act_bwd(pre[e], p.act);
-                *(uint2*)((u16*)p.C + o) = pack4<TT>(v[0], v[1], v[2], v[3]);
-            }
+            epilogue4<TT, EPI>(p, m, n, acc[i][j]);
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// 256x256x64 tile, 8 waves (2 x 4, 128 x 64 each), operands streamed HBM/L2 -> LDS by LDS-DMA
+// (global_load_lds_dwordx4, no staging registers), two 64-KiB stages, ONE raw s_barrier per K-tile:
+//     wait own DMA of tile t | barrier | issue DMA of tile t+1 into the other stage | MFMAs on tile t
+// so the next tile's transfer has the whole 64-MFMA phase to land.  The LDS image is lane-linear per DMA
+// piece (8 rows x 128 B), the XOR swizzle is applied to the per-lane SOURCE chunk and again on the read.
+// Halves L2->LDS bytes per FLOP vs the 128^2 kernel (1/128 B/FLOP) and LDS bytes per MFMA (0.375 KiB).
+constexpr int BM2 = 256, BN2 = 256;
+constexpr int TILE2 = BM2 * BK * 2;   // 32 KiB per operand per stage
+constexpr int STAGE2 = 2 * TILE2;     // 64 KiB
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+
+template <class TT, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+    const int tiles_n = p.N / BN2;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (logical / tiles_n) * BM2, n0 = (logical % tiles_n) * BN2;
+
+    // ---- DMA sources: wave w moves pieces w*4 + j (8 rows x 128 B each) of the A and of the B tile
+    const int prow = lane >> 3;                       // row inside the piece
+    const int schunk = (lane & 7) ^ prow;             // source-side swizzle (piece base is a multiple of 8 rows)
+    const u16* __restrict__ A = (const u16*)p.A;
+    const u16* __restrict__ B = (const u16*)p.B;
+    auto arow = [&](int j) { int r = m0 + (wid * 4 + j) * 8 + prow; return r < p.M ? r : p.M - 1; };
+    const u16* a0 = A + (size_t)arow(0) * p.lda + schunk * 8;
+    const u16* a1 = A + (size_t)arow(1) * p.lda + schunk * 8;
+    const u16* a2 = A + (size_t)arow(2) * p.lda + schunk * 8;
+    const u16* a3 = A + (size_t)arow(3) * p.lda + schunk * 8;
+    const u16* b0 = B + (size_t)(n0 + wid * 32 + prow) * p.ldb + schunk * 8;
+    const size_t bstep = (size_t)8 * p.ldb;
+    const int piece = wid * 4096;                     // byte offset of this wave's first piece inside a tile
+#define DMA16(src, dst) __builtin_amdgcn_global_load_lds((glb_void_t*)(src), (lds_void_t*)(dst), 16, 0, 0)
+#define ISSUE_TILE(stage, k0)                                                        \
+    {                                                                                \
+        char* sa_ = smem + (stage) * STAGE2 + piece;                                  \
+        char* sb_ = sa_ + TILE2;                                                     \
+        DMA16(a0 + (k0), sa_);          DMA16(a1 + (k0), sa_ + 1024);                \
+        DMA16(a2 + (k0), sa_ + 2048);   DMA16(a3 + (k0), sa_ + 3072);                \
+        DMA16(b0 + (k0), sb_);          DMA16(b0 + bstep + (k0), sb_ + 1024);        \
+        DMA16(b0 + 2 * bstep + (k0), sb_ + 2048); DMA16(b0 + 3 * bstep + (k0), sb_ + 3072); \
+    }
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fkc = lane >> 4;
+    // fragment offsets: rows frow + 16 i keep (row & 7) = frow & 7 -> one swizzled base per k-step + i * 2048
+    const int fo0 = lds_off(frow, fkc), fo1 = lds_off(frow, 4 + fkc);
+    const int xbase = wm * 128 * 128, wbase = TILE2 + wn * 64 * 128;
+#define COMPUTE2(stage)                                                                        \
+    {                                                                                          \
+        const char* st_ = smem + (stage) * STAGE2;                                             \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                     \
+            const int fo_ = ks ? fo1 : fo0;                                                    \
+            typename TT::vec8 xa[8], wb[4];                                                    \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                      \
+                wb[j] = *(const typename TT::vec8*)(st_ + wbase + fo_ + j * 2048);             \
+            _Pragma("unroll") for (int i = 0; i < 8; ++i)                                      \
+                xa[i] = *(const typename TT::vec8*)(st_ + xbase + fo_ + i * 2048);             \
+            _Pragma("unroll") for (int i = 0; i < 8; ++i)                                      \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                  \
+                    acc[i][j] = TT::mfma(wb[j], xa[i], acc[i][j]);                             \
+        }                                                                                      \
+    }
+
+    const int nt = p.K / BK;
+    ISSUE_TILE(0, 0)
+    for (int t = 0; t < nt - 1; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        ISSUE_TILE((t + 1) & 1, (t + 1) * BK)
+        COMPUTE2(t & 1)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    COMPUTE2((nt - 1) & 1)
+#undef DMA16
+#undef ISSUE_TILE
+#undef COMPUTE2
+
+    const int fq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + wm * 128 + i * 16 + frow;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) epilogue4<TT, EPI>(p, m, n0 + wn * 64 + j * 16 + 4 * fq, acc[i][j]);
     }
 }
 
 template <class TT>
 hipError_t launch_t(const GemmArgs& p, int epi, hipStream_t s) {
-    const int grid = ((p.M + BM - 1) / BM) * (p.N / BN);
-    const size_t lds = 4 * TILE_BYTES;
+    static int use256 = -1;
+    if (use256 < 0) { const char* e = getenv("LEAF_GEMM256"); use256 = (e && e[0] == '0') ? 0 : 1; }
+    const bool big = use256 && p.N % BN2 == 0 && p.M >= 2048;
+    const int grid = big ? ((p.M + BM2 - 1) / BM2) * (p.N / BN2) : ((p.M + BM - 1) / BM) * (p.N / BN);
+    const size_t lds = big ? 2 * STAGE2 : 4 * TILE_BYTES;
 #define LEAF_GEMM_CASE(E)                                                                    \
     case E: {                                                                                \
         static bool attr_done = false;                                                       \
         if (!attr_done) {                                                                    \
-            (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<TT, E>,                          \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
+            (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<TT, E>,                    \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES); \
+            (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<TT, E>,                 \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE2);     \
             attr_done = true;                                                                \
         }                                                                                    \
-        hipLaunchKernelGGL((gemm_nt_kernel<TT, E>), dim3(grid), dim3(256), lds, s, p);       \
+        if (big) hipLaunchKernelGGL((gemm_nt256_kernel<TT, E>), dim3(grid), dim3(512), lds, s, p); \
+        else hipLaunchKernelGGL((gemm_nt_kernel<TT, E>), dim3(grid), dim3(256), lds, s, p);  \
         break;                                                                               \
     }
     switch (epi) {
