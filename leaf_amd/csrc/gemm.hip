@@ -22,41 +22,67 @@ constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
-// one lane's 4 consecutive outputs C[m][n..n+3]
-template <class TT, int EPI>
-__device__ __forceinline__ void epilogue4(const GemmArgs& p, int m, int n, f32x4 a) {
-    float v[4] = {a[0], a[1], a[2], a[3]};
-    if (p.bias) {
-        float4 b = *(const float4*)(p.bias + n);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-    }
-    const size_t o = (size_t)m * p.ldc + n;
-    if constexpr (EPI == EPI_STORE_T) {
-        *(uint2*)((u16*)p.C + o) = pack4<TT>(v[0], v[1], v[2], v[3]);
-    } else if constexpr (EPI == EPI_ACT_T) {
-        if (p.aux) *(uint2*)((u16*)p.aux + o) = pack4<TT>(v[0], v[1], v[2], v[3]);
+// Epilogue for one accumulator row-group: NJ fragments (columns n0j + 16 j) of NI rows.  Bias is loaded once per
+// column group; read-modify-write operands (residual / pre-activation) are fetched for the whole batch BEFORE any
+// arithmetic so the loads overlap instead of serialising one L2 round trip per fragment.
+template <class TT, int EPI, int NI, int NJ>
+__device__ __forceinline__ void epilogue_block(const GemmArgs& p, const int (&m)[NI], int nbase, const float4 (&bias)[NJ],
+                                               f32x4 (&acc)[NI][NJ]) {
+    if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32) {
+        float4 r[NI][NJ];
+        const bool rd = (EPI == EPI_RESID_F32) || p.beta != 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], p.act);
-        *(uint2*)((u16*)p.C + o) = pack4<TT>(v[0], v[1], v[2], v[3]);
-    } else if constexpr (EPI == EPI_RESID_F32) {
-        float4* x = (float4*)((float*)p.C + o);
-        float4 r = *x;
-        r.x += v[0]; r.y += v[1]; r.z += v[2]; r.w += v[3];
-        *x = r;
-    } else if constexpr (EPI == EPI_STORE_F32) {
-        float4* x = (float4*)((float*)p.C + o);
-        float4 r = p.beta != 0.f ? *x : float4{0.f, 0.f, 0.f, 0.f};
-        r.x = r.x * p.beta + v[0]; r.y = r.y * p.beta + v[1];
-        r.z = r.z * p.beta + v[2]; r.w = r.w * p.beta + v[3];
-        *x = r;
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                r[i][j] = (rd && m[i] < p.M) ? *(const float4*)((const float*)p.C + (size_t)m[i] * p.ldc + nbase + 16 * j)
+                                             : float4{0.f, 0.f, 0.f, 0.f};
+        const float beta = (EPI == EPI_RESID_F32) ? 1.f : p.beta;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if (m[i] >= p.M) continue;
+                float4 o;
+                o.x = r[i][j].x * beta + acc[i][j][0] + bias[j].x; o.y = r[i][j].y * beta + acc[i][j][1] + bias[j].y;
+                o.z = r[i][j].z * beta + acc[i][j][2] + bias[j].z; o.w = r[i][j].w * beta + acc[i][j][3] + bias[j].w;
+                *(float4*)((float*)p.C + (size_t)m[i] * p.ldc + nbase + 16 * j) = o;
+            }
     } else if constexpr (EPI == EPI_ACTGRAD_T) {
-        // aux holds the stashed pre-activation in the FORWARD operand type (aux_f16 tells which)
-        uint2 u = *(const uint2*)((const u16*)p.aux + o);
-        float pre[4];
-        if (p.aux_f16) unpack4<F16>(u, pre); else unpack4<BF16>(u, pre);
+        uint2 u[NI][NJ];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= act_bwd(pre[e], p.act);
-        *(uint2*)((u16*)p.C + o) = pack4<TT>(v[0], v[1], v[2], v[3]);
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                u[i][j] = m[i] < p.M ? *(const uint2*)((const u16*)p.aux + (size_t)m[i] * p.ldc + nbase + 16 * j) : uint2{0u, 0u};
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if (m[i] >= p.M) continue;
+                float pre[4];
+                if (p.aux_f16) unpack4<F16>(u[i][j], pre); else unpack4<BF16>(u[i][j], pre);
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * act_bwd(pre[e], p.act);
+                *(uint2*)((u16*)p.C + (size_t)m[i] * p.ldc + nbase + 16 * j) = pack4<TT>(v[0], v[1], v[2], v[3]);
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if (m[i] >= p.M) continue;
+                float v[4] = {acc[i][j][0] + bias[j].x, acc[i][j][1] + bias[j].y, acc[i][j][2] + bias[j].z,
+                              acc[i][j][3] + bias[j].w};
+                const size_t o = (size_t)m[i] * p.ldc + nbase + 16 * j;
+                if constexpr (EPI == EPI_ACT_T) {
+                    if (p.aux) *(uint2*)((u16*)p.aux + o) = pack4<TT>(v[0], v[1], v[2], v[3]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], p.act);
+                }
+                *(uint2*)((u16*)p.C + o) = pack4<TT>(v[0], v[1], v[2], v[3]);
+            }
     }
 }
 
@@ -153,16 +179,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
 #undef COMPUTE
 
     // ---- epilogue: lane holds C[m][n..n+3], m = .. + (lane&15), n = .. + 4*(lane>>4)
-    const int fq = lane >> 4;
+    {
+        const int nbase = n0 + wn * 64 + 4 * (lane >> 4);
+        float4 bias4[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + frow;
-        if (m >= p.M) continue;
+        for (int j = 0; j < 4; ++j) bias4[j] = p.bias ? *(const float4*)(p.bias + nbase + 16 * j) : float4{0.f, 0.f, 0.f, 0.f};
+        int mrow[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + 4 * fq;
-            epilogue4<TT, EPI>(p, m, n, acc[i][j]);
-        }
+        for (int i = 0; i < 4; ++i) mrow[i] = m0 + wm * 64 + i * 16 + frow;
+        epilogue_block<TT, EPI, 4, 4>(p, mrow, nbase, bias4, acc);
     }
 }
 
@@ -246,8 +271,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        ISSUE_TILE((t + 1) & 1, (t + 1) * BK)
-        COMPUTE2(t & 1)
+        if (p.dbg != 1) ISSUE_TILE((t + 1) & 1, (t + 1) * BK)
+        if (p.dbg != 2) COMPUTE2(t & 1)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -257,13 +282,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs p) {
 #undef ISSUE_TILE
 #undef COMPUTE2
 
-    const int fq = lane >> 4;
+    {
+        const int nbase = n0 + wn * 64 + 4 * (lane >> 4);
+        float4 bias4[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int m = m0 + wm * 128 + i * 16 + frow;
-        if (m >= p.M) continue;
+        for (int j = 0; j < 4; ++j) bias4[j] = p.bias ? *(const float4*)(p.bias + nbase + 16 * j) : float4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) epilogue4<TT, EPI>(p, m, n0 + wn * 64 + j * 16 + 4 * fq, acc[i][j]);
+        for (int h = 0; h < 2; ++h) {   // two batches of 4 x 4 fragments: 16 loads in flight per lane
+            int mrow[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mrow[i] = m0 + wm * 128 + (4 * h + i) * 16 + frow;
+            f32x4 (&sub)[4][4] = *reinterpret_cast<f32x4 (*)[4][4]>(&acc[4 * h]);
+            epilogue_block<TT, EPI, 4, 4>(p, mrow, nbase, bias4, sub);
+        }
     }
 }
 
@@ -302,7 +333,11 @@ hipError_t launch_t(const GemmArgs& p, int epi, hipStream_t s) {
 
 }  // namespace
 
-hipError_t leaf_launch_gemm(const GemmArgs& p, int dtype, int epi, hipStream_t s) {
+hipError_t leaf_launch_gemm(const GemmArgs& p_in, int dtype, int epi, hipStream_t s) {
+    GemmArgs p = p_in;
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("LEAF_GEMM_DBG"); dbg = e ? atoi(e) : 0; }
+    p.dbg = dbg;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.N % BN || p.K % BK || p.lda % 8 || p.ldb % 8 || p.ldc % 4)
         return hipErrorInvalidValue;
     return dtype == LEAF_F16 ? launch_t<F16>(p, epi, s) : launch_t<BF16>(p, epi, s);

@@ -23,6 +23,7 @@ struct GemmArgs {
     int act;      // ACT_GELU / ACT_QUICKGELU
     int aux_f16;  // EPI_ACTGRAD_T: aux is fp16 (1) or bf16 (0)
     float beta;
+    int dbg;      // perf experiments only (LEAF_GEMM_DBG): 1 = no DMA in the K loop, 2 = no MFMA phase
 };
 
 hipError_t leaf_launch_gemm(const GemmArgs& p, int dtype, int epi, hipStream_t s);
