@@ -1,0 +1,332 @@
+"""Epoch loop, schedule, optimizer wrapper, text-only data readers and checkpointing for the LEAF text trainer.
+
+Mirrors the reference's host orchestration around the hot path:
+
+* ``train_one_epoch_text_only``  utils_AT.py:262-426 (same argument list; ``loss`` and ``scaler`` are accepted and
+  unused -- the reference never uses ``loss`` either, and bf16 gradient operands need no loss scaling)
+* ``cosine_lr`` / ``const_lr``   src/open_clip_train/scheduler.py:4-53
+* ``LeafAdamW``                  torch.optim.AdamW with the two groups of train_AT_text_only.py:323-341, executed
+  by ONE fused HIP kernel over the flat parameter buffer after ONE flat RCCL all-reduce
+* ``get_text_data``              captions only; the reference decodes, augments and then discards every image
+  (data_AT.py:499-503, utils_AT.py:290)
+* checkpoint / resume            train_AT_text_only.py:351-372,516-525
+"""
+from __future__ import annotations
+
+import csv
+import glob
+import io
+import logging
+import math
+import os
+import random
+import re
+import tarfile
+import time
+from typing import Iterator, List, Optional
+
+import numpy as np
+import torch
+
+from .attacks import DEFAULT_V, attack_text
+from .step import allreduce_grads
+
+LATEST_CHECKPOINT_NAME = "epoch_latest.pt"
+
+
+class AverageMeter:
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.val = self.avg = self.sum = self.count = 0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count
+
+
+def is_master(args, local=False):
+    return (getattr(args, "local_rank", 0) if local else getattr(args, "rank", 0)) == 0
+
+
+def unwrap_model(model):
+    return model.module if hasattr(model, "module") else model
+
+
+# ----------------------------------------------------------------------------- schedule
+def _assign_lr(optimizer, lr):
+    for g in optimizer.param_groups:
+        g["lr"] = lr
+
+
+def cosine_lr(optimizer, base_lr, warmup_length, steps):
+    def _lr_adjuster(step):
+        if step < warmup_length:
+            lr = base_lr * (step + 1) / warmup_length
+        else:
+            e, es = step - warmup_length, steps - warmup_length
+            lr = 0.5 * (1 + np.cos(np.pi * e / es)) * base_lr
+        _assign_lr(optimizer, lr)
+        return lr
+    return _lr_adjuster
+
+
+def const_lr(optimizer, base_lr, warmup_length, steps):
+    def _lr_adjuster(step):
+        lr = base_lr * (step + 1) / warmup_length if step < warmup_length else base_lr
+        _assign_lr(optimizer, lr)
+        return lr
+    return _lr_adjuster
+
+
+# ----------------------------------------------------------------------------- optimizer
+class LeafAdamW:
+    """AdamW over the engine's flat buffers.  ``param_groups`` mirrors the reference's two groups (excluded tensors
+    first with weight_decay 0, the rest with ``--wd``) so schedulers and loggers that poke ``param_groups[0]['lr']``
+    work unchanged."""
+
+    def __init__(self, model, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.model = model.enable_training()
+        nd = model.n_decay
+        excl = [k for k, (off, _) in model.layout.items() if off >= nd]
+        rest = [k for k, (off, _) in model.layout.items() if off < nd]
+        self.param_groups = [
+            {"params": excl, "weight_decay": 0.0, "lr": lr, "betas": tuple(betas), "eps": eps},
+            {"params": rest, "weight_decay": weight_decay, "lr": lr, "betas": tuple(betas), "eps": eps}]
+
+    def step(self):
+        g = self.param_groups[1]
+        scale = allreduce_grads(self.model)   # the single collective of the step
+        self.model.adamw_step(g["lr"], g["betas"], g["eps"], g["weight_decay"], grad_scale=scale)
+        self.model.pack()
+
+    def zero_grad(self):
+        self.model.zero_grad()
+
+    def state_dict(self):
+        m = self.model
+        return {"step": m.opt_step, "exp_avg": m.exp_avg.cpu(), "exp_avg_sq": m.exp_avg_sq.cpu(),
+                "layout": {k: (off, list(shape)) for k, (off, shape) in m.layout.items()},
+                "param_groups": [{k: v for k, v in g.items()} for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        m = self.model
+        m.opt_step = int(sd["step"])
+        m.exp_avg.copy_(sd["exp_avg"])
+        m.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        for g, s in zip(self.param_groups, sd["param_groups"]):
+            g.update({k: v for k, v in s.items() if k != "params"})
+
+
+# ----------------------------------------------------------------------------- data (captions only)
+def _expand_braces(pattern: str) -> List[str]:
+    """'{00000000..00001287}.tar' style ranges and '::'-separated sources (what braceexpand does for the scripts)."""
+    out = []
+    for part in pattern.split("::"):
+        m = re.search(r"\{(\d+)\.\.(\d+)\}", part)
+        if not m:
+            out += sorted(glob.glob(part)) or [part]
+            continue
+        a, b, width = int(m.group(1)), int(m.group(2)), len(m.group(1))
+        for i in range(a, b + 1):
+            out += _expand_braces(part[:m.start()] + str(i).zfill(width) + part[m.end():])
+    return out
+
+
+def _iter_tar_captions(paths: List[str]) -> Iterator[str]:
+    for path in paths:
+        try:
+            with tarfile.open(path) as tf:
+                for member in tf:
+                    if member.isfile() and member.name.endswith(".txt"):
+                        yield tf.extractfile(member).read().decode("utf-8", errors="replace").strip()
+        except (tarfile.TarError, OSError) as e:   # data_AT.py:285-288 log_and_continue
+            logging.warning(f"skipping shard {path}: {e}")
+
+
+class TextLoader:
+    """Iterable of ``(None, texts)`` batches (the reference's batches are ``(images, texts)`` with the images
+    discarded at utils_AT.py:290).  Sharded across ranks by stride; reshuffled per epoch with seed + epoch."""
+
+    def __init__(self, captions: Optional[List[str]], shards: Optional[List[str]], batch_size, num_samples, rank, world,
+                 seed):
+        self.captions, self.shards = captions, shards
+        self.batch_size, self.rank, self.world, self.seed = batch_size, rank, world, seed
+        self.epoch = 0
+        self.num_samples = num_samples
+        self.num_batches = max(1, math.ceil(num_samples / (batch_size * world)))
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def _stream(self) -> Iterator[str]:
+        rng = random.Random(self.seed + self.epoch)
+        if self.captions is not None:
+            idx = list(range(len(self.captions)))
+            rng.shuffle(idx)
+            while True:
+                for i in idx[self.rank::self.world]:
+                    yield self.captions[i]
+        else:
+            shards = list(self.shards)
+            rng.shuffle(shards)
+            mine = shards[self.rank::self.world] or shards
+            while True:
+                yield from _iter_tar_captions(mine)
+
+    def __iter__(self):
+        it = self._stream()
+        for _ in range(self.num_batches):
+            yield None, [next(it) for _ in range(self.batch_size)]
+
+    def __len__(self):
+        return self.num_batches
+
+
+class DataInfo:
+    def __init__(self, loader: TextLoader):
+        self.dataloader = loader
+
+    def set_epoch(self, epoch):
+        self.dataloader.set_epoch(epoch)
+
+
+_SYN_WORDS = ("a photo of the small red car on wet street with two people near old house in sunny park at night "
+              "dog cat bird tree river bridge mountain snow beach city table chair").split()
+
+
+def get_text_data(args, epoch=0):
+    rank, world = getattr(args, "rank", 0), getattr(args, "world_size", 1)
+    kind, src = args.dataset_type, args.train_data
+    if kind == "auto":
+        kind = "synthetic" if not src else ("webdataset" if src.endswith(".tar") or "{" in src else
+                                             ("csv" if src.endswith((".csv", ".tsv")) else "text"))
+    captions = shards = None
+    if kind == "synthetic":
+        rng = random.Random(args.seed)
+        n = args.train_num_samples or 1024
+        captions = [" ".join(rng.choice(_SYN_WORDS) for _ in range(rng.randint(3, 14))) for _ in range(n)]
+    elif kind == "text":
+        with open(src) as f:
+            captions = [l.strip() for l in f if l.strip()]
+    elif kind == "csv":
+        with open(src, newline="") as f:
+            captions = [row[args.csv_caption_key] for row in csv.DictReader(f, delimiter=getattr(args, "csv_separator", "\t"))]
+    else:
+        shards = _expand_braces(src)
+    n = args.train_num_samples or (len(captions) if captions is not None else None)
+    if n is None:
+        raise ValueError("--train-num-samples is required for webdataset shards (data_AT.py:455-465)")
+    loader = TextLoader(captions, shards, args.batch_size, n, rank, world, args.seed)
+    loader.set_epoch(epoch)
+    return {"train": DataInfo(loader)}
+
+
+# ----------------------------------------------------------------------------- the epoch loop
+def train_one_epoch_text_only(model, model_frozen, tokenizer, V, data, loss, epoch, optimizer, scaler, scheduler, args,
+                              tb_writer=None):
+    if getattr(args, "use_charmer", False):
+        raise NotImplementedError("--use_charmer (per-sentence Charmer attack) is outside the accelerated path")
+    if getattr(args, "horovod", False):
+        raise NotImplementedError("horovod is not supported; launch with torch.distributed.run (RCCL)")
+    if getattr(args, "normalize_fare", False):
+        raise NotImplementedError("--normalize_fare is not implemented in the training kernels")
+    device = torch.device(args.device)
+    model.train()
+    data['train'].set_epoch(epoch)
+    dataloader = data['train'].dataloader
+    num_batches_per_epoch = dataloader.num_batches // args.accum_freq
+    sample_digits = math.ceil(math.log(dataloader.num_samples + 1, 10))
+    losses_m, losses_accum, times = {}, {}, []
+    batch_time_m, data_time_m = AverageMeter(), AverageMeter()
+    log_data = {}
+    end = time.time()
+    for i, batch in enumerate(dataloader):
+        i_accum = i // args.accum_freq
+        step = num_batches_per_epoch * epoch + i_accum
+        if not args.skip_scheduler:
+            scheduler(step)
+        _, texts = batch
+        model.eval()
+        anchor = model_frozen.encode_text(tokenizer.encode_batch(texts))
+        t0 = time.time()
+        _, adv_texts = attack_text(model, tokenizer, texts, anchor, device, objective='l2', n=args.rho, k=args.k_adv,
+                                   V=V, constrain=args.constrain, debug=False)
+        times.append(time.time() - t0)
+        adv_tokens = tokenizer.encode_batch(adv_texts)
+        model.train()
+        feat = model.forward_train(adv_tokens)
+        data_time_m.update(time.time() - end)
+        loss_fare = model.backward(feat, anchor, accum_scale=1.0 / args.accum_freq)   # device scalar, no sync
+        for key in ("loss", "loss_FARE_text"):
+            losses_accum[key] = losses_accum.get(key, 0) + loss_fare / args.accum_freq
+        if args.grad_clip_norm is not None:
+            raise NotImplementedError("--grad-clip-norm (default off, params_AT.py:388-390) is not implemented")
+        if (i + 1) % args.accum_freq == 0:
+            optimizer.step()
+            optimizer.zero_grad()
+        with torch.no_grad():
+            unwrap_model(model).logit_scale.clamp_(0, math.log(100))
+        batch_time_m.update(time.time() - end)
+        end = time.time()
+        batch_count = i_accum + 1
+        if is_master(args) and (i + 1) % args.accum_freq == 0 and (
+                batch_count % args.log_every_n_steps == 0 or batch_count == num_batches_per_epoch):
+            batch_size = len(texts)
+            num_samples = batch_count * batch_size * args.accum_freq * args.world_size
+            percent_complete = 100.0 * batch_count / num_batches_per_epoch
+            for key, val in losses_accum.items():
+                losses_m.setdefault(key, AverageMeter()).update(float(val), batch_size)
+            loss_log = " ".join(f"{n.capitalize()}: {m.val:#.5g} ({m.avg:#.5g})" for n, m in losses_m.items())
+            sps = args.accum_freq * args.batch_size * args.world_size / batch_time_m.val
+            sps_gpu = args.accum_freq * args.batch_size / batch_time_m.val
+            logging.info(
+                f"Train Epoch: {epoch} [{num_samples:>{sample_digits}}/{dataloader.num_samples} ({percent_complete:.0f}%)] "
+                f"Data (t): {data_time_m.avg:.3f} Batch (t): {batch_time_m.avg:.3f}, {sps:#g}/s, {sps_gpu:#g}/s/gpu "
+                f"LR: {optimizer.param_groups[0]['lr']:5f} " + loss_log)
+            log_data = {"data_time": data_time_m.val, "batch_time": batch_time_m.val, "samples_per_second": sps,
+                        "samples_per_second_per_gpu": sps_gpu, "lr": optimizer.param_groups[0]["lr"]}
+            log_data.update({name: val.val for name, val in losses_m.items()})
+            log_data = {"train/" + name: val for name, val in log_data.items()}
+            if tb_writer is not None:
+                for name, val in log_data.items():
+                    tb_writer.add_scalar(name, val, step)
+            batch_time_m.reset()
+            data_time_m.reset()
+        if (i + 1) % args.accum_freq == 0:
+            losses_accum = {}
+    if is_master(args):  # the reference rewrites this file every step (utils_AT.py:311); same content at epoch end
+        with open(f"times_{getattr(args, 'use_charmer', False)}.csv", "w") as f:
+            f.write("0\n" + "\n".join(str(t) for t in times) + "\n")
+    return log_data
+
+
+# ----------------------------------------------------------------------------- checkpoints
+def natural_key(s):
+    return [int(t) if t.isdigit() else t for t in re.split(r'(\d+)', s.lower())]
+
+
+def get_latest_checkpoint(path: str):
+    cks = sorted(glob.glob(os.path.join(path, '**', '*.pt'), recursive=True), key=natural_key)
+    return cks[-1] if cks else None
+
+
+def save_checkpoint(path, epoch, name, model, optimizer):
+    from .checkpoint import save_training_checkpoint
+    save_training_checkpoint(path, epoch, name, model, optimizer.state_dict())
+
+
+def load_checkpoint(path, model, optimizer=None):
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    if "epoch" in ck:
+        model.load_state_dict(ck["state_dict"])
+        if optimizer is not None and "optimizer" in ck and "exp_avg" in ck["optimizer"]:
+            optimizer.load_state_dict(ck["optimizer"])
+        model.pack()
+        return ck["epoch"]
+    model.load_state_dict(ck)
+    model.pack()
+    return 0

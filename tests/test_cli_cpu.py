@@ -1,0 +1,71 @@
+"""Host logic of the CLI drop-in on CPU: flag set, Adam defaults, schedule, shard expansion, caption readers."""
+import io
+import json
+import os
+import tarfile
+
+import numpy as np
+import pytest
+
+from leaf_amd import params as P
+from leaf_amd import train as T
+
+REF_SCRIPT_FLAGS = """--save-frequency 1 --zeroshot-frequency 1 --report-to wandb --wandb-project-name datacomp_small
+ --train-data path/{00000000..00000003}.tar --imagenet-val=path/to/imagenet/val --val-text-classification fancyzhx/ag_news
+ --warmup 1400 --batch-size=128 --accum-freq=1 --lr=1e-5 --wd=1e-4 --epochs=30 --workers=8 --model hf-hub:chs20/fare2-clip
+ --dataset-type webdataset --train-num-samples 80000 --val-num-samples 1024 --k_adv 1 --k_adv_test 1 --rho=50
+ --n_charmer_test=20 --n_val_imagenet 1000 --seed 1 --custom_out_folder ViT-L-FARE2_constrained_ --constrain""".split()
+
+
+def test_reference_launch_script_flags_parse():
+    a = P.parse_args(REF_SCRIPT_FLAGS)     # scripts/train_leaf_vitl.sh
+    assert (a.batch_size, a.rho, a.k_adv, a.lr, a.wd, a.warmup, a.epochs, a.seed) == (128, 50, 1, 1e-5, 1e-4, 1400, 30, 1)
+    assert a.constrain and a.custom_out_folder == "ViT-L-FARE2_constrained_"
+    # params_AT.py:17-23,600-604: "vit" is not in "hf-hub:chs20/fare2-clip" -> beta2 0.999 / eps 1e-8
+    assert (a.beta1, a.beta2, a.eps) == (0.9, 0.999, 1e-8)
+    b = P.parse_args(["--model", "hf-hub:laion/CLIP-ViT-H-14-laion2B-s32B-b79K"])
+    assert (b.beta2, b.eps, b.lr, b.rho, b.wd, b.warmup) == (0.98, 1e-6, 5e-4, 20, 0.2, 10000)
+
+
+def test_cosine_lr_matches_reference_values(golden_dir):
+    c = json.load(open(os.path.join(golden_dir, "manifest.json")))["cosine_lr"]
+
+    class Opt:
+        param_groups = [{"lr": 0.0}, {"lr": 0.0}]
+    sched = T.cosine_lr(Opt, c["base_lr"], c["warmup"], c["steps"])
+    for s, v in c["values"].items():
+        sched(int(s))
+        assert abs(Opt.param_groups[0]["lr"] - v) < 1e-12 and Opt.param_groups[1]["lr"] == Opt.param_groups[0]["lr"]
+
+
+def test_brace_expansion_and_tar_caption_reader(tmp_path):
+    assert T._expand_braces("a/{0008..0011}.tar") == [f"a/{i:04d}.tar" for i in range(8, 12)]
+    assert T._expand_braces("x/{1..2}.tar::y/{7..7}.tar") == ["x/1.tar", "x/2.tar", "y/7.tar"]
+    shard = tmp_path / "00000000.tar"
+    with tarfile.open(shard, "w") as tf:
+        for i in range(6):
+            for ext, payload in ((".jpg", b"\xff\xd8not-an-image"), (".txt", f"caption number {i}".encode())):
+                ti = tarfile.TarInfo(f"s{i:03d}{ext}")
+                ti.size = len(payload)
+                tf.addfile(ti, io.BytesIO(payload))
+    caps = list(T._iter_tar_captions([str(shard), str(tmp_path / "missing.tar")]))   # missing shard is skipped
+    assert caps == [f"caption number {i}" for i in range(6)]
+    args = P.parse_args(["--train-data", str(tmp_path / "{00000000..00000000}.tar"), "--dataset-type", "webdataset",
+                         "--train-num-samples", "6", "--batch-size", "3"])
+    args.rank, args.world_size = 0, 1
+    data = T.get_text_data(args)
+    batches = list(data["train"].dataloader)
+    assert len(batches) == 2 and all(b[0] is None and len(b[1]) == 3 for b in batches)
+
+
+def test_synthetic_and_text_datasets(tmp_path):
+    f = tmp_path / "caps.txt"
+    f.write_text("a cat\n\na dog\nthe red car\n")
+    args = P.parse_args(["--train-data", str(f), "--batch-size", "2"])
+    args.rank, args.world_size = 0, 1
+    d = T.get_text_data(args)["train"].dataloader
+    assert d.num_samples == 3 and d.num_batches == 2
+    args = P.parse_args(["--dataset-type", "synthetic", "--train-num-samples", "10", "--batch-size", "4"])
+    args.rank, args.world_size = 0, 1
+    d = T.get_text_data(args)["train"].dataloader
+    assert d.num_batches == 3 and all(isinstance(t, str) and t for _, b in d for t in b)

@@ -1,0 +1,44 @@
+"""End-to-end CLI on the GPU (tiny model, synthetic captions): experiment folder, results.csv, epoch_latest.pt in the
+reference's checkpoint layout, resume, HF key round trip."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_train_cli_checkpoint_and_resume(tmp_path, monkeypatch):
+    import torch
+    import train_AT_text_only as cli
+    monkeypatch.chdir(tmp_path)
+    common = ["--model", "tiny-test-quickgelu", "--dataset-type", "synthetic", "--train-num-samples", "24", "--batch-size", "8",
+              "--lr", "1e-4", "--wd", "1e-4", "--warmup", "2", "--rho", "6", "--k_adv", "1", "--seed", "1",
+              "--custom_out_folder", "t_", "--logs", str(tmp_path / "logs"), "--name", "run"]
+    assert cli.main(common + ["--epochs", "1"]) == 0
+    out = tmp_path / "results" / "t_text_only_k1_rho6_seed1"
+    ck = torch.load(out / "epoch_latest.pt", map_location="cpu", weights_only=False)
+    assert set(ck) == {"epoch", "name", "state_dict", "optimizer"} and ck["epoch"] == 1      # train_AT_text_only.py:516-525
+    assert "transformer.resblocks.1.attn.in_proj_weight" in ck["state_dict"] and "logit_scale" in ck["state_dict"]
+    assert ck["optimizer"]["step"] == 3
+    rows = open(out / "results.csv").read().strip().splitlines()
+    assert len(rows) == 2 and "loss" in rows[0]
+    assert os.path.exists(tmp_path / "logs" / "run" / "params.txt")
+    assert cli.main(common + ["--epochs", "1"]) == -1                                         # experiment exists
+    assert cli.main(common[:-1] + ["run2", "--epochs", "2", "--resume", str(out / "epoch_latest.pt")]) == 0
+    ck2 = torch.load(out / "epoch_latest.pt", map_location="cpu", weights_only=False)
+    assert ck2["epoch"] == 2 and ck2["optimizer"]["step"] == 6
+    assert not torch.equal(ck["state_dict"]["text_projection"], ck2["state_dict"]["text_projection"])
+
+
+def test_hf_key_roundtrip_gives_same_embeddings():
+    import torch
+    from leaf_amd.checkpoint import openclip_to_hf
+    from leaf_amd.model import LeafCLIPText, create_model, get_config
+    from oracle import text_oracle as O
+    m = create_model("tiny-test", seed=11)
+    hf = openclip_to_hf(m.state_dict(), m.cfg)
+    assert "text_model.encoder.layers.0.self_attn.q_proj.weight" in hf and hf["text_projection.weight"].shape == (64, 128)
+    m2 = LeafCLIPText(get_config("tiny-test")).load_state_dict(hf)
+    toks = O.synthetic_tokens(5, seed=1)
+    assert np.array_equal(m.encode_text(toks).cpu().numpy(), m2.encode_text(toks).cpu().numpy())

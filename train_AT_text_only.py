@@ -1,0 +1,135 @@
+#!/usr/bin/env python3
+"""LEAF text-encoder adversarial fine-tuning on MI355X -- command-line drop-in for the reference's
+``train_AT_text_only.py`` (same flags: leaf_amd/params.py; same experiment folder, ``results.csv`` and
+``epoch_latest.pt`` layout: train_AT_text_only.py:57,483,516-525).
+
+    python3 train_AT_text_only.py --model hf-hub:chs20/fare2-clip --pretrained /path/to/open_clip_pytorch_model.bin \
+        --train-data 'shards/{00000000..00001287}.tar' --dataset-type webdataset --train-num-samples 80000 \
+        --batch-size 128 --lr 1e-5 --wd 1e-4 --warmup 1400 --epochs 30 --k_adv 1 --rho 50 --constrain --seed 1
+    python3 -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train_AT_text_only.py ...   # RCCL DP
+
+Differences from the reference, all outside the hot path: downstream evaluation (ImageNet / AG-News zero-shot,
+utils_AT.py:428-556) is not run; ``hf-hub:`` ids select the architecture but weights come from ``--pretrained``
+(no network); with WORLD_SIZE > 1 the step really is data parallel (the reference's DDP wrapper cannot reach
+``encode_text``).
+"""
+import logging
+import os
+import random
+import string
+import sys
+from datetime import datetime
+
+import numpy as np
+import torch
+
+from leaf_amd.params import parse_args
+from leaf_amd.tokenizer import get_tokenizer
+from leaf_amd.train import (LATEST_CHECKPOINT_NAME, LeafAdamW, const_lr, cosine_lr, get_latest_checkpoint, get_text_data,
+                            is_master, load_checkpoint, save_checkpoint, train_one_epoch_text_only)
+
+
+def random_seed(seed=42, rank=0):
+    torch.manual_seed(seed + rank)
+    np.random.seed(seed + rank)
+    random.seed(seed + rank)
+
+
+def init_distributed_device(args):
+    args.distributed, args.world_size, args.rank, args.local_rank = False, 1, 0, 0
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        args.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(args.local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group(backend=args.dist_backend)
+        args.world_size, args.rank, args.distributed = torch.distributed.get_world_size(), torch.distributed.get_rank(), True
+    if not torch.cuda.is_available():
+        raise SystemExit("train_AT_text_only.py needs an MI355X: the HIP engine has no CPU path")
+    args.device = f"cuda:{args.local_rank}"
+    torch.cuda.set_device(args.device)
+    return torch.device(args.device)
+
+
+def main(argv):
+    args = parse_args(argv)
+    V = [-1] + [ord(c) for c in string.ascii_lowercase + ' ' + string.ascii_uppercase + string.digits + string.punctuation]
+    device = init_distributed_device(args)
+    if args.name is None:
+        safe = args.model.replace('/', '-').replace(':', '-')
+        date_str = datetime.now().strftime("%Y_%m_%d-%H_%M_%S")
+        if args.distributed:
+            obj = [date_str]
+            torch.distributed.broadcast_object_list(obj, src=0)
+            date_str = obj[0]
+        args.name = '-'.join([date_str, f"model_{safe}", f"lr_{args.lr}", f"b_{args.batch_size}", f"f_{args.accum_freq}",
+                              f"k_{args.k_adv}", f"rho{args.rho}"])
+    log_base = os.path.join(args.logs, args.name)
+    args.checkpoint_path = os.path.join(log_base, "checkpoints")
+    handlers = [logging.StreamHandler()]
+    if is_master(args):
+        os.makedirs(args.checkpoint_path, exist_ok=True)
+        log_path = os.path.join(log_base, "out.log")
+        if os.path.exists(log_path) and args.resume != "latest":
+            print("Error. Experiment already exists. Use --name {} to specify a new experiment.")
+            return -1
+        handlers.append(logging.FileHandler(log_path))
+    logging.basicConfig(level=logging.INFO, format="%(asctime)s | %(levelname)s | %(message)s", handlers=handlers)
+    if args.resume == "latest":
+        args.resume = get_latest_checkpoint(args.checkpoint_path)
+
+    from leaf_amd.model import LeafCLIPText, create_model
+    dtype = "bf16" if "bf16" in args.precision or "bfloat16" in args.precision else "fp16"
+    if args.precision == "fp32":
+        logging.warning("--precision fp32 is not offered by the MFMA path; using fp16 operands with fp32 accumulation")
+    name = args.model + ("-quickgelu" if args.force_quick_gelu and not args.model.endswith("quickgelu") and not args.model.startswith("hf-hub:") else "")
+    model = create_model(name, device=device, dtype=dtype, pretrained=args.pretrained or None, trainable=True, seed=args.seed)
+    random_seed(args.seed, args.rank)
+    if is_master(args):
+        with open(os.path.join(log_base, "params.txt"), "w") as f:
+            for k in sorted(vars(args)):
+                f.write(f"{k}: {getattr(args, k)}\n")
+    optimizer = LeafAdamW(model, lr=args.lr, betas=(args.beta1, args.beta2), eps=args.eps, weight_decay=args.wd)
+    start_epoch = 0
+    if args.resume:
+        start_epoch = load_checkpoint(args.resume, model, optimizer)
+        logging.info(f"=> resuming checkpoint '{args.resume}' (epoch {start_epoch})")
+    tokenizer = get_tokenizer(args.model)
+    if args.constrain:
+        from leaf_amd import attacks
+        attacks.set_dictionary(attacks.Dictionary.from_file(args.dictionary_file) if args.dictionary_file
+                               else attacks.Dictionary.from_nltk())
+    data = get_text_data(args, epoch=start_epoch)
+    total_steps = (data["train"].dataloader.num_batches // args.accum_freq) * args.epochs
+    scheduler = (cosine_lr if args.lr_scheduler == "cosine" else const_lr)(optimizer, args.lr, args.warmup, total_steps)
+    # frozen anchor model = the weights the run STARTED from (train_AT_text_only.py:439-465)
+    frozen = LeafCLIPText(model.cfg, device=device, dtype=dtype)
+    if args.resume and args.pretrained:
+        from leaf_amd.checkpoint import load_checkpoint_file
+        frozen.load_state_dict(load_checkpoint_file(args.pretrained))
+    else:
+        frozen.copy_from(model)
+    frozen.pack()
+    model.pack()
+    out_dir = f'./results/{args.custom_out_folder}text_only_k{args.k_adv}_rho{args.rho}_seed{args.seed}'
+    if is_master(args):
+        os.makedirs(out_dir, exist_ok=True)
+    results = []
+    for epoch in range(start_epoch, args.epochs):
+        if is_master(args):
+            logging.info(f'Start epoch {epoch}')
+        log = train_one_epoch_text_only(model, frozen, tokenizer, V, data, None, epoch, optimizer, None, scheduler, args)
+        completed = epoch + 1
+        if is_master(args):
+            results.append({"epoch": completed, **{k.replace("train/", ""): v for k, v in log.items()}})
+            import pandas as pd
+            pd.DataFrame(results).to_csv(os.path.join(out_dir, "results.csv"), index=False)
+            if completed == args.epochs or (args.save_frequency > 0 and completed % args.save_frequency == 0):
+                save_checkpoint(os.path.join(out_dir, LATEST_CHECKPOINT_NAME), completed, args.name, model, optimizer)
+    if args.distributed:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]) or 0)
