@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--k-adv", type=int, default=int(os.environ.get("LEAF_BENCH_K", "1")))
     ap.add_argument("--dtype", default=os.environ.get("LEAF_DTYPE", "fp16"), choices=["fp16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dense", action="store_true", help="compute all 77 rows per sequence (no EOT trimming)")
     ap.add_argument("--cpu-batch", type=int, default=2)
     args = ap.parse_args()
 
@@ -113,6 +114,7 @@ def main():
         base[i, 0] = cfg.vocab_size - 2
         base[i, 1:1 + n] = torch.randint(1, cfg.vocab_size - 2, (n,), generator=g, dtype=torch.int32)
         base[i, 1 + n] = cfg.vocab_size - 1
+    base_lens = None if args.dense else (lens.numpy().astype(np.int32) + 2)   # SOT + n ids + EOT rows are kept
     base = base.to(dev)
 
     def barrier():
@@ -122,7 +124,7 @@ def main():
 
     step_id = 0
     for _ in range(args.warmup):
-        train_step_tokens(model, frozen, base, sc, seed=step_id)
+        train_step_tokens(model, frozen, base, sc, seed=step_id, base_lens=base_lens)
         step_id += 1
     lib = _lib.lib()
     barrier()
@@ -131,7 +133,7 @@ def main():
     t0 = time.perf_counter()
     loss = None
     for _ in range(args.steps):
-        loss = train_step_tokens(model, frozen, base, sc, seed=step_id)
+        loss = train_step_tokens(model, frozen, base, sc, seed=step_id, base_lens=base_lens)
         step_id += 1
     barrier()
     dt = time.perf_counter() - t0
@@ -174,6 +176,10 @@ def main():
             },
             "step_mfma_frac": value * flops_per_sample / (world * PEAK_TFLOPS_16BIT * 1e12),
             "algorithmic_tflop_per_sample": flops_per_sample / 1e12,
+            "exact_work_skipping": "none (dense, 77 rows per sequence)" if args.dense else
+                                   "EOT trimming: rows after EOT are not computed (bit-identical outputs); "
+                                   f"mean kept rows {float(base_lens.mean()):.1f} of 77",
+            "executed_gemm_tflop_per_step": gemm_total_fl / args.steps / 1e12,
             "loss": float(loss),
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -61,27 +61,37 @@ int leaf_text_pack_weights(leaf_text_t h, const float* params, void* w16_fwd, vo
 size_t leaf_text_workspace_bytes(leaf_text_t h, int n_seq, int mode);
 size_t leaf_text_stash_bytes(leaf_text_t h, int n_seq);
 
+/* Exact work skipping ("EOT trimming"): the causal mask makes a sequence's pooled EOT state independent of every
+ * position after EOT, so only the first len = eot_pos + 1 rows of each sequence need computing.  Entry points that
+ * run the layer stack take an OPTIONAL pair: seq_lens (HOST int32 [n_seq], 1..ctx) and cu_rows (DEVICE int32
+ * [n_seq+1], exclusive prefix sum of seq_lens).  Both NULL = dense (ctx rows per sequence).  Results are
+ * bit-identical either way (tests/test_gpu_forward.py::test_packed_rows_are_bit_exact). */
+
 /* CLIP.encode_text (src/open_clip/model.py:269-284): tokens [n_seq,ctx] -> out fp32 [n_seq,embed_dim] */
-int leaf_text_forward(leaf_text_t h, const float* params, const void* w16_fwd, const int32_t* tokens, int n_seq,
-                      float* out, int normalize, void* ws, size_t ws_bytes, leaf_stream_t s);
+int leaf_text_forward(leaf_text_t h, const float* params, const void* w16_fwd, const int32_t* tokens,
+                      const int32_t* seq_lens, const int32_t* cu_rows, int n_seq, float* out, int normalize, void* ws,
+                      size_t ws_bytes, leaf_stream_t s);
 
 /* one search stage of attack_text_leaf (utils_attacks.py:330-348 / 368-386,393): forward of B*rho candidates,
  * loss per objective against anchor [B,embed_dim], first-index arg-max over rho, gather of the winning rows.
  * loss (fp32 [B,rho]) and best_feat (fp32 [B,embed_dim]) may be NULL. */
 int leaf_score_candidates(leaf_text_t h, const float* params, const void* w16_fwd, const int32_t* tokens,
-                          const float* anchor, int B, int rho, int objective, int32_t* best_idx, float* best_feat,
-                          float* loss, void* ws, size_t ws_bytes, leaf_stream_t s);
+                          const int32_t* seq_lens, const int32_t* cu_rows, const float* anchor, int B, int rho,
+                          int objective, int32_t* best_idx, float* best_feat, float* loss, void* ws, size_t ws_bytes,
+                          leaf_stream_t s);
 
 /* training forward (utils_AT.py:317-319) keeping activations in `stash` for the backward pass */
-int leaf_text_forward_train(leaf_text_t h, const float* params, const void* w16_fwd, const int32_t* tokens, int n_seq,
-                            float* out, void* stash, size_t stash_bytes, void* ws, size_t ws_bytes, leaf_stream_t s);
+int leaf_text_forward_train(leaf_text_t h, const float* params, const void* w16_fwd, const int32_t* tokens,
+                            const int32_t* seq_lens, const int32_t* cu_rows, int n_seq, float* out, void* stash,
+                            size_t stash_bytes, void* ws, size_t ws_bytes, leaf_stream_t s);
 
 /* TextFARE loss + backward (utils_AT.py:321-337): loss = mean_b sum_j (anchor - feat)^2; back-propagates
  * loss * accum_scale (= 1/accum_freq) and ACCUMULATES (+=) into grads (flat fp32, parameter layout).
  * loss_out: one device float (unscaled loss). */
-int leaf_textfare_backward(leaf_text_t h, const float* params, const void* w16_bwd, const int32_t* tokens, int n_seq,
-                           const float* feat, const float* anchor, float accum_scale, const void* stash,
-                           float* grads, float* loss_out, void* ws, size_t ws_bytes, leaf_stream_t s);
+int leaf_textfare_backward(leaf_text_t h, const float* params, const void* w16_bwd, const int32_t* tokens,
+                           const int32_t* seq_lens, const int32_t* cu_rows, int n_seq, const float* feat,
+                           const float* anchor, float accum_scale, const void* stash, float* grads, float* loss_out,
+                           void* ws, size_t ws_bytes, leaf_stream_t s);
 
 /* torch.optim.AdamW step over the flat buffers (train_AT_text_only.py:326-341): decoupled weight decay `wd`
  * on the first n_decay elements, 0 on the rest; step counts from 1; grads are multiplied by grad_scale first

@@ -198,45 +198,62 @@ FwdBuf carve_fwd(const leaf_text* h, Carver& c, int cs) {
     return b;
 }
 
-// run the layer stack on `cs` sequences; features -> out [cs, D]
-int forward_chunk(const leaf_text* h, const float* P, const uint16_t* W, const int32_t* tokens, int cs, float* out,
-                  int normalize, const FwdBuf& b, hipStream_t s) {
+// run the layer stack on `cs` sequences (rows = their packed row count); features -> out [cs, D]
+int forward_chunk(const leaf_text* h, const float* P, const uint16_t* W, const int32_t* tokens, int cs, int rows,
+                  RowMap map, float* out, int normalize, const FwdBuf& b, hipStream_t s) {
     const leaf_text_cfg& c = h->cfg;
-    const int d = c.width, rows = cs * c.context_length, dt = h->fwd_dtype;
+    const int d = c.width, dt = h->fwd_dtype;
     const LayerOff& o0 = h->layer[0];
     LEAF_TRY(leaf_launch_embed_ln(tokens, P + h->tok_emb, P + h->pos_emb, P + o0.ln1_w, P + o0.ln1_b, c.ln_eps, b.x,
-                                  b.a, rows, c.context_length, d, c.vocab_size, dt, s));
+                                  b.a, rows, cs, map, d, c.vocab_size, dt, s));
     for (int l = 0; l < c.layers; ++l) {
         const LayerOff& o = h->layer[l];
         if (l > 0) LEAF_TRY(leaf_launch_layernorm(b.x, P + o.ln1_w, P + o.ln1_b, c.ln_eps, b.a, rows, d, dt, s));
         if (leaf_gemm(dt, EPI_STORE_T, b.a, d, W + h->w16_qkv(l), d, b.qkv, 3 * d, P + o.qkv_b, nullptr, rows, 3 * d, d, 0, s))
             return 1;
-        LEAF_TRY(leaf_launch_attention_fwd(b.qkv, b.a, cs, c.context_length, c.heads, d, dt, s));
+        LEAF_TRY(leaf_launch_attention_fwd(b.qkv, b.a, cs, map, c.heads, d, dt, s));
         if (leaf_gemm(dt, EPI_RESID_F32, b.a, d, W + h->w16_out(l), d, b.x, d, P + o.out_b, nullptr, rows, d, d, 0, s))
             return 1;
         LEAF_TRY(leaf_launch_layernorm(b.x, P + o.ln2_w, P + o.ln2_b, c.ln_eps, b.a, rows, d, dt, s));
         if (leaf_gemm(dt, EPI_ACT_T, b.a, d, W + h->w16_fc(l), d, b.hh, 4 * d, P + o.fc_b, nullptr, rows, 4 * d, d,
-                 c.activation, s))
+                      c.activation, s))
             return 1;
         if (leaf_gemm(dt, EPI_RESID_F32, b.hh, 4 * d, W + h->w16_proj(l), 4 * d, b.x, d, P + o.proj_b, nullptr, rows, d,
-                 4 * d, 0, s))
+                      4 * d, 0, s))
             return 1;
     }
     LEAF_TRY(leaf_launch_pool_project(b.x, tokens, P + h->lnf_w, P + h->lnf_b, c.ln_eps, P + h->text_proj, out, nullptr,
-                                      nullptr, cs, c.context_length, d, c.embed_dim, normalize, s));
+                                      nullptr, cs, map, d, c.embed_dim, normalize, s));
     return 0;
 }
 
-int forward_all(const leaf_text* h, const float* P, const void* W, const int32_t* tokens, int n_seq, float* out,
-                int normalize, Carver& c, hipStream_t s) {
-    const int cs = n_seq < h->chunk ? n_seq : h->chunk;
-    FwdBuf b = carve_fwd(h, c, cs);
+// Sequences are processed in chunks bounded by a ROW budget (chunk * ctx rows): with EOT-trimmed (packed) rows a
+// chunk holds more sequences, so the GEMMs keep their M.  lens == nullptr -> dense (every sequence ctx rows).
+int forward_all(const leaf_text* h, const float* P, const void* W, const int32_t* tokens, const int32_t* lens,
+                const int32_t* cu_dev, int n_seq, float* out, int normalize, Carver& c, hipStream_t s) {
+    const int ctx = h->cfg.context_length;
+    if ((lens == nullptr) != (cu_dev == nullptr)) { leaf_set_error("seq_lens (host) and cu_rows (device) go together"); return 1; }
+    const size_t budget = (size_t)(n_seq < h->chunk ? n_seq : h->chunk) * ctx;
+    FwdBuf b = carve_fwd(h, c, (int)(budget / ctx));
     if (!c.ok()) { leaf_set_error("workspace too small: need %zu bytes, have %zu", c.off, c.cap); return 1; }
-    for (int s0 = 0; s0 < n_seq; s0 += cs) {
-        const int n = n_seq - s0 < cs ? n_seq - s0 : cs;
-        if (forward_chunk(h, P, (const uint16_t*)W, tokens + (size_t)s0 * h->cfg.context_length, n,
-                          out + (size_t)s0 * h->cfg.embed_dim, normalize, b, s))
+    int s0 = 0;
+    size_t row0 = 0;
+    while (s0 < n_seq) {
+        int s1 = s0;
+        size_t rows = 0;
+        while (s1 < n_seq) {
+            const int L = lens ? lens[s1] : ctx;
+            if (L < 1 || L > ctx) { leaf_set_error("seq_lens[%d] = %d out of range 1..%d", s1, L, ctx); return 1; }
+            if (rows + L > budget) break;
+            rows += L;
+            ++s1;
+        }
+        RowMap map{cu_dev, s0, (int)row0, ctx};
+        if (forward_chunk(h, P, (const uint16_t*)W, tokens, s1 - s0, (int)rows, map, out + (size_t)s0 * h->cfg.embed_dim,
+                          normalize, b, s))
             return 1;
+        s0 = s1;
+        row0 += rows;
     }
     return 0;
 }
@@ -253,14 +270,16 @@ extern "C" size_t leaf_text_workspace_bytes(leaf_text_t h, int n_seq, int mode) 
 }
 
 extern "C" int leaf_text_forward(leaf_text_t h, const float* params, const void* w16_fwd, const int32_t* tokens,
-                                 int n_seq, float* out, int normalize, void* ws, size_t ws_bytes, leaf_stream_t s) {
+                                 const int32_t* seq_lens, const int32_t* cu_rows, int n_seq, float* out, int normalize,
+                                 void* ws, size_t ws_bytes, leaf_stream_t s) {
     if (!h || !params || !w16_fwd || !tokens || !out || !ws || n_seq < 1) { leaf_set_error("null/invalid argument"); return 1; }
     Carver c(ws, ws_bytes);
-    return forward_all(h, params, w16_fwd, tokens, n_seq, out, normalize, c, (hipStream_t)s);
+    return forward_all(h, params, w16_fwd, tokens, seq_lens, cu_rows, n_seq, out, normalize, c, (hipStream_t)s);
 }
 
 extern "C" int leaf_score_candidates(leaf_text_t h, const float* params, const void* w16_fwd, const int32_t* tokens,
-                                     const float* anchor, int B, int rho, int objective, int32_t* best_idx,
+                                     const int32_t* seq_lens, const int32_t* cu_rows, const float* anchor, int B,
+                                     int rho, int objective, int32_t* best_idx,
                                      float* best_feat, float* loss, void* ws, size_t ws_bytes, leaf_stream_t s) {
     if (!h || !params || !w16_fwd || !tokens || !anchor || !best_idx || !ws || B < 1 || rho < 1) {
         leaf_set_error("null/invalid argument");
@@ -271,7 +290,7 @@ extern "C" int leaf_score_candidates(leaf_text_t h, const float* params, const v
     const int n_seq = B * rho;
     float* feat = (float*)c.take((size_t)n_seq * h->cfg.embed_dim * 4);
     const int normalize = (objective == LEAF_OBJ_SIM || objective == LEAF_OBJ_DISSIM);
-    if (forward_all(h, params, w16_fwd, tokens, n_seq, feat, normalize, c, (hipStream_t)s)) return 1;
+    if (forward_all(h, params, w16_fwd, tokens, seq_lens, cu_rows, n_seq, feat, normalize, c, (hipStream_t)s)) return 1;
     LEAF_TRY(leaf_launch_score(feat, anchor, B, rho, h->cfg.embed_dim, objective, best_idx, best_feat, loss,
                                (hipStream_t)s));
     return 0;
@@ -284,7 +303,8 @@ extern "C" int leaf_op_gemm(int dtype, int epi, const void* A, const void* B, vo
 }
 extern "C" int leaf_op_attention_fwd(const void* qkv, void* out, int n_seq, int ctx, int heads, int width, int dtype,
                                      leaf_stream_t s) {
-    return leaf_check(leaf_launch_attention_fwd(qkv, out, n_seq, ctx, heads, width, dtype, (hipStream_t)s), "attention_fwd");
+    return leaf_check(leaf_launch_attention_fwd(qkv, out, n_seq, RowMap{nullptr, 0, 0, ctx}, heads, width, dtype,
+                                                (hipStream_t)s), "attention_fwd");
 }
 extern "C" int leaf_op_layernorm(const float* x, const float* g, const float* b, float eps, void* out16, int rows,
                                  int width, int dtype, leaf_stream_t s) {
@@ -292,6 +312,6 @@ extern "C" int leaf_op_layernorm(const float* x, const float* g, const float* b,
 }
 extern "C" int leaf_op_attention_bwd(const void* qkv, int qkv_dtype, const void* dout_bf16, void* dqkv_bf16, int n_seq,
                                      int ctx, int heads, int width, leaf_stream_t s) {
-    return leaf_check(leaf_launch_attention_bwd(qkv, qkv_dtype, dout_bf16, dqkv_bf16, n_seq, ctx, heads, width,
-                                                (hipStream_t)s), "attention_bwd");
+    return leaf_check(leaf_launch_attention_bwd(qkv, qkv_dtype, dout_bf16, dqkv_bf16, n_seq, RowMap{nullptr, 0, 0, ctx},
+                                                heads, width, (hipStream_t)s), "attention_bwd");
 }

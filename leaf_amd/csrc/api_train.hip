@@ -17,8 +17,15 @@ struct Stash {
     int32_t* eot;    // [n]
 };
 
-Stash carve_stash(const leaf_text* h, Carver& c, int n_seq) {
-    const size_t rows = (size_t)n_seq * h->cfg.context_length, d = h->cfg.width, L = h->cfg.layers;
+size_t total_rows(const leaf_text* h, const int32_t* lens, int n_seq) {
+    if (!lens) return (size_t)n_seq * h->cfg.context_length;
+    size_t r = 0;
+    for (int i = 0; i < n_seq; ++i) r += lens[i];
+    return r;
+}
+
+Stash carve_stash(const leaf_text* h, Carver& c, int n_seq, size_t rows) {
+    const size_t d = h->cfg.width, L = h->cfg.layers;
     Stash s;
     s.xin = (float*)c.take((L + 1) * rows * d * 4);
     s.x1 = (float*)c.take(L * rows * d * 4);
@@ -45,8 +52,8 @@ struct BwdBuf {
     float* dout;      // [n,D]
 };
 
-BwdBuf carve_bwd(const leaf_text* h, Carver& c, int n_seq) {
-    const size_t rows = (size_t)n_seq * h->cfg.context_length, d = h->cfg.width;
+BwdBuf carve_bwd(const leaf_text* h, Carver& c, int n_seq, size_t rows) {
+    const size_t d = h->cfg.width;
     const size_t rpad = align_up(rows, 64);
     BwdBuf b;
     b.dx = (float*)c.take(rows * d * 4);
@@ -65,32 +72,35 @@ BwdBuf carve_bwd(const leaf_text* h, Carver& c, int n_seq) {
 
 size_t leaf_train_ws_bytes(const leaf_text* h, int n_seq) {
     Carver c(nullptr, 0);
-    carve_bwd(h, c, n_seq);
+    carve_bwd(h, c, n_seq, (size_t)n_seq * h->cfg.context_length);
     return align_up(c.off, 256) + 256;
 }
 
 extern "C" size_t leaf_text_stash_bytes(leaf_text_t h, int n_seq) {
     if (!h || n_seq < 1) return 0;
     Carver c(nullptr, 0);
-    carve_stash(h, c, n_seq);
+    carve_stash(h, c, n_seq, (size_t)n_seq * h->cfg.context_length);
     return align_up(c.off, 256) + 256;
 }
 
 extern "C" int leaf_text_forward_train(leaf_text_t h, const float* P, const void* w16_fwd, const int32_t* tokens,
-                                       int n_seq, float* out, void* stash, size_t stash_bytes, void* ws,
-                                       size_t ws_bytes, leaf_stream_t s_) {
+                                       const int32_t* seq_lens, const int32_t* cu_rows, int n_seq, float* out,
+                                       void* stash, size_t stash_bytes, void* ws, size_t ws_bytes, leaf_stream_t s_) {
     (void)ws; (void)ws_bytes;
     if (!h || !P || !w16_fwd || !tokens || !out || !stash || n_seq < 1) { leaf_set_error("null/invalid argument"); return 1; }
     hipStream_t s = (hipStream_t)s_;
-    Carver c(stash, stash_bytes);
-    Stash st = carve_stash(h, c, n_seq);
-    if (!c.ok()) { leaf_set_error("stash too small: need %zu bytes, have %zu", c.off, c.cap); return 1; }
+    if ((seq_lens == nullptr) != (cu_rows == nullptr)) { leaf_set_error("seq_lens (host) and cu_rows (device) go together"); return 1; }
     const leaf_text_cfg& cf = h->cfg;
-    const int d = cf.width, rows = n_seq * cf.context_length, dt = h->fwd_dtype, L = cf.layers;
+    const int rows = (int)total_rows(h, seq_lens, n_seq);
+    Carver c(stash, stash_bytes);
+    Stash st = carve_stash(h, c, n_seq, rows);
+    if (!c.ok()) { leaf_set_error("stash too small: need %zu bytes, have %zu", c.off, c.cap); return 1; }
+    const RowMap map{cu_rows, 0, 0, cf.context_length};
+    const int d = cf.width, dt = h->fwd_dtype, L = cf.layers;
     const size_t rd = (size_t)rows * d;
     const uint16_t* W = (const uint16_t*)w16_fwd;
     LEAF_TRY(leaf_launch_embed_ln(tokens, P + h->tok_emb, P + h->pos_emb, P + h->layer[0].ln1_w, P + h->layer[0].ln1_b,
-                                  cf.ln_eps, st.xin, st.xn1, rows, cf.context_length, d, cf.vocab_size, dt, s));
+                                  cf.ln_eps, st.xin, st.xn1, rows, n_seq, map, d, cf.vocab_size, dt, s));
     for (int l = 0; l < L; ++l) {
         const LayerOff& o = h->layer[l];
         float* xin = st.xin + l * rd; float* x1 = st.x1 + l * rd; float* xout = st.xin + (l + 1) * rd;
@@ -98,7 +108,7 @@ extern "C" int leaf_text_forward_train(leaf_text_t h, const float* P, const void
         uint16_t* xn2 = st.xn2 + l * rd; uint16_t* pre = st.pre + 4 * l * rd; uint16_t* hh = st.hh + 4 * l * rd;
         if (l > 0) LEAF_TRY(leaf_launch_layernorm(xin, P + o.ln1_w, P + o.ln1_b, cf.ln_eps, xn1, rows, d, dt, s));
         if (leaf_gemm(dt, EPI_STORE_T, xn1, d, W + h->w16_qkv(l), d, qkv, 3 * d, P + o.qkv_b, nullptr, rows, 3 * d, d, 0, s)) return 1;
-        LEAF_TRY(leaf_launch_attention_fwd(qkv, ao, n_seq, cf.context_length, cf.heads, d, dt, s));
+        LEAF_TRY(leaf_launch_attention_fwd(qkv, ao, n_seq, map, cf.heads, d, dt, s));
         LEAF_TRY(hipMemcpyAsync(x1, xin, rd * 4, hipMemcpyDeviceToDevice, s));
         if (leaf_gemm(dt, EPI_RESID_F32, ao, d, W + h->w16_out(l), d, x1, d, P + o.out_b, nullptr, rows, d, d, 0, s)) return 1;
         LEAF_TRY(leaf_launch_layernorm(x1, P + o.ln2_w, P + o.ln2_b, cf.ln_eps, xn2, rows, d, dt, s));
@@ -107,13 +117,13 @@ extern "C" int leaf_text_forward_train(leaf_text_t h, const float* P, const void
         if (leaf_gemm(dt, EPI_RESID_F32, hh, 4 * d, W + h->w16_proj(l), 4 * d, xout, d, P + o.proj_b, nullptr, rows, d, 4 * d, 0, s)) return 1;
     }
     LEAF_TRY(leaf_launch_pool_project(st.xin + (size_t)L * rd, tokens, P + h->lnf_w, P + h->lnf_b, cf.ln_eps,
-                                      P + h->text_proj, out, st.pooled, st.eot, n_seq, cf.context_length, d,
-                                      cf.embed_dim, 0, s));
+                                      P + h->text_proj, out, st.pooled, st.eot, n_seq, map, d, cf.embed_dim, 0, s));
     return 0;
 }
 
 extern "C" int leaf_textfare_backward(leaf_text_t h, const float* P, const void* w16_bwd, const int32_t* tokens,
-                                      int n_seq, const float* feat, const float* anchor, float accum_scale,
+                                      const int32_t* seq_lens, const int32_t* cu_rows, int n_seq, const float* feat,
+                                      const float* anchor, float accum_scale,
                                       const void* stash, float* G, float* loss_out, void* ws, size_t ws_bytes,
                                       leaf_stream_t s_) {
     if (!h || !P || !w16_bwd || !tokens || !feat || !anchor || !stash || !G || !ws || n_seq < 1) {
@@ -121,13 +131,16 @@ extern "C" int leaf_textfare_backward(leaf_text_t h, const float* P, const void*
         return 1;
     }
     hipStream_t s = (hipStream_t)s_;
-    Carver cs((void*)stash, (size_t)-1);
-    Stash st = carve_stash(h, cs, n_seq);
-    Carver cw(ws, ws_bytes);
-    BwdBuf b = carve_bwd(h, cw, n_seq);
-    if (!cw.ok()) { leaf_set_error("workspace too small: need %zu bytes, have %zu", cw.off, cw.cap); return 1; }
+    if ((seq_lens == nullptr) != (cu_rows == nullptr)) { leaf_set_error("seq_lens (host) and cu_rows (device) go together"); return 1; }
     const leaf_text_cfg& cf = h->cfg;
-    const int d = cf.width, rows = n_seq * cf.context_length, L = cf.layers, D = cf.embed_dim;
+    const int rows = (int)total_rows(h, seq_lens, n_seq);
+    Carver cs((void*)stash, (size_t)-1);
+    Stash st = carve_stash(h, cs, n_seq, rows);
+    Carver cw(ws, ws_bytes);
+    BwdBuf b = carve_bwd(h, cw, n_seq, rows);
+    if (!cw.ok()) { leaf_set_error("workspace too small: need %zu bytes, have %zu", cw.off, cw.cap); return 1; }
+    const RowMap map{cu_rows, 0, 0, cf.context_length};
+    const int d = cf.width, L = cf.layers, D = cf.embed_dim;
     const int rpad = (int)align_up((size_t)rows, 64);
     const size_t rd = (size_t)rows * d;
     const int fk = h->fwd_dtype == LEAF_DTYPE_FP16 ? 1 : 0;  // source kind of stashed activations
@@ -144,7 +157,7 @@ extern "C" int leaf_textfare_backward(leaf_text_t h, const float* P, const void*
     LEAF_TRY(hipMemsetAsync(b.dx, 0, rd * 4, s));
     LEAF_TRY(leaf_launch_pool_project_bwd(b.dout, st.pooled, st.xin + (size_t)L * rd, st.eot, P + h->lnf_w, P + h->lnf_b,
                                           cf.ln_eps, P + h->text_proj, b.dx, G + h->text_proj, G + h->lnf_w,
-                                          G + h->lnf_b, n_seq, cf.context_length, d, D, s));
+                                          G + h->lnf_b, n_seq, map, d, D, s));
     LEAF_TRY(leaf_launch_f32_to_bf16_rows(b.dx, b.dx16, rd, s));
 
     for (int l = L - 1; l >= 0; --l) {
@@ -167,7 +180,7 @@ extern "C" int leaf_textfare_backward(leaf_text_t h, const float* P, const void*
         if (wgrad(b.dx16, d, ao, fk, d, G + o.out_w)) return 1;
         LEAF_TRY(leaf_launch_colsum(b.dx16, d, rows, d, G + o.out_b, s));
         if (leaf_gemm(LEAF_BF16, EPI_STORE_T, b.dx16, d, WT + h->w16_out(l), d, b.do16, d, nullptr, nullptr, rows, d, d, 0, s)) return 1;
-        LEAF_TRY(leaf_launch_attention_bwd(qkv, h->fwd_dtype, b.do16, b.dqkv, n_seq, cf.context_length, cf.heads, d, s));
+        LEAF_TRY(leaf_launch_attention_bwd(qkv, h->fwd_dtype, b.do16, b.dqkv, n_seq, map, cf.heads, d, s));
         if (wgrad(b.dqkv, 3 * d, xn1, fk, d, G + o.qkv_w)) return 1;
         LEAF_TRY(leaf_launch_colsum(b.dqkv, 3 * d, rows, 3 * d, G + o.qkv_b, s));
         if (leaf_gemm(LEAF_BF16, EPI_STORE_F32, b.dqkv, 3 * d, WT + h->w16_qkv(l), 3 * d, b.dxn, d, nullptr, nullptr, rows, d,
@@ -175,8 +188,7 @@ extern "C" int leaf_textfare_backward(leaf_text_t h, const float* P, const void*
         LEAF_TRY(leaf_launch_layernorm_bwd(b.dxn, xin, P + o.ln1_w, cf.ln_eps, b.dx, b.dx16, G + o.ln1_w, G + o.ln1_b,
                                            rows, d, s));
     }
-    LEAF_TRY(leaf_launch_embed_bwd(b.dx, tokens, G + h->tok_emb, G + h->pos_emb, rows, cf.context_length, d,
-                                   cf.vocab_size, s));
+    LEAF_TRY(leaf_launch_embed_bwd(b.dx, tokens, G + h->tok_emb, G + h->pos_emb, rows, n_seq, map, d, cf.vocab_size, s));
     return 0;
 }
 

@@ -56,7 +56,7 @@ __device__ __forceinline__ typename TT::vec8 load_vt_frag(const char* vlds, int 
 
 template <class TT, bool USE_TR>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const u16* __restrict__ qkv, u16* __restrict__ out, int n_items,
-                                                       int ctx, int heads, int d) {
+                                                       RowMap map, int heads, int d) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int item = blockIdx.x * 4 + wid;
@@ -65,7 +65,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const u16* __restrict__ q
     char* plds = vlds + V_BYTES;
     const int n = item / heads, h = item % heads;
     const int ld = 3 * d;
-    const u16* base = qkv + (size_t)n * ctx * ld + h * HD;
+    const int row_s = seq_row(map, map.s0 + n), ctx = seq_len(map, map.s0 + n);
+    const u16* base = qkv + (size_t)row_s * ld + h * HD;
     const int r16 = lane & 15, g = lane >> 4;
     const int nt = (ctx + 15) >> 4;
 
@@ -129,7 +130,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const u16* __restrict__ q
             sum += __shfl_xor(sum, 32, 64);
             const float inv = 1.0f / sum;
             // P -> LDS [16 q][keys], zero-filled up to the k-step boundary
-            constexpr int dummy = 0; (void)dummy;
             const int nks = (qt + 2) >> 1;
 #pragma unroll
             for (int kt = 0; kt < MAXT; ++kt) {
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const u16* __restrict__ q
                 }
             }
             if (qidx < ctx) {
-                u16* op = out + ((size_t)n * ctx + qidx) * d + h * HD + 4 * g;
+                u16* op = out + ((size_t)row_s + qidx) * d + h * HD + 4 * g;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt)
                     *(uint2*)(op + dt * 16) = pack4<TT>(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
@@ -167,9 +167,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const u16* __restrict__ q
 
 }  // namespace
 
-hipError_t leaf_launch_attention_fwd(const void* qkv, void* out, int n_seq, int ctx, int heads, int d, int dtype,
+hipError_t leaf_launch_attention_fwd(const void* qkv, void* out, int n_seq, RowMap map, int heads, int d, int dtype,
                                      hipStream_t s) {
-    if (d != heads * HD || ctx > 16 * MAXT || ctx < 1) return hipErrorInvalidValue;
+    if (d != heads * HD || map.ctx > 16 * MAXT || map.ctx < 1) return hipErrorInvalidValue;
     static int use_tr = -1;
     if (use_tr < 0) {
         const char* e = getenv("LEAF_ATTN_TR");
@@ -186,7 +186,7 @@ hipError_t leaf_launch_attention_fwd(const void* qkv, void* out, int n_seq, int 
                                 (int)lds);                                                                  \
             attr = true;                                                                                    \
         }                                                                                                   \
-        hipLaunchKernelGGL((attn_fwd_kernel<TT, TR>), grid, blk, lds, s, (const u16*)qkv, (u16*)out, items, ctx, heads, d); \
+        hipLaunchKernelGGL((attn_fwd_kernel<TT, TR>), grid, blk, lds, s, (const u16*)qkv, (u16*)out, items, map, heads, d); \
     } while (0)
     if (dtype == LEAF_F16) { if (use_tr) LEAF_ATTN(F16, true); else LEAF_ATTN(F16, false); }
     else                   { if (use_tr) LEAF_ATTN(BF16, true); else LEAF_ATTN(BF16, false); }

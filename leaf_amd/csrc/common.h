@@ -82,3 +82,24 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb) {
     int q = nb >> 3, r = nb & 7, x = bid & 7, slot = bid >> 3;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + slot;
 }
+
+// ---- packed (EOT-trimmed) row layout -------------------------------------------------------------------------
+// Sequences keep only their first len = eot + 1 rows; cu[s] is the global packed row of sequence s's first row
+// (cu == nullptr means dense: cu[s] = s * ctx).  A launch covers sequences [s0, s0 + n) whose rows start at row0.
+struct RowMap {
+    const int32_t* cu;
+    int s0, row0, ctx;
+};
+__device__ __forceinline__ int seq_row(const RowMap& m, int s) { return (m.cu ? m.cu[s] : s * m.ctx) - m.row0; }
+__device__ __forceinline__ int seq_len(const RowMap& m, int s) { return m.cu ? m.cu[s + 1] - m.cu[s] : m.ctx; }
+// sequence owning local row r (n sequences in this launch)
+__device__ __forceinline__ int seq_of_row(const RowMap& m, int r, int n) {
+    const int R = m.row0 + r;
+    if (!m.cu) return R / m.ctx;
+    int lo = m.s0, hi = m.s0 + n - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (m.cu[mid] <= R) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}

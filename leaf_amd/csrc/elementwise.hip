@@ -48,18 +48,20 @@ template <class TT, bool EMBED>
 __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x_in, const int32_t* __restrict__ tokens,
                                                  const float* __restrict__ tok_emb, const float* __restrict__ pos_emb,
                                                  const float* __restrict__ g, const float* __restrict__ b, float eps,
-                                                 float* __restrict__ x_out, u16* __restrict__ xn, int rows, int ctx, int d,
-                                                 int vocab) {
+                                                 float* __restrict__ x_out, u16* __restrict__ xn, int rows, int n_seq,
+                                                 RowMap map, int d, int vocab) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int nq = d >> 2;
     float4 v[MAXCH];
     if constexpr (EMBED) {
-        int tok = tokens[row];
+        const int sq = seq_of_row(map, row, n_seq);
+        const int pos = row - seq_row(map, sq);
+        int tok = tokens[(size_t)sq * map.ctx + pos];
         tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
         const float* te = tok_emb + (size_t)tok * d;
-        const float* pe = pos_emb + (size_t)(row % ctx) * d;
+        const float* pe = pos_emb + (size_t)pos * d;
         float* xo = x_out + (size_t)row * d;
 #pragma unroll
         for (int i = 0; i < MAXCH; ++i) {
@@ -89,8 +91,8 @@ __global__ __launch_bounds__(256) void pool_project_kernel(const float* __restri
                                                            const float* __restrict__ g, const float* __restrict__ b,
                                                            float eps, const float* __restrict__ proj,
                                                            float* __restrict__ out, float* __restrict__ pooled,
-                                                           int32_t* __restrict__ eot_idx, int n_seq, int ctx, int d, int D,
-                                                           int normalize) {
+                                                           int32_t* __restrict__ eot_idx, int n_seq, RowMap map, int d,
+                                                           int D, int normalize) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* xs = (float*)smem;               // [PR][d]
     float* red = xs + PR * d;               // [4][PR]
@@ -105,10 +107,11 @@ __global__ __launch_bounds__(256) void pool_project_kernel(const float* __restri
             for (int c = lane; c < d; c += 64) xr[c] = 0.f;
             continue;
         }
-        // first index of the maximum token id (torch argmax)
+        // first index of the maximum token id (torch argmax) among the rows this sequence keeps
+        const int sg = map.s0 + n, ctx = seq_len(map, sg);
         int bv = -2147483647 - 1, bi = 0;
         for (int p = lane; p < ctx; p += 64) {
-            int t = tokens[(size_t)n * ctx + p];
+            int t = tokens[(size_t)sg * map.ctx + p];
             if (t > bv) { bv = t; bi = p; }
         }
 #pragma unroll
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(256) void pool_project_kernel(const float* __restri
             if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
         }
         if (eot_idx && lane == 0) eot_idx[n] = bi;
-        const float* xi = x + ((size_t)n * ctx + bi) * d;
+        const float* xi = x + ((size_t)seq_row(map, sg) + bi) * d;
         float4 v[MAXCH];
         float s = 0.f;
 #pragma unroll
@@ -254,16 +257,16 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src
 }  // namespace
 
 hipError_t leaf_launch_embed_ln(const int32_t* tokens, const float* tok_emb, const float* pos_emb, const float* g,
-                                const float* b, float eps, float* x, void* xn, int rows, int ctx, int d, int vocab,
-                                int dtype, hipStream_t s) {
+                                const float* b, float eps, float* x, void* xn, int rows, int n_seq, RowMap map, int d,
+                                int vocab, int dtype, hipStream_t s) {
     if (d % 4 || d > 256 * MAXCH) return hipErrorInvalidValue;
     dim3 grid((rows + 3) / 4), blk(256);
     if (dtype == LEAF_F16)
         hipLaunchKernelGGL((ln_kernel<F16, true>), grid, blk, 0, s, nullptr, tokens, tok_emb, pos_emb, g, b, eps, x,
-                           (u16*)xn, rows, ctx, d, vocab);
+                           (u16*)xn, rows, n_seq, map, d, vocab);
     else
         hipLaunchKernelGGL((ln_kernel<BF16, true>), grid, blk, 0, s, nullptr, tokens, tok_emb, pos_emb, g, b, eps, x,
-                           (u16*)xn, rows, ctx, d, vocab);
+                           (u16*)xn, rows, n_seq, map, d, vocab);
     return hipGetLastError();
 }
 
@@ -273,15 +276,15 @@ hipError_t leaf_launch_layernorm(const float* x, const float* g, const float* b,
     dim3 grid((rows + 3) / 4), blk(256);
     if (dtype == LEAF_F16)
         hipLaunchKernelGGL((ln_kernel<F16, false>), grid, blk, 0, s, x, nullptr, nullptr, nullptr, g, b, eps, nullptr,
-                           (u16*)xn, rows, 1, d, 0);
+                           (u16*)xn, rows, 0, RowMap{nullptr, 0, 0, 1}, d, 0);
     else
         hipLaunchKernelGGL((ln_kernel<BF16, false>), grid, blk, 0, s, x, nullptr, nullptr, nullptr, g, b, eps, nullptr,
-                           (u16*)xn, rows, 1, d, 0);
+                           (u16*)xn, rows, 0, RowMap{nullptr, 0, 0, 1}, d, 0);
     return hipGetLastError();
 }
 
 hipError_t leaf_launch_pool_project(const float* x, const int32_t* tokens, const float* g, const float* b, float eps,
-                                    const float* proj, float* out, float* pooled, int32_t* eot_idx, int n_seq, int ctx,
+                                    const float* proj, float* out, float* pooled, int32_t* eot_idx, int n_seq, RowMap map,
                                     int d, int D, int normalize, hipStream_t s) {
     if (d % 4 || d > 256 * MAXCH || D > 256 * JJMAX) return hipErrorInvalidValue;
     size_t lds = (size_t)(PR * d + 4 * PR) * sizeof(float);
@@ -291,7 +294,7 @@ hipError_t leaf_launch_pool_project(const float* x, const int32_t* tokens, const
         attr = true;
     }
     hipLaunchKernelGGL(pool_project_kernel, dim3((n_seq + PR - 1) / PR), dim3(256), lds, s, x, tokens, g, b, eps, proj,
-                       out, pooled, eot_idx, n_seq, ctx, d, D, normalize);
+                       out, pooled, eot_idx, n_seq, map, d, D, normalize);
     return hipGetLastError();
 }
 

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "common.h"
+
 enum { LEAF_BF16 = 0, LEAF_F16 = 1 };
 
 enum {
@@ -31,14 +33,14 @@ hipError_t leaf_launch_gemm(const GemmArgs& p, int dtype, int epi, hipStream_t s
 // ---- forward elementwise / reduction kernels (elementwise.hip)
 // x[r,:] = tok_emb[tokens[r],:] + pos_emb[r % ctx,:]   and   xn = LN(x) (16-bit)
 hipError_t leaf_launch_embed_ln(const int32_t* tokens, const float* tok_emb, const float* pos_emb, const float* g,
-                                const float* b, float eps, float* x, void* xn, int rows, int ctx, int d, int vocab,
-                                int dtype, hipStream_t s);
+                                const float* b, float eps, float* x, void* xn, int rows, int n_seq, RowMap map, int d,
+                                int vocab, int dtype, hipStream_t s);
 hipError_t leaf_launch_layernorm(const float* x, const float* g, const float* b, float eps, void* xn, int rows, int d,
                                  int dtype, hipStream_t s);
 // out[n,:] = LN_final(x[n*ctx + eot(n),:]) @ P  (fp32 math), optional L2 normalisation; pooled (optional) keeps
 // the normalised EOT row and eot_idx the pooled position (training stash).
 hipError_t leaf_launch_pool_project(const float* x, const int32_t* tokens, const float* g, const float* b, float eps,
-                                    const float* proj, float* out, float* pooled, int32_t* eot_idx, int n_seq, int ctx,
+                                    const float* proj, float* out, float* pooled, int32_t* eot_idx, int n_seq, RowMap map,
                                     int d, int D, int normalize, hipStream_t s);
 // loss[b,r] per objective, arg-max over rho (first maximum wins), best feature gather
 hipError_t leaf_launch_score(const float* feat, const float* anchor, int B, int rho, int D, int objective,
@@ -47,7 +49,7 @@ hipError_t leaf_launch_score(const float* feat, const float* anchor, int B, int 
 hipError_t leaf_launch_cast(const float* src, void* dst, size_t n, int dtype, hipStream_t s);
 
 // ---- attention (attention.hip): qkv [rows, 3d] 16-bit (q | k | v, heads inside each), out [rows, d]
-hipError_t leaf_launch_attention_fwd(const void* qkv, void* out, int n_seq, int ctx, int heads, int d, int dtype,
+hipError_t leaf_launch_attention_fwd(const void* qkv, void* out, int n_seq, RowMap map, int heads, int d, int dtype,
                                      hipStream_t s);
 
 // ---- training-only kernels (train.hip)
@@ -62,7 +64,7 @@ hipError_t leaf_launch_fare_loss(const float* feat, const float* anchor, int B, 
 // dproj [d,D], dg/db of ln_final.
 hipError_t leaf_launch_pool_project_bwd(const float* dout, const float* pooled, const float* x, const int32_t* eot_idx,
                                         const float* g, const float* b, float eps, const float* proj, float* dx,
-                                        float* dproj, float* dg, float* db, int n_seq, int ctx, int d, int D,
+                                        float* dproj, float* dg, float* db, int n_seq, RowMap map, int d, int D,
                                         hipStream_t s);
 // dx_out = dx_in + LNbwd(dy, x, g);  dg += ..., db += ...;  dx16 = bf16(dx_out) (optional)
 hipError_t leaf_launch_layernorm_bwd(const float* dy, const float* x, const float* g, float eps, float* dx_inout,
@@ -71,10 +73,10 @@ hipError_t leaf_launch_layernorm_bwd(const float* dy, const float* x, const floa
 hipError_t leaf_launch_colsum(const void* dy_bf16, int ld, int rows, int n, float* dbias, hipStream_t s);
 // attention backward: q,k,v from qkv (fwd dtype), dO bf16 [rows,d] -> dqkv bf16 [rows,3d]
 hipError_t leaf_launch_attention_bwd(const void* qkv, int qkv_dtype, const void* dout_bf16, void* dqkv_bf16, int n_seq,
-                                     int ctx, int heads, int d, hipStream_t s);
+                                     RowMap map, int heads, int d, hipStream_t s);
 // dtok[tokens[r],:] += dx[r,:] ; dpos[r % ctx,:] += dx[r,:]
-hipError_t leaf_launch_embed_bwd(const float* dx, const int32_t* tokens, float* dtok, float* dpos, int rows, int ctx,
-                                 int d, int vocab, hipStream_t s);
+hipError_t leaf_launch_embed_bwd(const float* dx, const int32_t* tokens, float* dtok, float* dpos, int rows, int n_seq,
+                                 RowMap map, int d, int vocab, hipStream_t s);
 hipError_t leaf_launch_adamw(float* p, const float* g, float* m, float* v, size_t n, size_t n_decay, float lr,
                              float beta1, float beta2, float eps, float wd, int step, float grad_scale, hipStream_t s);
 hipError_t leaf_launch_f32_to_bf16_rows(const float* src, void* dst, size_t n, hipStream_t s);

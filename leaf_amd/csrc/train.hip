@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void proj_wgrad_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ x,
                                                        const int32_t* __restrict__ eot_idx, const float* __restrict__ g,
                                                        float eps, const float* __restrict__ proj, float* __restrict__ dx,
-                                                       float* __restrict__ dg, float* __restrict__ db, int ctx, int d,
+                                                       float* __restrict__ dg, float* __restrict__ db, RowMap map, int d,
                                                        int D) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sdo = (float*)smem;   // [D]
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
         if (lane == 0) sdp[k] = s;
     }
     __syncthreads();
-    const size_t row = (size_t)b * ctx + eot_idx[b];
+    const size_t row = (size_t)seq_row(map, map.s0 + b) + eot_idx[b];
     const float* xr = x + row * d;
     // block-wide LN backward for one row
     float s1 = 0.f;
@@ -230,19 +230,20 @@ __global__ __launch_bounds__(256) void colsum_kernel(const u16* __restrict__ dy,
 constexpr int HD = 64, HP = 65;
 
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const u16* __restrict__ qkv, int qkv_f16,
-                                                       const u16* __restrict__ dO, u16* __restrict__ dqkv, int ctx,
+                                                       const u16* __restrict__ dO, u16* __restrict__ dqkv, RowMap map,
                                                        int heads, int d) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int n = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int ctx = seq_len(map, map.s0 + n);
     float* sq = (float*)smem;            // [ctx][HP]
     float* sk = sq + ctx * HP;
     float* sv = sk + ctx * HP;
     float* sdo = sv + ctx * HP;
     float* sp = sdo + ctx * HP;          // [ctx][ctx+1]  P
     float* sds = sp + ctx * (ctx + 1);   // [ctx][ctx+1]  dS
-    const int n = blockIdx.x / heads, h = blockIdx.x % heads;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int ld = 3 * d, PS = ctx + 1;
-    const size_t row0 = (size_t)n * ctx;
+    const size_t row0 = (size_t)seq_row(map, map.s0 + n);
     for (int idx = tid; idx < ctx * HD; idx += 256) {
         const int r = idx >> 6, c = idx & 63;
         const size_t o = (row0 + r) * ld + h * HD + c;
@@ -308,18 +309,21 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const u16* __restrict__ q
 
 // dpos[p][:] += sum_n dx[n*ctx+p][:]   (grid = ctx) ; dtok via atomics (grid-stride over rows)
 __global__ __launch_bounds__(256) void pos_bwd_kernel(const float* __restrict__ dx, float* __restrict__ dpos, int n_seq,
-                                                      int ctx, int d) {
+                                                      RowMap map, int d) {
     const int p = blockIdx.x;
     for (int c = threadIdx.x; c < d; c += 256) {
         float s = 0.f;
-        for (int n = 0; n < n_seq; ++n) s += dx[((size_t)n * ctx + p) * d + c];
+        for (int n = 0; n < n_seq; ++n)
+            if (p < seq_len(map, map.s0 + n)) s += dx[((size_t)seq_row(map, map.s0 + n) + p) * d + c];
         dpos[(size_t)p * d + c] += s;
     }
 }
 __global__ __launch_bounds__(256) void tok_bwd_kernel(const float* __restrict__ dx, const int32_t* __restrict__ tokens,
-                                                      float* __restrict__ dtok, int rows, int d, int vocab) {
+                                                      float* __restrict__ dtok, int rows, int n_seq, RowMap map, int d,
+                                                      int vocab) {
     const int row = blockIdx.x;
-    int tok = tokens[row];
+    const int sq = seq_of_row(map, row, n_seq);
+    int tok = tokens[(size_t)sq * map.ctx + (row - seq_row(map, sq))];
     tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
     for (int c = threadIdx.x; c < d; c += 256) atomicAdd(dtok + (size_t)tok * d + c, dx[(size_t)row * d + c]);
 }
@@ -377,14 +381,14 @@ hipError_t leaf_launch_fare_loss(const float* feat, const float* anchor, int B, 
 
 hipError_t leaf_launch_pool_project_bwd(const float* dout, const float* pooled, const float* x, const int32_t* eot_idx,
                                         const float* g, const float* b, float eps, const float* proj, float* dx,
-                                        float* dproj, float* dg, float* db, int n_seq, int ctx, int d, int D,
+                                        float* dproj, float* dg, float* db, int n_seq, RowMap map, int d, int D,
                                         hipStream_t s) {
     (void)b;
     hipLaunchKernelGGL(proj_wgrad_kernel, dim3(d), dim3(256), 0, s, pooled, dout, dproj, n_seq, d, D);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     size_t lds = (size_t)(D + d + 8) * sizeof(float);
-    hipLaunchKernelGGL(pool_bwd_kernel, dim3(n_seq), dim3(256), lds, s, dout, x, eot_idx, g, eps, proj, dx, dg, db, ctx,
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3(n_seq), dim3(256), lds, s, dout, x, eot_idx, g, eps, proj, dx, dg, db, map,
                        d, D);
     return hipGetLastError();
 }
@@ -410,7 +414,8 @@ hipError_t leaf_launch_colsum(const void* dy_bf16, int ld, int rows, int n, floa
 }
 
 hipError_t leaf_launch_attention_bwd(const void* qkv, int qkv_dtype, const void* dout_bf16, void* dqkv_bf16, int n_seq,
-                                     int ctx, int heads, int d, hipStream_t s) {
+                                     RowMap map, int heads, int d, hipStream_t s) {
+    const int ctx = map.ctx;
     if (d != heads * HD || ctx > 128) return hipErrorInvalidValue;
     size_t lds = ((size_t)4 * ctx * HP + (size_t)2 * ctx * (ctx + 1)) * sizeof(float);
     static bool attr = false;
@@ -420,16 +425,16 @@ hipError_t leaf_launch_attention_bwd(const void* qkv, int qkv_dtype, const void*
     }
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     hipLaunchKernelGGL(attn_bwd_kernel, dim3(n_seq * heads), dim3(256), lds, s, (const u16*)qkv,
-                       qkv_dtype == LEAF_F16 ? 1 : 0, (const u16*)dout_bf16, (u16*)dqkv_bf16, ctx, heads, d);
+                       qkv_dtype == LEAF_F16 ? 1 : 0, (const u16*)dout_bf16, (u16*)dqkv_bf16, map, heads, d);
     return hipGetLastError();
 }
 
-hipError_t leaf_launch_embed_bwd(const float* dx, const int32_t* tokens, float* dtok, float* dpos, int rows, int ctx,
-                                 int d, int vocab, hipStream_t s) {
-    hipLaunchKernelGGL(pos_bwd_kernel, dim3(ctx), dim3(256), 0, s, dx, dpos, rows / ctx, ctx, d);
+hipError_t leaf_launch_embed_bwd(const float* dx, const int32_t* tokens, float* dtok, float* dpos, int rows, int n_seq,
+                                 RowMap map, int d, int vocab, hipStream_t s) {
+    hipLaunchKernelGGL(pos_bwd_kernel, dim3(map.ctx), dim3(256), 0, s, dx, dpos, n_seq, map, d);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(tok_bwd_kernel, dim3(rows), dim3(256), 0, s, dx, tokens, dtok, rows, d, vocab);
+    hipLaunchKernelGGL(tok_bwd_kernel, dim3(rows), dim3(256), 0, s, dx, tokens, dtok, rows, n_seq, map, d, vocab);
     return hipGetLastError();
 }
 

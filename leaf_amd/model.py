@@ -108,6 +108,8 @@ class LeafCLIPText:
         self.logit_scale = torch.tensor(math.log(1 / 0.07), device=self.device)  # carried for checkpoints only
         self._ws: Dict[int, torch.Tensor] = {}
         self._packed = False
+        # exact work skipping: compute only rows up to EOT (include/leaf_hip.h, "EOT trimming"); LEAF_PACK=0 disables
+        self.trim_rows = os.environ.get("LEAF_PACK", "1") != "0"
         self.training = False
         # training state (allocated on demand)
         self.grads = self.exp_avg = self.exp_avg_sq = self.w16_bwd = self._stash = None
@@ -225,24 +227,43 @@ class LeafCLIPText:
             raise ValueError(f"tokens must be [N,{self.cfg.context_length}], got {tuple(t.shape)}")
         return t
 
-    def encode_text(self, text, normalize: bool = False) -> torch.Tensor:
+    def _row_plan(self, text, seq_lens):
+        """(host lens pointer, device cu tensor, keep-alive) for EOT trimming, or NULLs for the dense layout.
+        Lengths come from the caller (host array) or, for host-resident tokens, from argmax(tokens) + 1."""
+        if not self.trim_rows:
+            return C.c_void_p(0), None, None
+        if seq_lens is None:
+            if isinstance(text, np.ndarray):
+                seq_lens = text.reshape(-1, text.shape[-1]).argmax(-1) + 1
+            elif isinstance(text, torch.Tensor) and text.device.type == "cpu":
+                seq_lens = (text.reshape(-1, text.shape[-1]).argmax(-1) + 1).numpy()
+            else:
+                return C.c_void_p(0), None, None       # device-resident tokens, lengths unknown on the host
+        lens = np.ascontiguousarray(np.asarray(seq_lens).reshape(-1), dtype=np.int32)
+        cu = np.zeros(lens.size + 1, dtype=np.int32)
+        np.cumsum(lens, out=cu[1:])
+        return C.c_void_p(lens.ctypes.data), torch.from_numpy(cu).to(self.device), lens
+
+    def encode_text(self, text, normalize: bool = False, seq_lens=None) -> torch.Tensor:
         if not self._packed:
             self.pack()
+        lens_p, cu, keep = self._row_plan(text, seq_lens)
         t = self._tokens(text)
         n = t.shape[0]
         out = torch.empty(n, self.cfg.embed_dim, dtype=torch.float32, device=self.device)
         ws = self._workspace(0, n)
-        _lib.check(self._lib.leaf_text_forward(self._h, _ptr(self.flat), _ptr(self.w16), _ptr(t), n, _ptr(out),
-                                               int(bool(normalize)), _ptr(ws), ws.numel(), self._stream()),
+        _lib.check(self._lib.leaf_text_forward(self._h, _ptr(self.flat), _ptr(self.w16), _ptr(t), lens_p, _ptr(cu), n,
+                                               _ptr(out), int(bool(normalize)), _ptr(ws), ws.numel(), self._stream()),
                    "leaf_text_forward")
         return out
 
     def score_candidates(self, tokens, anchor: torch.Tensor, rho: int, objective: str = "l2", want_features=True,
-                         want_loss=False):
+                         want_loss=False, seq_lens=None):
         """tokens [B*rho, ctx] (or [B,rho,ctx]); anchor [B,D] fp32 CUDA.  Returns (best_idx int32[B],
         best_feat [B,D] or None) (+ loss [B,rho] when want_loss)."""
         if not self._packed:
             self.pack()
+        lens_p, cu, keep = self._row_plan(tokens, seq_lens)
         if isinstance(tokens, np.ndarray):
             tokens = torch.from_numpy(tokens)
         t = self._tokens(tokens.reshape(-1, tokens.shape[-1]))
@@ -254,9 +275,10 @@ class LeafCLIPText:
         feat = torch.empty(B, self.cfg.embed_dim, dtype=torch.float32, device=self.device) if want_features else None
         loss = torch.empty(B, rho, dtype=torch.float32, device=self.device) if want_loss else None
         ws = self._workspace(1, B * rho)
-        _lib.check(self._lib.leaf_score_candidates(self._h, _ptr(self.flat), _ptr(self.w16), _ptr(t), _ptr(anchor), B,
-                                                   rho, _OBJ[objective], _ptr(idx), _ptr(feat), _ptr(loss), _ptr(ws),
-                                                   ws.numel(), self._stream()), "leaf_score_candidates")
+        _lib.check(self._lib.leaf_score_candidates(self._h, _ptr(self.flat), _ptr(self.w16), _ptr(t), lens_p, _ptr(cu),
+                                                   _ptr(anchor), B, rho, _OBJ[objective], _ptr(idx), _ptr(feat),
+                                                   _ptr(loss), _ptr(ws), ws.numel(), self._stream()),
+                   "leaf_score_candidates")
         return (idx, feat, loss) if want_loss else (idx, feat)
 
     # ------------------------------------------------------------------ training
@@ -273,10 +295,12 @@ class LeafCLIPText:
     def zero_grad(self):
         self.grads.zero_()
 
-    def forward_train(self, text) -> torch.Tensor:
+    def forward_train(self, text, seq_lens=None) -> torch.Tensor:
         self.enable_training()
         if not self._packed:
             self.pack()
+        self._train_plan = self._row_plan(text, seq_lens)
+        lens_p, cu, keep = self._train_plan
         t = self._tokens(text)
         n = t.shape[0]
         need = self._lib.leaf_text_stash_bytes(self._h, n)
@@ -285,9 +309,9 @@ class LeafCLIPText:
             with torch.cuda.device(self.device):
                 self._stash = torch.empty(need, dtype=torch.uint8, device=self.device)
         out = torch.empty(n, self.cfg.embed_dim, dtype=torch.float32, device=self.device)
-        _lib.check(self._lib.leaf_text_forward_train(self._h, _ptr(self.flat), _ptr(self.w16), _ptr(t), n, _ptr(out),
-                                                     _ptr(self._stash), self._stash.numel(), C.c_void_p(0), 0,
-                                                     self._stream()), "leaf_text_forward_train")
+        _lib.check(self._lib.leaf_text_forward_train(self._h, _ptr(self.flat), _ptr(self.w16), _ptr(t), lens_p, _ptr(cu),
+                                                     n, _ptr(out), _ptr(self._stash), self._stash.numel(),
+                                                     C.c_void_p(0), 0, self._stream()), "leaf_text_forward_train")
         self._train_tokens = t
         return out
 
@@ -299,8 +323,9 @@ class LeafCLIPText:
         loss = torch.empty((), dtype=torch.float32, device=self.device)
         anchor = anchor.to(device=self.device, dtype=torch.float32).contiguous()
         ws = self._workspace(2, n)
-        _lib.check(self._lib.leaf_textfare_backward(self._h, _ptr(self.flat), _ptr(self.w16_bwd), _ptr(t), n,
-                                                    _ptr(feat.contiguous()), _ptr(anchor), float(accum_scale),
+        lens_p, cu, keep = self._train_plan
+        _lib.check(self._lib.leaf_textfare_backward(self._h, _ptr(self.flat), _ptr(self.w16_bwd), _ptr(t), lens_p,
+                                                    _ptr(cu), n, _ptr(feat.contiguous()), _ptr(anchor), float(accum_scale),
                                                     _ptr(self._stash), _ptr(self.grads), _ptr(loss), _ptr(ws),
                                                     ws.numel(), self._stream()), "leaf_textfare_backward")
         return loss

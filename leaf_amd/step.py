@@ -68,17 +68,24 @@ class SyntheticCandidates:
         return cand
 
 
-def search_synthetic(model, anchor: torch.Tensor, base: torch.Tensor, cfg: StepConfig, seed: int) -> torch.Tensor:
-    """2k calls of score_candidates on [B*rho, ctx] synthetic candidates; returns the adversarial ids [B, ctx]."""
+def search_synthetic(model, anchor: torch.Tensor, base: torch.Tensor, cfg: StepConfig, seed: int,
+                     base_lens=None) -> torch.Tensor:
+    """2k calls of score_candidates on [B*rho, ctx] synthetic candidates; returns the adversarial ids [B, ctx].
+    ``base_lens`` (host int array, EOT position + 1 per caption) enables EOT trimming: the synthetic edits never move
+    EOT, so every candidate of caption b has the same length as b."""
+    import numpy as np
+    cand_lens = None if base_lens is None else np.repeat(np.asarray(base_lens, dtype=np.int32), cfg.rho)
     gen = SyntheticCandidates(base, cfg.rho, model.cfg.vocab_size, seed)
     cur = base
     B = base.shape[0]
     ar = torch.arange(B, device=base.device)
     for _ in range(cfg.k_adv):
         cand, pos = gen.stage1(cur)
-        best1, _ = model.score_candidates(cand.view(B * cfg.rho, -1), anchor, cfg.rho, "l2", want_features=False)
+        best1, _ = model.score_candidates(cand.view(B * cfg.rho, -1), anchor, cfg.rho, "l2", want_features=False,
+                                          seq_lens=cand_lens)
         cand = gen.stage2(cur, pos, best1)
-        best2, _ = model.score_candidates(cand.view(B * cfg.rho, -1), anchor, cfg.rho, "l2", want_features=False)
+        best2, _ = model.score_candidates(cand.view(B * cfg.rho, -1), anchor, cfg.rho, "l2", want_features=False,
+                                          seq_lens=cand_lens)
         cur = cand[ar, best2.to(torch.int64)]
     return cur
 
@@ -93,13 +100,13 @@ def allreduce_grads(model) -> float:
 
 
 def train_step_tokens(model, frozen, base: torch.Tensor, cfg: StepConfig, seed: int, lr: Optional[float] = None,
-                      micro_index: int = 0) -> torch.Tensor:
+                      micro_index: int = 0, base_lens=None) -> torch.Tensor:
     """Full outer step on token ids (int32 [B, ctx] on the model's device).  Returns the TextFARE loss (0-d)."""
     model.eval()
-    anchor = frozen.encode_text(base)
-    adv = search_synthetic(model, anchor, base, cfg, seed)
+    anchor = frozen.encode_text(base, seq_lens=base_lens)
+    adv = search_synthetic(model, anchor, base, cfg, seed, base_lens=base_lens)
     model.train()
-    feat = model.forward_train(adv)
+    feat = model.forward_train(adv, seq_lens=base_lens)
     if micro_index % cfg.accum_freq == 0:
         model.zero_grad()
     loss = model.backward(feat, anchor, accum_scale=1.0 / cfg.accum_freq)

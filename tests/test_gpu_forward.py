@@ -148,3 +148,33 @@ def test_attack_text_replays_reference_trace(torch_mod, golden_dir):
             l_got = ((f_got - z["anchor"]) ** 2).sum(-1)
             assert t["k"] > 1 or np.all(l_got >= l_ref * (1 - 5e-3)), (adv, t["adv"])
     attacks.set_dictionary(None)
+
+
+def test_packed_rows_are_bit_exact(torch_mod, monkeypatch):
+    """EOT trimming (compute only rows <= EOT) is exact work skipping: outputs, search decisions and losses are
+    bit-identical to the dense 77-row computation, for host tokens (lengths inferred) and device tokens + lens."""
+    from leaf_amd.model import LeafCLIPText, get_config
+    toks = O.synthetic_tokens(45, seed=6, min_len=1, max_len=74)
+    toks[0, :] = 0; toks[0, 0] = 49406; toks[0, 1] = 49407            # shortest possible caption (len 2)
+    toks[1] = np.arange(1, 78); toks[1, 0] = 49406; toks[1, 76] = 49407   # longest (len 77)
+    m = _model("tiny-test-quickgelu", 12)
+    assert m.trim_rows
+    packed = m.encode_text(toks).cpu().numpy()
+    m.trim_rows = False
+    dense = m.encode_text(toks).cpu().numpy()
+    m.trim_rows = True
+    assert np.array_equal(packed, dense)
+    dev = torch_mod.from_numpy(toks.astype(np.int32)).cuda()
+    lens = toks.argmax(-1) + 1
+    assert np.array_equal(m.encode_text(dev, seq_lens=lens).cpu().numpy(), dense)
+    small = LeafCLIPText(get_config("tiny-test-quickgelu"), chunk=4).copy_from(m)   # chunks split by row budget
+    assert np.array_equal(small.encode_text(toks).cpu().numpy(), dense)
+    # search stage
+    B, rho = 5, 12
+    base = O.synthetic_tokens(B, seed=2)
+    cand = O.synthetic_candidates(base, rho, seed=3).reshape(-1, 77)
+    anchor = m.encode_text(base)
+    i1, f1, l1 = m.score_candidates(cand, anchor, rho, "l2", want_loss=True)
+    m.trim_rows = False
+    i2, f2, l2 = m.score_candidates(cand, anchor, rho, "l2", want_loss=True)
+    assert torch_mod.equal(i1, i2) and torch_mod.equal(f1, f2) and torch_mod.equal(l1, l2)

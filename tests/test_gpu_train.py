@@ -95,3 +95,21 @@ def test_full_step_moves_loss_down(torch_mod):
     feat = m.encode_text(adv)
     final = float(((feat - anchor) ** 2).sum(-1).mean())
     assert np.isfinite(losses).all() and final < losses[0], (losses, final)
+
+
+def test_packed_training_matches_dense(torch_mod):
+    """Training forward/backward on EOT-trimmed rows gives the same loss and gradients as the dense layout (only the
+    order of fp32 atomic adds differs)."""
+    from leaf_amd.model import create_model
+    toks = O.synthetic_tokens(8, seed=21, min_len=3, max_len=60)
+    res = []
+    for trim in (True, False):
+        m = create_model("tiny-test", seed=11, trainable=True)
+        m.trim_rows = trim
+        anchor = m.encode_text(toks) + 0.1
+        feat = m.forward_train(toks)
+        m.zero_grad()
+        loss = float(m.backward(feat, anchor))
+        res.append((loss, feat.cpu().numpy(), m.grads.cpu().numpy()))
+    assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1])
+    assert rel_l2(res[0][2], res[1][2]) < 1e-5
