@@ -152,24 +152,34 @@ __global__ __launch_bounds__(256) void pool_project_kernel(const float* __restri
         }
     }
     __syncthreads();
-    // phase 2: out[r][j] = sum_k xs[r][k] * proj[k][j]; thread owns columns tid + 256*jj
+    // phase 2: out[r][j] = sum_k xs[r][k] * proj[k][j]; thread owns columns tid + 256*jj.  k is walked in blocks of
+    // KU with all KU x JJ projection loads issued before the FMAs (otherwise every k pays one L2 round trip).
+    constexpr int KU = 8;
     float acc[JJMAX][PR];
 #pragma unroll
     for (int jj = 0; jj < JJMAX; ++jj)
 #pragma unroll
         for (int r = 0; r < PR; ++r) acc[jj][r] = 0.f;
-    for (int k = 0; k < d; ++k) {
-        float xv[PR];
+    const int njj = (D + 255) >> 8;
+    for (int k0 = 0; k0 < d; k0 += KU) {
+        float pv[KU][JJMAX];
 #pragma unroll
-        for (int r = 0; r < PR; ++r) xv[r] = xs[r * d + k];
+        for (int u = 0; u < KU; ++u)
 #pragma unroll
-        for (int jj = 0; jj < JJMAX; ++jj) {
-            int j = tid + 256 * jj;
-            if (j < D) {
-                float pv = proj[(size_t)k * D + j];
-#pragma unroll
-                for (int r = 0; r < PR; ++r) acc[jj][r] = fmaf(xv[r], pv, acc[jj][r]);
+            for (int jj = 0; jj < JJMAX; ++jj) {
+                const int j = tid + 256 * jj;
+                pv[u][jj] = (jj < njj && j < D) ? proj[(size_t)(k0 + u) * D + j] : 0.f;
             }
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            float xv[PR];
+#pragma unroll
+            for (int r = 0; r < PR; ++r) xv[r] = xs[r * d + k0 + u];
+#pragma unroll
+            for (int jj = 0; jj < JJMAX; ++jj)
+                if (jj < njj)
+#pragma unroll
+                    for (int r = 0; r < PR; ++r) acc[jj][r] = fmaf(xv[r], pv[u][jj], acc[jj][r]);
         }
     }
     if (normalize) {

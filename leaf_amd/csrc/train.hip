@@ -198,15 +198,22 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             }
         }
     }
+    // block-level reduction of the per-wave column partials through LDS, then one atomic per column per block
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* red = (float4*)smem;   // [4 waves][2][nq]
 #pragma unroll
     for (int i = 0; i < MAXCH; ++i) {
         int c = lane + 64 * i;
-        if (c < nq) {
-            atomicAdd(dg + 4 * c + 0, pg[i].x); atomicAdd(dg + 4 * c + 1, pg[i].y);
-            atomicAdd(dg + 4 * c + 2, pg[i].z); atomicAdd(dg + 4 * c + 3, pg[i].w);
-            atomicAdd(db + 4 * c + 0, pb[i].x); atomicAdd(db + 4 * c + 1, pb[i].y);
-            atomicAdd(db + 4 * c + 2, pb[i].z); atomicAdd(db + 4 * c + 3, pb[i].w);
-        }
+        if (c < nq) { red[(wid * 2 + 0) * nq + c] = pg[i]; red[(wid * 2 + 1) * nq + c] = pb[i]; }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * nq; c += 256) {
+        const int which = c / nq, cc = c - which * nq;
+        float4 a = red[(0 * 2 + which) * nq + cc], b1 = red[(1 * 2 + which) * nq + cc];
+        float4 b2 = red[(2 * 2 + which) * nq + cc], b3 = red[(3 * 2 + which) * nq + cc];
+        float* dst = (which ? db : dg) + 4 * cc;
+        atomicAdd(dst + 0, (a.x + b1.x) + (b2.x + b3.x)); atomicAdd(dst + 1, (a.y + b1.y) + (b2.y + b3.y));
+        atomicAdd(dst + 2, (a.z + b1.z) + (b2.z + b3.z)); atomicAdd(dst + 3, (a.w + b1.w) + (b2.w + b3.w));
     }
 }
 
@@ -396,10 +403,10 @@ hipError_t leaf_launch_pool_project_bwd(const float* dout, const float* pooled, 
 hipError_t leaf_launch_layernorm_bwd(const float* dy, const float* x, const float* g, float eps, float* dx_inout,
                                      void* dx16, float* dg, float* db, int rows, int d, hipStream_t s) {
     if (d % 4 || d > 256 * MAXCH) return hipErrorInvalidValue;
-    int grid = (rows + 3) / 4;
-    if (grid > 512) grid = 512;
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), 0, s, dy, x, g, eps, dx_inout, (__bf16*)dx16, dg, db, rows,
-                       d);
+    int grid = (rows + 15) / 16;
+    if (grid > 256) grid = 256;
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), (size_t)8 * d * sizeof(float), s, dy, x, g, eps, dx_inout,
+                       (__bf16*)dx16, dg, db, rows, d);
     return hipGetLastError();
 }
 
