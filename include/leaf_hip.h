@@ -110,6 +110,11 @@ int leaf_prof_end(double* ms, double* flops, int64_t* count, int n_keys);
  * 3 fp32 = beta*C + acc, 4 store16(acc * act'(aux)).  A, B 16-bit of `dtype`, contiguous. */
 int leaf_op_gemm(int dtype, int epi, const void* A, const void* B, void* C, const float* bias, void* aux, int M, int N,
                  int K, int act, float beta, int aux_f16, leaf_stream_t s);
+/* same with explicit row strides (elements) */
+int leaf_op_gemm_ld(int dtype, int epi, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias,
+                    void* aux, int M, int N, int K, int act, float beta, int aux_f16, leaf_stream_t s);
+/* diagnostic builds (-DLEAF_GEMM_STAMPS) only: 8 x uint64 s_memtime stamps per GEMM workgroup land in buf */
+int leaf_debug_gemm_stamps(void* buf);
 int leaf_op_attention_fwd(const void* qkv, void* out, int n_seq, int ctx, int heads, int width, int dtype,
                           leaf_stream_t s);
 int leaf_op_layernorm(const float* x, const float* g, const float* b, float eps, void* out16, int rows, int width,

@@ -135,7 +135,7 @@ int leaf_gemm(int dtype, int epi, const void* A, int lda, const void* B, int ldb
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.aux = aux;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
-    g.act = act; g.aux_f16 = aux_f16; g.beta = beta; g.dbg = 0;
+    g.act = act; g.aux_f16 = aux_f16; g.beta = beta; g.stamps = nullptr;
     if (!g_prof_on) return leaf_check(leaf_launch_gemm(g, dtype, epi, s), "gemm");
     ProfRec r;
     r.key = dtype * 8 + epi;
@@ -301,6 +301,12 @@ extern "C" int leaf_op_gemm(int dtype, int epi, const void* A, const void* B, vo
                             int M, int N, int K, int act, float beta, int aux_f16, leaf_stream_t s) {
     return leaf_gemm(dtype, epi, A, K, B, K, C, N, bias, aux, M, N, K, act, (hipStream_t)s, beta, aux_f16);
 }
+extern "C" int leaf_op_gemm_ld(int dtype, int epi, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                               const float* bias, void* aux, int M, int N, int K, int act, float beta, int aux_f16,
+                               leaf_stream_t s) {
+    return leaf_gemm(dtype, epi, A, lda, B, ldb, C, ldc, bias, aux, M, N, K, act, (hipStream_t)s, beta, aux_f16);
+}
+extern "C" int leaf_debug_gemm_stamps(void* buf) { leaf_gemm_set_stamps(buf); return 0; }
 extern "C" int leaf_op_attention_fwd(const void* qkv, void* out, int n_seq, int ctx, int heads, int width, int dtype,
                                      leaf_stream_t s) {
     return leaf_check(leaf_launch_attention_fwd(qkv, out, n_seq, RowMap{nullptr, 0, 0, ctx}, heads, width, dtype,

@@ -63,7 +63,8 @@ __device__ __forceinline__ float wave_max(float v) {
 enum { ACT_GELU = 0, ACT_QUICKGELU = 1 };
 
 __device__ __forceinline__ float act_fwd(float x, int act) {
-    if (act == ACT_QUICKGELU) return x / (1.f + __expf(-1.702f * x));
+    // x * sigmoid(1.702 x) with the hardware exp2 / rcp (1 ulp each): 5 VALU ops instead of a ~20-op IEEE divide
+    if (act == ACT_QUICKGELU) return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.4554669595930157f * x));
     return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
 }
 __device__ __forceinline__ float act_bwd(float x, int act) {

@@ -205,6 +205,19 @@ constexpr int STAGE2 = 2 * TILE2;     // 64 KiB
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
 
+// Diagnostic build only (-DLEAF_GEMM_STAMPS): wave 0 stores s_memtime at five points of every block into p.stamps
+// (a buffer nothing else reads).  The shipped library is built without it.
+#ifdef LEAF_GEMM_STAMPS
+#define STAMP(i)                                                                                          \
+    if (p.stamps && threadIdx.x == 0) {                                                                   \
+        unsigned long long t_;                                                                            \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                        \
+        ((unsigned long long*)p.stamps)[(size_t)blockIdx.x * 8 + (i)] = t_;                               \
+    }
+#else
+#define STAMP(i)
+#endif
+
 template <class TT, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -266,14 +279,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs p) {
     }
 
     const int nt = p.K / BK;
+    STAMP(0)
     ISSUE_TILE(0, 0)
     for (int t = 0; t < nt - 1; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (t == 0) { STAMP(1) }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (p.dbg != 1) ISSUE_TILE((t + 1) & 1, (t + 1) * BK)
-        if (p.dbg != 2) COMPUTE2(t & 1)
+        ISSUE_TILE((t + 1) & 1, (t + 1) * BK)
+        COMPUTE2(t & 1)
     }
+    STAMP(2)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -282,6 +298,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs p) {
 #undef ISSUE_TILE
 #undef COMPUTE2
 
+    STAMP(3)
     {
         const int nbase = n0 + wn * 64 + 4 * (lane >> 4);
         float4 bias4[4];
@@ -296,6 +313,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs p) {
             epilogue_block<TT, EPI, 4, 4>(p, mrow, nbase, bias4, sub);
         }
     }
+    STAMP(4)
 }
 
 template <class TT>
@@ -333,11 +351,16 @@ hipError_t launch_t(const GemmArgs& p, int epi, hipStream_t s) {
 
 }  // namespace
 
+static void* g_stamps = nullptr;
+void leaf_gemm_set_stamps(void* p) { g_stamps = p; }
+
 hipError_t leaf_launch_gemm(const GemmArgs& p_in, int dtype, int epi, hipStream_t s) {
     GemmArgs p = p_in;
-    static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("LEAF_GEMM_DBG"); dbg = e ? atoi(e) : 0; }
-    p.dbg = dbg;
+    p.stamps = g_stamps;
+    static int ver = -1;   // LEAF_GEMM_V=1 forces the previous-generation kernels (A/B runs)
+    if (ver < 0) { const char* e = getenv("LEAF_GEMM_V"); ver = e ? atoi(e) : 2; }
+    if (ver >= 2 && p.M > 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && leaf_gemm256_eligible(p, epi))
+        return leaf_launch_gemm256(p, dtype, epi, s);
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.N % BN || p.K % BK || p.lda % 8 || p.ldb % 8 || p.ldc % 4)
         return hipErrorInvalidValue;
     return dtype == LEAF_F16 ? launch_t<F16>(p, epi, s) : launch_t<BF16>(p, epi, s);

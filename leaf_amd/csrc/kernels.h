@@ -25,10 +25,14 @@ struct GemmArgs {
     int act;      // ACT_GELU / ACT_QUICKGELU
     int aux_f16;  // EPI_ACTGRAD_T: aux is fp16 (1) or bf16 (0)
     float beta;
-    int dbg;      // perf experiments only (LEAF_GEMM_DBG): 1 = no DMA in the K loop, 2 = no MFMA phase
+    void* stamps; // diagnostic builds only (-DLEAF_GEMM_STAMPS)
 };
 
 hipError_t leaf_launch_gemm(const GemmArgs& p, int dtype, int epi, hipStream_t s);
+void leaf_gemm_set_stamps(void* p);
+// 256x256 4-stage LDS-DMA ring kernel (gemm256.hip); eligible() says whether a problem may use it
+bool leaf_gemm256_eligible(const GemmArgs& p, int epi);
+hipError_t leaf_launch_gemm256(const GemmArgs& p, int dtype, int epi, hipStream_t s);
 
 // ---- forward elementwise / reduction kernels (elementwise.hip)
 // x[r,:] = tok_emb[tokens[r],:] + pos_emb[r % ctx,:]   and   xn = LN(x) (16-bit)

@@ -18,13 +18,15 @@ def main():
     shapes = [("qkv", 0, 3 * d, d), ("out", 2, d, d), ("fc", 1, 4 * d, d), ("proj", 2, d, 4 * d)]
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     tot_ms, tot_fl = 0.0, 0.0
+    pad = int(os.environ.get("PAD", "0"))     # extra elements per row (stride experiments)
     for name, epi, N, K in shapes:
-        A = (torch.randn(M, K, device=dev) * 0.5).half()
-        B = (torch.randn(N, K, device=dev) * 0.05).half()
+        A = (torch.randn(M, K + pad, device=dev) * 0.5).half()
+        B = (torch.randn(N, K + pad, device=dev) * 0.05).half()
         bias = torch.randn(N, device=dev)
-        Cm = torch.zeros(M, N, device=dev, dtype=torch.float32 if epi == 2 else torch.float16)
-        args = (1, epi, C.c_void_p(A.data_ptr()), C.c_void_p(B.data_ptr()), C.c_void_p(Cm.data_ptr()),
-                C.c_void_p(bias.data_ptr()), None, M, N, K, 1, 0.0, 0, st)
+        Cm = torch.zeros(M, N + pad, device=dev, dtype=torch.float32 if epi == 2 else torch.float16)
+        args = (1, epi, C.c_void_p(A.data_ptr()), K + pad, C.c_void_p(B.data_ptr()), K + pad, C.c_void_p(Cm.data_ptr()),
+                N + pad, C.c_void_p(bias.data_ptr()), None, M, N, K, 1, 0.0, 0, st)
+        lib.leaf_op_gemm = lib.leaf_op_gemm_ld
         for _ in range(3):
             _lib.check(lib.leaf_op_gemm(*args), "gemm")
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
