@@ -36,7 +36,7 @@ extern "C" int leaf_text_create(const leaf_text_cfg* cfg, int fwd_dtype, leaf_te
     leaf_text* h = new leaf_text();
     h->cfg = *cfg;
     h->fwd_dtype = fwd_dtype;
-    h->chunk = 1024;
+    h->chunk = 4096;
     const int L = cfg->layers, D = cfg->embed_dim;
     size_t off = 0;
     auto add = [&](const std::string& name, int64_t rows, int64_t cols) {

@@ -89,7 +89,7 @@ class LeafCLIPText:
         h = C.c_void_p()
         _lib.check(self._lib.leaf_text_create(C.byref(c), _DTYPES[dtype], C.byref(h)), "leaf_text_create")
         self._h = h
-        chunk = chunk or int(os.environ.get("LEAF_CHUNK", "1024"))
+        chunk = chunk or int(os.environ.get("LEAF_CHUNK", "4096"))   # sequences-worth of rows per pass (x 77 rows)
         _lib.check(self._lib.leaf_text_set_chunk(h, chunk), "leaf_text_set_chunk")
         self.n_params = self._lib.leaf_text_param_count(h)
         self.n_decay = self._lib.leaf_text_decay_count(h)
@@ -242,7 +242,8 @@ class LeafCLIPText:
         lens = np.ascontiguousarray(np.asarray(seq_lens).reshape(-1), dtype=np.int32)
         cu = np.zeros(lens.size + 1, dtype=np.int32)
         np.cumsum(lens, out=cu[1:])
-        return C.c_void_p(lens.ctypes.data), torch.from_numpy(cu).to(self.device), lens
+        # pinned + non_blocking: a pageable H2D copy would make the host wait for all queued GPU work
+        return C.c_void_p(lens.ctypes.data), torch.from_numpy(cu).pin_memory().to(self.device, non_blocking=True), lens
 
     def encode_text(self, text, normalize: bool = False, seq_lens=None) -> torch.Tensor:
         if not self._packed:

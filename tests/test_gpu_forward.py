@@ -178,3 +178,18 @@ def test_packed_rows_are_bit_exact(torch_mod, monkeypatch):
     m.trim_rows = False
     i2, f2, l2 = m.score_candidates(cand, anchor, rho, "l2", want_loss=True)
     assert torch_mod.equal(i1, i2) and torch_mod.equal(f1, f2) and torch_mod.equal(l1, l2)
+
+
+@pytest.mark.parametrize("model", ["ViT-H-14", "ViT-bigG-14"])
+def test_encode_text_large_towers_vs_oracle(torch_mod, model):
+    """BASELINE.json configs[3]/[4] shapes (d=1024/24 layers, d=1280/32 layers, erf-GELU): a few captions against the
+    fp32 oracle, same 1e-3 rel-L2 gate."""
+    cfg = O.CONFIGS[model]
+    w = O.init_weights(cfg, seed=2)
+    m = _model(model, 2)
+    toks = O.synthetic_tokens(6, seed=11, min_len=5, max_len=60)
+    want = O.encode_text(w, cfg, toks)
+    got = m.encode_text(toks).cpu().numpy()
+    r = row_rel_l2(got, want)
+    print(f"{model}: rel-L2 global {rel_l2(got, want):.3e} row max {r.max():.3e}")
+    assert rel_l2(got, want) < TOL_GLOBAL and r.max() < TOL_ROW
