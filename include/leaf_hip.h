@@ -100,6 +100,22 @@ int leaf_adamw_step(float* params, const float* grads, float* exp_avg, float* ex
                     float lr, float beta1, float beta2, float eps, float wd, int step, float grad_scale,
                     leaf_stream_t s);
 
+/* ---- native host side of the search: CLIP BPE + single-edit mutation, multithreaded ----
+ * leaf_tok_create takes the DECOMPRESSED text of bpe_simple_vocab_16e6.txt (src/open_clip/tokenizer.py:139-150).
+ * Fast path = printable ASCII without '&'; other inputs are flagged in `fallback` (1 byte per text / per candidate)
+ * and must be tokenised by the caller's reference-equivalent tokenizer.  lens[i] = EOT position + 1. */
+typedef struct leaf_tok* leaf_tok_t;
+int leaf_tok_create(const char* merges_text, size_t len, leaf_tok_t* out);
+void leaf_tok_destroy(leaf_tok_t tk);
+/* SimpleTokenizer.__call__ (tokenizer.py:226-265): texts -> int32 [n, ctx] */
+int leaf_tok_encode_batch(leaf_tok_t tk, const char* const* texts, const int32_t* text_len, int n, int ctx,
+                          int32_t* tokens, int32_t* lens, uint8_t* fallback, int n_threads);
+/* generate_sentence(S, z, u, V, alternative=-1) (utils_attacks.py:169-213) for B sentences x rho (z, c = V[u]) pairs,
+ * then tokenisation of every candidate: -> int32 [B*rho, ctx] */
+int leaf_tok_mutate_encode(leaf_tok_t tk, const char* const* sentences, const int32_t* sent_len, int B, const int32_t* z,
+                           const int32_t* c, int rho, int ctx, int32_t* tokens, int32_t* lens, uint8_t* fallback,
+                           int n_threads);
+
 /* ---- per-launch GEMM timing (bench.py roofline): between begin/end every GEMM launch is bracketed by HIP events on
  * its stream; end() sums duration / algorithmic FLOPs / launches per key = operand_dtype*8 + epilogue id. */
 int leaf_prof_begin(void);

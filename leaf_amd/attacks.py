@@ -132,46 +132,71 @@ def valid_sentence_batched(original, attacked, debug=False):
 
 
 # ----------------------------------------------------------------------------- the search
+def _apply_edit(S: str, z: int, c: int) -> str:
+    """generate_sentence(S, z, u, V, alternative=-1) with c = V[u] (code point or -1)."""
+    if z & 1:
+        i = (z - 1) // 2
+        return S[:i] + S[i + 1:] if (c == -1 or S[i] == chr(c)) else S[:i] + chr(c) + S[i + 1:]
+    i = z // 2
+    return S if (c == -1 or c == 95) else S[:i] + chr(c) + S[i:]     # a slot holds '_' (95) in the expanded view
+
+
+def _stage_candidates(tokenizer, sentences, z, c, constrain, trace):
+    """Token ids / kept lengths of the B x rho single-edit candidates (z, c) of ``sentences``.
+    With a ``NativeTokenizer`` the mutation + BPE of all candidates run in C++ threads
+    (leaf_amd/csrc/host_text.cpp); strings are only materialised for --constrain, traces and fast-path misses."""
+    B, rho = z.shape
+    native = hasattr(tokenizer, "mutate_encode")
+    need_strings = constrain or trace is not None or not native
+    SS = None
+    if need_strings:
+        SS = [[_apply_edit(S, int(z[b, r]), int(c[b, r])) for r in range(rho)] for b, S in enumerate(sentences)]
+        if constrain:
+            valid = valid_sentence_batched(sentences, SS)
+            for b, S in enumerate(sentences):
+                for r in range(rho):
+                    if not valid[b][r]:
+                        SS[b][r] = S
+                        z[b, r], c[b, r] = 0, -1          # the no-op edit: candidate == original sentence
+        if trace is not None:
+            trace.append([x for row in SS for x in row])
+    if native:
+        toks, lens = tokenizer.mutate_encode(sentences, z, c, lambda b, r: _apply_edit(sentences[b], int(z[b, r]), int(c[b, r])))
+    else:
+        toks = tokenizer.encode_batch([x for row in SS for x in row])
+        lens = None
+    return toks, lens
+
+
 def attack_text_leaf(model, tokenizer, sentences, anchor_features, device=None, objective="l2", n=10, k=1,
                      V=DEFAULT_V, constrain=False, debug=False, return_trace: Optional[list] = None):
     """LEAF attack on a batch of sentences.  ``model`` is a ``leaf_amd.model.LeafCLIPText`` (anything with
     ``score_candidates``); ``anchor_features`` a float32 CUDA tensor [B, D].  Returns
-    ``(best_features [B,D], adversarial sentences)`` like the reference."""
-    import torch
+    ``(best_features [B,D], adversarial sentences)`` like the reference.  The numpy global RNG is consumed exactly as
+    the reference does (one ``np.random.choice`` per sentence and stage, utils_attacks.py:317,236)."""
     sentences = list(sentences)
     B = len(sentences)
     if objective in ("dissim", "sim"):
         anchor_features /= anchor_features.norm(dim=-1, keepdim=True)   # in place, as the reference does
-    space = [ord(' ')]
     best_feat = None
+    Varr = np.asarray(V, dtype=np.int32)
     for _ in range(k):
         # stage 1: rho random positions, insert / replace-with / delete a space
-        positions, SS = [], []
-        for S in sentences:
-            positions.append(np.random.choice(range(2 * len(S) + 1), size=n, replace=n > 2 * len(S) + 1))
-            SS.append(generate_all_sentences(S, space, subset_z=positions[-1], alternative=-1))
-        if constrain:
-            valid = valid_sentence_batched(sentences, SS)
-            SS = [[c if ok else S for c, ok in zip(row, vrow)] for S, row, vrow in zip(sentences, SS, valid)]
-        flat = [c for row in SS for c in row]
-        if return_trace is not None:
-            return_trace.append(flat)
-        ids_best, _ = model.score_candidates(tokenizer.encode_batch(flat), anchor_features, n, objective,
-                                             want_features=False)
+        z = np.stack([np.random.choice(range(2 * len(S) + 1), size=n, replace=n > 2 * len(S) + 1) for S in sentences]).astype(np.int32)
+        c = np.full((B, n), ord(' '), dtype=np.int32)
+        positions = z.copy()            # the reference reads the winner's position from the sampled ones (:351-353)
+        toks, lens = _stage_candidates(tokenizer, sentences, z, c, constrain, return_trace)
+        ids_best, _ = model.score_candidates(toks, anchor_features, n, objective, want_features=False, seq_lens=lens)
         ids_best = ids_best.cpu().numpy()
-        best_pos = [positions[row][i] for row, i in enumerate(ids_best)]
+        best_pos = positions[np.arange(B), ids_best]
         # stage 2: rho random characters at the chosen position
-        SS = [generate_random_sentences_at_z(S, best_pos[i], V, n, alternative=-1) for i, S in enumerate(sentences)]
-        if constrain:
-            valid = valid_sentence_batched(sentences, SS)
-            SS = [[c if ok else S for c, ok in zip(row, vrow)] for S, row, vrow in zip(sentences, SS, valid)]
-        flat = [c for row in SS for c in row]
-        if return_trace is not None:
-            return_trace.append(flat)
-        ids_best, best_feat = model.score_candidates(tokenizer.encode_batch(flat), anchor_features, n, objective,
-                                                     want_features=True)
+        u = np.stack([np.random.choice(range(len(V)), size=n, replace=(n > len(V))) for _ in sentences])
+        c = Varr[u]
+        z = np.repeat(best_pos[:, None], n, axis=1).astype(np.int32)
+        toks, lens = _stage_candidates(tokenizer, sentences, z, c, constrain, return_trace)
+        ids_best, best_feat = model.score_candidates(toks, anchor_features, n, objective, want_features=True, seq_lens=lens)
         ids_best = ids_best.cpu().numpy()
-        sentences = [flat[row * n + int(i)] for row, i in enumerate(ids_best)]
+        sentences = [_apply_edit(S, int(z[b, ids_best[b]]), int(c[b, ids_best[b]])) for b, S in enumerate(sentences)]
         if debug:
             print(sentences[0])
     return best_feat, sentences

@@ -143,5 +143,13 @@ def get_tokenizer(model_name: str = "", context_length: int = DEFAULT_CONTEXT_LE
     """open_clip.get_tokenizer equivalent for the CLIP text towers in scope (all use the same BPE)."""
     global _default
     if _default is None or _default.context_length != context_length:
-        _default = SimpleTokenizer(context_length=context_length)
+        _default = None
+        if os.environ.get("LEAF_NATIVE_HOST", "1") != "0":
+            try:   # C++ threads for the batch paths (leaf_amd/csrc/host_text.cpp); same results
+                from .native_text import NativeTokenizer
+                _default = NativeTokenizer(context_length=context_length)
+            except Exception:
+                _default = None
+        if _default is None:
+            _default = SimpleTokenizer(context_length=context_length)
     return _default

@@ -114,7 +114,8 @@ def test_score_candidates_vs_oracle(torch_mod, objective):
         assert rel_l2(feat[b], O.encode_text(w, cfg, cand[b, idx[b]][None], normalize=objective in ("sim", "dissim"))[0]) < 2e-3
 
 
-def test_attack_text_replays_reference_trace(torch_mod, golden_dir):
+@pytest.mark.parametrize("native", [False, True])
+def test_attack_text_replays_reference_trace(torch_mod, golden_dir, native):
     """Same numpy seed -> same candidate strings per stage and same adversarial sentences as the reference run
     (utils_attacks.py:297-393), on the tiny model; also with --constrain on the stub dictionary."""
     from leaf_amd import attacks
@@ -123,7 +124,11 @@ def test_attack_text_replays_reference_trace(torch_mod, golden_dir):
         trace = json.load(f)
     with open(os.path.join(golden_dir, "mutation_kat.json")) as f:
         stub = json.load(f)["stub_words"]
-    tok = SimpleTokenizer()
+    if native:
+        from leaf_amd.native_text import NativeTokenizer
+        tok = NativeTokenizer(n_threads=4)
+    else:
+        tok = SimpleTokenizer()
     m = _model("tiny-test-quickgelu", 12)
     attacks.set_dictionary(attacks.Dictionary(stub))
     for key, t in trace.items():

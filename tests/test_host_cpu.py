@@ -106,3 +106,38 @@ def test_product_has_no_oracle_or_cpu_fallback():
         from leaf_amd.model import LeafCLIPText, get_config
         with pytest.raises(_lib.LeafHipError):
             LeafCLIPText(get_config("tiny-test"), device="cpu")
+
+
+def test_native_tokenizer_and_stage_match_python(golden_dir):
+    """leaf_amd/csrc/host_text.cpp (C++ threads) == the Python tokenizer / mutation on known answers, random printable
+    ASCII, and inputs that must take the fallback (non-ASCII, entities)."""
+    import random
+    import string
+    from leaf_amd import attacks
+    from leaf_amd.native_text import NativeTokenizer
+    from leaf_amd.tokenizer import SimpleTokenizer
+    with open(os.path.join(golden_dir, "tokenizer_kat.json")) as f:
+        kat = json.load(f)
+    nt, pt = NativeTokenizer(n_threads=4), SimpleTokenizer()
+    toks, lens = nt.encode_batch_lens(kat["texts"])
+    assert np.array_equal(toks, np.array(kat["ids"], dtype=np.int32))
+    assert np.array_equal(lens, np.array(kat["ids"]).argmax(-1) + 1)
+    rnd = random.Random(0)
+    alphabet = string.ascii_letters + string.digits + string.punctuation + "     \t"
+    texts = ["".join(rnd.choice(alphabet) for _ in range(rnd.randint(0, 150))) for _ in range(500)]
+    texts += ["café au lait", "你好 world", "AT&amp;T &lt;b&gt;", "x <start_of_text> y", "tab\tsep\x1fend", "bell\x07char"]
+    assert np.array_equal(nt.encode_batch(texts), pt.encode_batch(texts))
+    # fused mutation + tokenisation of a search stage
+    sents = ["a photo of a cat", "I'm sure it's 42 degrees, isn't it?", "café au lait", "x", "AT&T tower", "under_score _"]
+    rho = 40
+    z = np.stack([np.array([rnd.randrange(2 * len(S) + 1) for _ in range(rho)]) for S in sents]).astype(np.int32)
+    c = np.array([[rnd.choice(attacks.DEFAULT_V) for _ in range(rho)] for _ in sents], dtype=np.int32)
+    c[:, :5] = ord(' ')
+    got, lens = nt.mutate_encode(sents, z, c, lambda b, r: attacks._apply_edit(sents[b], int(z[b, r]), int(c[b, r])))
+    V = attacks.DEFAULT_V
+    want_strings = [attacks.generate_sentence(S, int(z[b, r]), V.index(int(c[b, r])), V, 1, alternative=-1)
+                    for b, S in enumerate(sents) for r in range(rho)]
+    assert [attacks._apply_edit(S, int(z[b, r]), int(c[b, r])) for b, S in enumerate(sents) for r in range(rho)] == want_strings
+    want = pt.encode_batch(want_strings)
+    assert np.array_equal(got, want)
+    assert np.array_equal(lens, want.argmax(-1) + 1)
