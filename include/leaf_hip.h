@@ -53,7 +53,8 @@ int leaf_text_param_info(leaf_text_t h, int index, char* name, size_t name_len, 
                          int64_t* cols); /* cols = 0 for 1-D tensors */
 
 /* 16-bit operand copies of the GEMM weights.  w16_fwd: [N,K] as stored, forward dtype.  w16_bwd (may be
- * NULL): transposed [K,N] bf16 copies for the data-gradient GEMMs.  Call after every optimizer step. */
+ * NULL): transposed [K,N] copies for the data-gradient GEMMs in the gradient path's 16-bit type (fp16 with a
+ * per-step power-of-two loss scale by default, bf16 unscaled with LEAF_GRAD_DTYPE=bf16).  Call after every optimizer step. */
 size_t leaf_text_w16_bytes(leaf_text_t h);
 int leaf_text_pack_weights(leaf_text_t h, const float* params, void* w16_fwd, void* w16_bwd, leaf_stream_t s);
 

@@ -2,6 +2,7 @@
 // score_candidates.  Host orchestration only -- every device operation is a launch on the caller's stream.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "engine.h"
@@ -37,6 +38,10 @@ extern "C" int leaf_text_create(const leaf_text_cfg* cfg, int fwd_dtype, leaf_te
     h->cfg = *cfg;
     h->fwd_dtype = fwd_dtype;
     h->chunk = 4096;
+    {   // gradient path: fp16 + per-step power-of-two loss scale unless LEAF_GRAD_DTYPE=bf16
+        const char* e = getenv("LEAF_GRAD_DTYPE");
+        h->grad_dtype = (e && (e[0] == 'b' || e[0] == 'B')) ? LEAF_DTYPE_BF16 : LEAF_DTYPE_FP16;
+    }
     const int L = cfg->layers, D = cfg->embed_dim;
     size_t off = 0;
     auto add = [&](const std::string& name, int64_t rows, int64_t cols) {
@@ -114,9 +119,9 @@ extern "C" int leaf_text_pack_weights(leaf_text_t h, const float* params, void* 
             if (w16_fwd)
                 LEAF_TRY(leaf_launch_cast(params + t.src, (uint16_t*)w16_fwd + t.dst, (size_t)t.rows * t.cols,
                                           h->fwd_dtype, s));
-            if (w16_bwd)  // [rows,cols] fp32 -> [cols,rows] bf16
-                LEAF_TRY(leaf_launch_transpose_bf16(params + t.src, 2, (uint16_t*)w16_bwd + t.dst, t.rows, t.cols,
-                                                    t.cols, t.rows, s));
+            if (w16_bwd)  // [rows,cols] fp32 -> [cols,rows] in the gradient path's 16-bit type
+                LEAF_TRY(leaf_launch_transpose16(params + t.src, 2, (uint16_t*)w16_bwd + t.dst, h->grad_dtype, t.rows,
+                                                 t.cols, t.cols, t.rows, s));
         }
     }
     return 0;
@@ -131,11 +136,11 @@ std::vector<ProfRec> g_prof;
 }  // namespace
 
 int leaf_gemm(int dtype, int epi, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias,
-              void* aux, int M, int N, int K, int act, hipStream_t s, float beta, int aux_f16) {
+              void* aux, int M, int N, int K, int act, hipStream_t s, float beta, int aux_f16, const float* alpha) {
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.aux = aux;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
-    g.act = act; g.aux_f16 = aux_f16; g.beta = beta; g.stamps = nullptr;
+    g.act = act; g.aux_f16 = aux_f16; g.beta = beta; g.stamps = nullptr; g.alpha = alpha;
     if (!g_prof_on) return leaf_check(leaf_launch_gemm(g, dtype, epi, s), "gemm");
     ProfRec r;
     r.key = dtype * 8 + epi;
@@ -318,6 +323,6 @@ extern "C" int leaf_op_layernorm(const float* x, const float* g, const float* b,
 }
 extern "C" int leaf_op_attention_bwd(const void* qkv, int qkv_dtype, const void* dout_bf16, void* dqkv_bf16, int n_seq,
                                      int ctx, int heads, int width, leaf_stream_t s) {
-    return leaf_check(leaf_launch_attention_bwd(qkv, qkv_dtype, dout_bf16, dqkv_bf16, n_seq, RowMap{nullptr, 0, 0, ctx},
-                                                heads, width, (hipStream_t)s), "attention_bwd");
+    return leaf_check(leaf_launch_attention_bwd(qkv, qkv_dtype, dout_bf16, dqkv_bf16, LEAF_BF16, n_seq,
+                                                RowMap{nullptr, 0, 0, ctx}, heads, width, (hipStream_t)s), "attention_bwd");
 }

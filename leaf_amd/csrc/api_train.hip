@@ -50,6 +50,7 @@ struct BwdBuf {
     uint16_t* tA;     // [4d,rpad] bf16
     uint16_t* tB;     // [4d,rpad] bf16
     float* dout;      // [n,D]
+    float* gscale;    // {S, 1/S}
 };
 
 BwdBuf carve_bwd(const leaf_text* h, Carver& c, int n_seq, size_t rows) {
@@ -65,6 +66,7 @@ BwdBuf carve_bwd(const leaf_text* h, Carver& c, int n_seq, size_t rows) {
     b.tA = (uint16_t*)c.take(4 * d * rpad * 2);
     b.tB = (uint16_t*)c.take(4 * d * rpad * 2);
     b.dout = (float*)c.take((size_t)n_seq * h->cfg.embed_dim * 4);
+    b.gscale = (float*)c.take(256);
     return b;
 }
 
@@ -144,21 +146,24 @@ extern "C" int leaf_textfare_backward(leaf_text_t h, const float* P, const void*
     const int rpad = (int)align_up((size_t)rows, 64);
     const size_t rd = (size_t)rows * d;
     const int fk = h->fwd_dtype == LEAF_DTYPE_FP16 ? 1 : 0;  // source kind of stashed activations
+    const int gk = h->grad_dtype == LEAF_DTYPE_FP16 ? 1 : 0;  // 16-bit kind of the gradient path (kind == LEAF_* dtype id)
+    const float* inv_s = b.gscale + 1;
     const uint16_t* WT = (const uint16_t*)w16_bwd;
 
-    // dW[Nw,Kw] += dY^T X  via  NT GEMM on transposed bf16 copies
+    // dW[Nw,Kw] += (dY^T X) / S  via  NT GEMM on transposed 16-bit copies; alpha = 1/S read on the device
     auto wgrad = [&](const uint16_t* dY, int Nw, const void* X, int xkind, int Kw, float* dW) -> int {
-        LEAF_TRY(leaf_launch_transpose_bf16(dY, 0, b.tA, rows, Nw, Nw, rpad, s));
-        LEAF_TRY(leaf_launch_transpose_bf16(X, xkind, b.tB, rows, Kw, Kw, rpad, s));
-        return leaf_gemm(LEAF_BF16, EPI_STORE_F32, b.tA, rpad, b.tB, rpad, dW, Kw, nullptr, nullptr, Nw, Kw, rpad, 0, s, 1.0f);
+        LEAF_TRY(leaf_launch_transpose16(dY, gk, b.tA, gk, rows, Nw, Nw, rpad, s));
+        LEAF_TRY(leaf_launch_transpose16(X, xkind, b.tB, gk, rows, Kw, Kw, rpad, s));
+        return leaf_gemm(gk, EPI_STORE_F32, b.tA, rpad, b.tB, rpad, dW, Kw, nullptr, nullptr, Nw, Kw, rpad, 0, s, 1.0f, 0,
+                         inv_s);
     };
 
-    LEAF_TRY(leaf_launch_fare_loss(feat, anchor, n_seq, D, accum_scale, loss_out, b.dout, s));
+    LEAF_TRY(leaf_launch_fare_loss(feat, anchor, n_seq, D, accum_scale, loss_out, b.dout, b.gscale, gk == 1, s));
     LEAF_TRY(hipMemsetAsync(b.dx, 0, rd * 4, s));
     LEAF_TRY(leaf_launch_pool_project_bwd(b.dout, st.pooled, st.xin + (size_t)L * rd, st.eot, P + h->lnf_w, P + h->lnf_b,
                                           cf.ln_eps, P + h->text_proj, b.dx, G + h->text_proj, G + h->lnf_w,
-                                          G + h->lnf_b, n_seq, map, d, D, s));
-    LEAF_TRY(leaf_launch_f32_to_bf16_rows(b.dx, b.dx16, rd, s));
+                                          G + h->lnf_b, b.gscale, n_seq, map, d, D, s));
+    LEAF_TRY(leaf_launch_cast16(b.dx, 2, b.dx16, gk, rd, s));
 
     for (int l = L - 1; l >= 0; --l) {
         const LayerOff& o = h->layer[l];
@@ -167,28 +172,28 @@ extern "C" int leaf_textfare_backward(leaf_text_t h, const float* P, const void*
         const uint16_t* xn2 = st.xn2 + l * rd; const uint16_t* pre = st.pre + 4 * l * rd; const uint16_t* hh = st.hh + 4 * l * rd;
         // ---- MLP
         if (wgrad(b.dx16, d, hh, fk, 4 * d, G + o.proj_w)) return 1;
-        LEAF_TRY(leaf_launch_colsum(b.dx16, d, rows, d, G + o.proj_b, s));
-        if (leaf_gemm(LEAF_BF16, EPI_ACTGRAD_T, b.dx16, d, WT + h->w16_proj(l), d, b.big16, 4 * d, nullptr, (void*)pre, rows,
+        LEAF_TRY(leaf_launch_colsum(b.dx16, gk, b.gscale, d, rows, d, G + o.proj_b, s));
+        if (leaf_gemm(gk, EPI_ACTGRAD_T, b.dx16, d, WT + h->w16_proj(l), d, b.big16, 4 * d, nullptr, (void*)pre, rows,
                  4 * d, d, cf.activation, s, 0.f, fk)) return 1;
         if (wgrad(b.big16, 4 * d, xn2, fk, d, G + o.fc_w)) return 1;
-        LEAF_TRY(leaf_launch_colsum(b.big16, 4 * d, rows, 4 * d, G + o.fc_b, s));
-        if (leaf_gemm(LEAF_BF16, EPI_STORE_F32, b.big16, 4 * d, WT + h->w16_fc(l), 4 * d, b.dxn, d, nullptr, nullptr, rows, d,
+        LEAF_TRY(leaf_launch_colsum(b.big16, gk, b.gscale, 4 * d, rows, 4 * d, G + o.fc_b, s));
+        if (leaf_gemm(gk, EPI_STORE_F32, b.big16, 4 * d, WT + h->w16_fc(l), 4 * d, b.dxn, d, nullptr, nullptr, rows, d,
                  4 * d, 0, s)) return 1;
-        LEAF_TRY(leaf_launch_layernorm_bwd(b.dxn, x1, P + o.ln2_w, cf.ln_eps, b.dx, b.dx16, G + o.ln2_w, G + o.ln2_b,
-                                           rows, d, s));
+        LEAF_TRY(leaf_launch_layernorm_bwd(b.dxn, x1, P + o.ln2_w, cf.ln_eps, b.dx, b.dx16, gk, b.gscale, G + o.ln2_w,
+                                           G + o.ln2_b, rows, d, s));
         // ---- attention
         if (wgrad(b.dx16, d, ao, fk, d, G + o.out_w)) return 1;
-        LEAF_TRY(leaf_launch_colsum(b.dx16, d, rows, d, G + o.out_b, s));
-        if (leaf_gemm(LEAF_BF16, EPI_STORE_T, b.dx16, d, WT + h->w16_out(l), d, b.do16, d, nullptr, nullptr, rows, d, d, 0, s)) return 1;
-        LEAF_TRY(leaf_launch_attention_bwd(qkv, h->fwd_dtype, b.do16, b.dqkv, n_seq, map, cf.heads, d, s));
+        LEAF_TRY(leaf_launch_colsum(b.dx16, gk, b.gscale, d, rows, d, G + o.out_b, s));
+        if (leaf_gemm(gk, EPI_STORE_T, b.dx16, d, WT + h->w16_out(l), d, b.do16, d, nullptr, nullptr, rows, d, d, 0, s)) return 1;
+        LEAF_TRY(leaf_launch_attention_bwd(qkv, h->fwd_dtype, b.do16, b.dqkv, gk, n_seq, map, cf.heads, d, s));
         if (wgrad(b.dqkv, 3 * d, xn1, fk, d, G + o.qkv_w)) return 1;
-        LEAF_TRY(leaf_launch_colsum(b.dqkv, 3 * d, rows, 3 * d, G + o.qkv_b, s));
-        if (leaf_gemm(LEAF_BF16, EPI_STORE_F32, b.dqkv, 3 * d, WT + h->w16_qkv(l), 3 * d, b.dxn, d, nullptr, nullptr, rows, d,
+        LEAF_TRY(leaf_launch_colsum(b.dqkv, gk, b.gscale, 3 * d, rows, 3 * d, G + o.qkv_b, s));
+        if (leaf_gemm(gk, EPI_STORE_F32, b.dqkv, 3 * d, WT + h->w16_qkv(l), 3 * d, b.dxn, d, nullptr, nullptr, rows, d,
                  3 * d, 0, s)) return 1;
-        LEAF_TRY(leaf_launch_layernorm_bwd(b.dxn, xin, P + o.ln1_w, cf.ln_eps, b.dx, b.dx16, G + o.ln1_w, G + o.ln1_b,
-                                           rows, d, s));
+        LEAF_TRY(leaf_launch_layernorm_bwd(b.dxn, xin, P + o.ln1_w, cf.ln_eps, b.dx, b.dx16, gk, b.gscale, G + o.ln1_w,
+                                           G + o.ln1_b, rows, d, s));
     }
-    LEAF_TRY(leaf_launch_embed_bwd(b.dx, tokens, G + h->tok_emb, G + h->pos_emb, rows, n_seq, map, d, cf.vocab_size, s));
+    LEAF_TRY(leaf_launch_embed_bwd(b.dx, b.gscale, tokens, G + h->tok_emb, G + h->pos_emb, rows, n_seq, map, d, cf.vocab_size, s));
     return 0;
 }
 

@@ -21,6 +21,7 @@ struct leaf_text {
     leaf_text_cfg cfg;
     int fwd_dtype;
     int chunk;  // sequences per pass
+    int grad_dtype;  // 16-bit type of the gradient path: LEAF_F16 (loss-scaled, default) or LEAF_BF16
     std::vector<TensorInfo> tensors;
     std::vector<LayerOff> layer;
     size_t tok_emb, pos_emb, text_proj, lnf_w, lnf_b;
@@ -37,7 +38,8 @@ size_t leaf_train_ws_bytes(const leaf_text* h, int n_seq);  // api_train.hip
 // GEMM launch shared by both API files; when the profiler is armed (leaf_prof_begin) each launch is bracketed
 // by HIP events on its own stream and accounted under its epilogue id.
 int leaf_gemm(int dtype, int epi, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias,
-              void* aux, int M, int N, int K, int act, hipStream_t s, float beta = 0.f, int aux_f16 = 0);
+              void* aux, int M, int N, int K, int act, hipStream_t s, float beta = 0.f, int aux_f16 = 0,
+              const float* alpha = nullptr);
 void leaf_set_error(const char* fmt, ...);
 int leaf_check(hipError_t e, const char* what);
 

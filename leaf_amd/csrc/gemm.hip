@@ -28,6 +28,13 @@ __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + 
 template <class TT, int EPI, int NI, int NJ>
 __device__ __forceinline__ void epilogue_block(const GemmArgs& p, const int (&m)[NI], int nbase, const float4 (&bias)[NJ],
                                                f32x4 (&acc)[NI][NJ]) {
+    if (p.alpha) {   // gradient un-scaling (weight gradients of the fp16 loss-scaled backward)
+        const float al = *p.alpha;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] *= al;
+    }
     if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32) {
         float4 r[NI][NJ];
         const bool rd = (EPI == EPI_RESID_F32) || p.beta != 0.f;

@@ -180,6 +180,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_ring_kernel(GemmArgs p) {
     // ---------------- epilogue through this wave's private LDS slice (ring is idle after one more barrier)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    if (p.alpha) {   // gradient un-scaling (weight gradients of the fp16 loss-scaled backward)
+        const float al = *p.alpha;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] *= al;
+    }
     char* sl = smem + wid * SLICE;
     const int fq = lane >> 4;
     const int nb = n0 + wn * 64;          // first column of this wave's sub-tile

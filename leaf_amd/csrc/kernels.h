@@ -26,6 +26,7 @@ struct GemmArgs {
     int aux_f16;  // EPI_ACTGRAD_T: aux is fp16 (1) or bf16 (0)
     float beta;
     void* stamps; // diagnostic builds only (-DLEAF_GEMM_STAMPS)
+    const float* alpha;  // optional DEVICE scalar multiplying the accumulator (gradient un-scaling), or null
 };
 
 hipError_t leaf_launch_gemm(const GemmArgs& p, int dtype, int epi, hipStream_t s);
@@ -57,30 +58,32 @@ hipError_t leaf_launch_attention_fwd(const void* qkv, void* out, int n_seq, RowM
                                      hipStream_t s);
 
 // ---- training-only kernels (train.hip)
-// dst[c, r] = (bf16) src[r, c], zero padded to rpad columns.  src_kind: 0 bf16, 1 fp16, 2 fp32
-hipError_t leaf_launch_transpose_bf16(const void* src, int src_kind, void* dst, int rows, int cols, int ld_src,
-                                      int rpad, hipStream_t s);
-hipError_t leaf_launch_cast_bf16(const void* src, int src_kind, void* dst, size_t n, hipStream_t s);
-// loss = mean_b sum_j (anchor-feat)^2 ; dout = 2 (feat-anchor) / B * scale
+// dst[c, r] = (16-bit) src[r, c], zero padded to rpad columns.  kinds: 0 bf16, 1 fp16, 2 fp32 (source only)
+hipError_t leaf_launch_transpose16(const void* src, int src_kind, void* dst, int dst_kind, int rows, int cols, int ld_src,
+                                   int rpad, hipStream_t s);
+hipError_t leaf_launch_cast16(const void* src, int src_kind, void* dst, int dst_kind, size_t n, hipStream_t s);
+// loss = mean_b sum_j (anchor-feat)^2 ; dout = 2 (feat-anchor) / B * scale.  gscale[0] = S, gscale[1] = 1/S: the
+// power-of-two loss scale of the fp16 gradient path (S = 1 when use_scaling == 0), chosen so that max|dout| * S ~ 16.
 hipError_t leaf_launch_fare_loss(const float* feat, const float* anchor, int B, int D, float scale, float* loss,
-                                 float* dout, hipStream_t s);
+                                 float* dout, float* gscale, int use_scaling, hipStream_t s);
 // projection + pooling + final-LN backward: writes dx (fp32 [rows,d], zero except EOT rows), accumulates
 // dproj [d,D], dg/db of ln_final.
 hipError_t leaf_launch_pool_project_bwd(const float* dout, const float* pooled, const float* x, const int32_t* eot_idx,
                                         const float* g, const float* b, float eps, const float* proj, float* dx,
-                                        float* dproj, float* dg, float* db, int n_seq, RowMap map, int d, int D,
-                                        hipStream_t s);
-// dx_out = dx_in + LNbwd(dy, x, g);  dg += ..., db += ...;  dx16 = bf16(dx_out) (optional)
+                                        float* dproj, float* dg, float* db, const float* gscale, int n_seq, RowMap map,
+                                        int d, int D, hipStream_t s);
+// dx_out = dx_in + LNbwd(dy, x, g);  dg += .../S, db += .../S;  dx16 = 16-bit(dx_out) of kind gkind (optional)
 hipError_t leaf_launch_layernorm_bwd(const float* dy, const float* x, const float* g, float eps, float* dx_inout,
-                                     void* dx16, float* dg, float* db, int rows, int d, hipStream_t s);
-// dbias[n] += sum_r dy[r,n]   (dy bf16, row stride ld)
-hipError_t leaf_launch_colsum(const void* dy_bf16, int ld, int rows, int n, float* dbias, hipStream_t s);
-// attention backward: q,k,v from qkv (fwd dtype), dO bf16 [rows,d] -> dqkv bf16 [rows,3d]
-hipError_t leaf_launch_attention_bwd(const void* qkv, int qkv_dtype, const void* dout_bf16, void* dqkv_bf16, int n_seq,
-                                     RowMap map, int heads, int d, hipStream_t s);
+                                     void* dx16, int gkind, const float* gscale, float* dg, float* db, int rows, int d,
+                                     hipStream_t s);
+// dbias[n] += sum_r dy[r,n] / S   (dy 16-bit of kind gkind, row stride ld)
+hipError_t leaf_launch_colsum(const void* dy16, int gkind, const float* gscale, int ld, int rows, int n, float* dbias,
+                              hipStream_t s);
+// attention backward: q,k,v from qkv (fwd dtype), dO [rows,d] -> dqkv [rows,3d], both 16-bit of kind gkind
+hipError_t leaf_launch_attention_bwd(const void* qkv, int qkv_dtype, const void* dout16, void* dqkv16, int gkind,
+                                     int n_seq, RowMap map, int heads, int d, hipStream_t s);
 // dtok[tokens[r],:] += dx[r,:] ; dpos[r % ctx,:] += dx[r,:]
-hipError_t leaf_launch_embed_bwd(const float* dx, const int32_t* tokens, float* dtok, float* dpos, int rows, int n_seq,
-                                 RowMap map, int d, int vocab, hipStream_t s);
+hipError_t leaf_launch_embed_bwd(const float* dx, const float* gscale, const int32_t* tokens, float* dtok, float* dpos,
+                                 int rows, int n_seq, RowMap map, int d, int vocab, hipStream_t s);
 hipError_t leaf_launch_adamw(float* p, const float* g, float* m, float* v, size_t n, size_t n_decay, float lr,
                              float beta1, float beta2, float eps, float wd, int step, float grad_scale, hipStream_t s);
-hipError_t leaf_launch_f32_to_bf16_rows(const float* src, void* dst, size_t n, hipStream_t s);

@@ -1,7 +1,9 @@
 // Training-step kernels (TextFARE loss + backward + AdamW).  These run on B sequences once per outer
 // step (about 3/(2*rho*k+4) of the step's FLOPs -- SURVEY.md 8a row a8), so they are written for clarity
 // and coalesced access, with the heavy contractions (data/weight gradients) routed through the MFMA
-// GEMM in gemm.hip.  Gradient-side tensors are bf16 (fp32 exponent range, no loss scaling needed).
+// GEMM in gemm.hip.  Gradient-side 16-bit tensors are either fp16 with a per-step power-of-two loss scale S (default:
+// 11 significand bits, the reference's fp16-autocast + GradScaler regime; conversions saturate, never inf) or bf16
+// unscaled (S = 1).  gscale = {S, 1/S} lives on the device; parameter gradients are accumulated un-scaled in fp32.
 //
 // Reference: utils_AT.py:317-337 (loss, backward), train_AT_text_only.py:326-341 (AdamW groups).
 #include "common.h"
@@ -14,11 +16,21 @@ __device__ __forceinline__ float load_as_f32(const void* p, int kind, size_t i) 
     if (kind == 1) return F16::to_f32(((const _Float16*)p)[i]);
     return ((const float*)p)[i];
 }
+__device__ __forceinline__ void store16(void* p, int kind, size_t i, float v) {
+    if (kind == 0) ((__bf16*)p)[i] = BF16::from_f32(v);
+    else ((_Float16*)p)[i] = F16::from_f32(v);
+}
+__device__ __forceinline__ uint2 pack4k(int kind, float a, float b, float c, float d) {
+    return kind == 0 ? pack4<BF16>(a, b, c, d) : pack4<F16>(a, b, c, d);
+}
+__device__ __forceinline__ void unpack4k(int kind, uint2 u, float (&o)[4]) {
+    if (kind == 0) unpack4<BF16>(u, o); else unpack4<F16>(u, o);
+}
 
 // dst[c][r] = bf16(src[r][c]), r >= rows -> 0
-__global__ __launch_bounds__(256) void transpose_bf16_kernel(const void* __restrict__ src, int kind,
-                                                             __bf16* __restrict__ dst, int rows, int cols, int ld_src,
-                                                             int rpad) {
+__global__ __launch_bounds__(256) void transpose16_kernel(const void* __restrict__ src, int kind,
+                                                          void* __restrict__ dst, int dkind, int rows, int cols, int ld_src,
+                                                          int rpad) {
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
@@ -31,35 +43,52 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const void* __restr
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int c = c0 + ty + 8 * i, r = r0 + tx;
-        if (c < cols && r < rpad) dst[(size_t)c * rpad + r] = BF16::from_f32(tile[tx][ty + 8 * i]);
+        if (c < cols && r < rpad) store16(dst, dkind, (size_t)c * rpad + r, tile[tx][ty + 8 * i]);
     }
 }
 
-__global__ __launch_bounds__(256) void cast_bf16_kernel(const void* __restrict__ src, int kind, __bf16* __restrict__ dst,
-                                                        size_t n) {
+__global__ __launch_bounds__(256) void cast16_kernel(const void* __restrict__ src, int kind, void* __restrict__ dst,
+                                                     int dkind, size_t n) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * 256;
-    for (; i < n; i += stride) dst[i] = BF16::from_f32(load_as_f32(src, kind, i));
+    for (; i < n; i += stride) store16(dst, dkind, i, load_as_f32(src, kind, i));
 }
 
-// single block: loss = mean_b sum_j (a-f)^2 ; dout = 2 (f-a)/B * scale
+// single block: loss = mean_b sum_j (a-f)^2 ; dout = 2 (f-a)/B * scale ; gscale = {S, 1/S}
 __global__ __launch_bounds__(256) void fare_loss_kernel(const float* __restrict__ feat, const float* __restrict__ anchor,
                                                         int B, int D, float scale, float* __restrict__ loss,
-                                                        float* __restrict__ dout) {
-    __shared__ float red[4];
+                                                        float* __restrict__ dout, float* __restrict__ gscale,
+                                                        int use_scaling) {
+    __shared__ float red[8];
     const int tid = threadIdx.x;
     const size_t n = (size_t)B * D;
-    float s = 0.f;
+    float s = 0.f, amax = 0.f;
     const float k = 2.0f / (float)B * scale;
     for (size_t i = tid; i < n; i += 256) {
         float df = feat[i] - anchor[i];
         s = fmaf(df, df, s);
-        if (dout) dout[i] = k * df;
+        const float g = k * df;
+        amax = fmaxf(amax, fabsf(g));
+        if (dout) dout[i] = g;
     }
     s = wave_sum(s);
-    if ((tid & 63) == 0) red[tid >> 6] = s;
+    amax = wave_max(amax);
+    if ((tid & 63) == 0) { red[tid >> 6] = s; red[4 + (tid >> 6)] = amax; }
     __syncthreads();
-    if (tid == 0 && loss) *loss = (red[0] + red[1] + red[2] + red[3]) / (float)B;
+    if (tid == 0) {
+        if (loss) *loss = (red[0] + red[1] + red[2] + red[3]) / (float)B;
+        float S = 1.f;
+        const float a = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+        if (use_scaling && a > 0.f && a < 3.0e38f) {
+            int e;
+            frexpf(a, &e);                      // a = m * 2^e, m in [0.5, 1)
+            e = 4 - e;                          // bring max|dout| into [8, 16)
+            e = e > 40 ? 40 : (e < -40 ? -40 : e);
+            S = ldexpf(1.f, e);
+        }
+        gscale[0] = S;
+        gscale[1] = 1.f / S;
+    }
 }
 
 // dproj[k][j] += sum_b pooled[b][k] * dout[b][j]      grid = d blocks
@@ -77,8 +106,8 @@ __global__ __launch_bounds__(256) void proj_wgrad_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ x,
                                                        const int32_t* __restrict__ eot_idx, const float* __restrict__ g,
                                                        float eps, const float* __restrict__ proj, float* __restrict__ dx,
-                                                       float* __restrict__ dg, float* __restrict__ db, RowMap map, int d,
-                                                       int D) {
+                                                       float* __restrict__ dg, float* __restrict__ db,
+                                                       const float* __restrict__ gscale, RowMap map, int d, int D) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sdo = (float*)smem;   // [D]
     float* sdp = sdo + D;        // [d] dpooled
@@ -123,7 +152,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__
     const float mean2 = (red[4] + red[5] + red[6] + red[7]) / (float)d;
     for (int c = tid; c < d; c += 256) {
         float xh = (xr[c] - mu) * rstd, dy = sdp[c], dxh = dy * g[c];
-        dx[row * d + c] = rstd * (dxh - mean1 - xh * mean2);
+        dx[row * d + c] = rstd * (dxh - mean1 - xh * mean2) * gscale[0];   // the gradient stream carries the loss scale
         atomicAdd(dg + c, dy * xh);
         atomicAdd(db + c, dy);
     }
@@ -134,8 +163,8 @@ constexpr int MAXCH = 8;
 // grid-stride over rows, one wave per row; per-lane column partials for dg/db reduced at the end
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ g, float eps, float* __restrict__ dx,
-                                                     __bf16* __restrict__ dx16, float* __restrict__ dg,
-                                                     float* __restrict__ db, int rows, int d) {
+                                                     void* __restrict__ dx16, int gkind, const float* __restrict__ gscale,
+                                                     float* __restrict__ dg, float* __restrict__ db, int rows, int d) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int nq = d >> 2;
     float4 pg[MAXCH], pb[MAXCH], gg[MAXCH];
@@ -194,7 +223,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                 o.x += rstd * (dv[i].x - m1 - xv[i].x * m2); o.y += rstd * (dv[i].y - m1 - xv[i].y * m2);
                 o.z += rstd * (dv[i].z - m1 - xv[i].z * m2); o.w += rstd * (dv[i].w - m1 - xv[i].w * m2);
                 *(float4*)(dxr + 4 * c) = o;
-                if (dx16) *(uint2*)((u16*)dx16 + (size_t)row * d + 4 * c) = pack4<BF16>(o.x, o.y, o.z, o.w);
+                if (dx16) *(uint2*)((u16*)dx16 + (size_t)row * d + 4 * c) = pack4k(gkind, o.x, o.y, o.z, o.w);
             }
         }
     }
@@ -212,33 +241,34 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         float4 a = red[(0 * 2 + which) * nq + cc], b1 = red[(1 * 2 + which) * nq + cc];
         float4 b2 = red[(2 * 2 + which) * nq + cc], b3 = red[(3 * 2 + which) * nq + cc];
         float* dst = (which ? db : dg) + 4 * cc;
-        atomicAdd(dst + 0, (a.x + b1.x) + (b2.x + b3.x)); atomicAdd(dst + 1, (a.y + b1.y) + (b2.y + b3.y));
-        atomicAdd(dst + 2, (a.z + b1.z) + (b2.z + b3.z)); atomicAdd(dst + 3, (a.w + b1.w) + (b2.w + b3.w));
+        const float inv = gscale[1];
+        atomicAdd(dst + 0, ((a.x + b1.x) + (b2.x + b3.x)) * inv); atomicAdd(dst + 1, ((a.y + b1.y) + (b2.y + b3.y)) * inv);
+        atomicAdd(dst + 2, ((a.z + b1.z) + (b2.z + b3.z)) * inv); atomicAdd(dst + 3, ((a.w + b1.w) + (b2.w + b3.w)) * inv);
     }
 }
 
 // dbias[n] += sum_r dy[r][n]; thread owns 4 columns, waves/blocks split rows
-__global__ __launch_bounds__(256) void colsum_kernel(const u16* __restrict__ dy, int ld, int rows, int n,
-                                                     float* __restrict__ dbias) {
+__global__ __launch_bounds__(256) void colsum_kernel(const u16* __restrict__ dy, int gkind, const float* __restrict__ gscale,
+                                                     int ld, int rows, int n, float* __restrict__ dbias) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int c = (blockIdx.x * 64 + lane) * 4;
     if (c >= n) return;
     float a[4] = {0.f, 0.f, 0.f, 0.f};
     for (int r = blockIdx.y * 4 + wid; r < rows; r += gridDim.y * 4) {
         float v[4];
-        unpack4<BF16>(*(const uint2*)(dy + (size_t)r * ld + c), v);
+        unpack4k(gkind, *(const uint2*)(dy + (size_t)r * ld + c), v);
         a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) atomicAdd(dbias + c + e, a[e]);
+    for (int e = 0; e < 4; ++e) atomicAdd(dbias + c + e, a[e] * gscale[1]);
 }
 
 // ---------------------------------------------------------------- attention backward (one block per seq x head)
 constexpr int HD = 64, HP = 65;
 
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const u16* __restrict__ qkv, int qkv_f16,
-                                                       const u16* __restrict__ dO, u16* __restrict__ dqkv, RowMap map,
-                                                       int heads, int d) {
+                                                       const u16* __restrict__ dO, u16* __restrict__ dqkv, int gkind,
+                                                       RowMap map, int heads, int d) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int n = blockIdx.x / heads, h = blockIdx.x % heads;
     const int ctx = seq_len(map, map.s0 + n);
@@ -257,7 +287,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const u16* __restrict__ q
         sq[r * HP + c] = load_as_f32(qkv, qkv_f16 ? 1 : 0, o);
         sk[r * HP + c] = load_as_f32(qkv, qkv_f16 ? 1 : 0, o + d);
         sv[r * HP + c] = load_as_f32(qkv, qkv_f16 ? 1 : 0, o + 2 * d);
-        sdo[r * HP + c] = load_as_f32(dO, 0, (row0 + r) * d + h * HD + c);
+        sdo[r * HP + c] = load_as_f32(dO, gkind, (row0 + r) * d + h * HD + c);
     }
     __syncthreads();
     // P rows (softmax of causal scores) and dS rows, one wave per query row
@@ -308,31 +338,32 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const u16* __restrict__ q
             dv = fmaf(sp[i * PS + r], sdo[i * HP + c], dv);
         }
         const size_t o = (row0 + r) * ld + h * HD + c;
-        ((__bf16*)dqkv)[o] = BF16::from_f32(dq);
-        ((__bf16*)dqkv)[o + d] = BF16::from_f32(dk);
-        ((__bf16*)dqkv)[o + 2 * d] = BF16::from_f32(dv);
+        store16(dqkv, gkind, o, dq);
+        store16(dqkv, gkind, o + d, dk);
+        store16(dqkv, gkind, o + 2 * d, dv);
     }
 }
 
 // dpos[p][:] += sum_n dx[n*ctx+p][:]   (grid = ctx) ; dtok via atomics (grid-stride over rows)
-__global__ __launch_bounds__(256) void pos_bwd_kernel(const float* __restrict__ dx, float* __restrict__ dpos, int n_seq,
-                                                      RowMap map, int d) {
+__global__ __launch_bounds__(256) void pos_bwd_kernel(const float* __restrict__ dx, const float* __restrict__ gscale,
+                                                      float* __restrict__ dpos, int n_seq, RowMap map, int d) {
     const int p = blockIdx.x;
     for (int c = threadIdx.x; c < d; c += 256) {
         float s = 0.f;
         for (int n = 0; n < n_seq; ++n)
             if (p < seq_len(map, map.s0 + n)) s += dx[((size_t)seq_row(map, map.s0 + n) + p) * d + c];
-        dpos[(size_t)p * d + c] += s;
+        dpos[(size_t)p * d + c] += s * gscale[1];
     }
 }
-__global__ __launch_bounds__(256) void tok_bwd_kernel(const float* __restrict__ dx, const int32_t* __restrict__ tokens,
-                                                      float* __restrict__ dtok, int rows, int n_seq, RowMap map, int d,
-                                                      int vocab) {
+__global__ __launch_bounds__(256) void tok_bwd_kernel(const float* __restrict__ dx, const float* __restrict__ gscale,
+                                                      const int32_t* __restrict__ tokens, float* __restrict__ dtok, int rows,
+                                                      int n_seq, RowMap map, int d, int vocab) {
     const int row = blockIdx.x;
     const int sq = seq_of_row(map, row, n_seq);
     int tok = tokens[(size_t)sq * map.ctx + (row - seq_row(map, sq))];
     tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
-    for (int c = threadIdx.x; c < d; c += 256) atomicAdd(dtok + (size_t)tok * d + c, dx[(size_t)row * d + c]);
+    const float inv = gscale[1];
+    for (int c = threadIdx.x; c < d; c += 256) atomicAdd(dtok + (size_t)tok * d + c, dx[(size_t)row * d + c] * inv);
 }
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -360,68 +391,66 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 
 }  // namespace
 
-hipError_t leaf_launch_transpose_bf16(const void* src, int src_kind, void* dst, int rows, int cols, int ld_src,
-                                      int rpad, hipStream_t s) {
+hipError_t leaf_launch_transpose16(const void* src, int src_kind, void* dst, int dst_kind, int rows, int cols, int ld_src,
+                                   int rpad, hipStream_t s) {
     dim3 grid((cols + 31) / 32, (rpad + 31) / 32);
-    hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, s, src, src_kind, (__bf16*)dst, rows, cols, ld_src,
-                       rpad);
+    hipLaunchKernelGGL(transpose16_kernel, grid, dim3(256), 0, s, src, src_kind, dst, dst_kind, rows, cols, ld_src, rpad);
     return hipGetLastError();
 }
 
-hipError_t leaf_launch_cast_bf16(const void* src, int src_kind, void* dst, size_t n, hipStream_t s) {
+hipError_t leaf_launch_cast16(const void* src, int src_kind, void* dst, int dst_kind, size_t n, hipStream_t s) {
     if (!n) return hipSuccess;
     size_t nb = (n + 255) / 256;
-    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), 0, s, src, src_kind,
-                       (__bf16*)dst, n);
+    hipLaunchKernelGGL(cast16_kernel, dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), 0, s, src, src_kind, dst,
+                       dst_kind, n);
     return hipGetLastError();
-}
-
-hipError_t leaf_launch_f32_to_bf16_rows(const float* src, void* dst, size_t n, hipStream_t s) {
-    return leaf_launch_cast_bf16(src, 2, dst, n, s);
 }
 
 hipError_t leaf_launch_fare_loss(const float* feat, const float* anchor, int B, int D, float scale, float* loss,
-                                 float* dout, hipStream_t s) {
-    hipLaunchKernelGGL(fare_loss_kernel, dim3(1), dim3(256), 0, s, feat, anchor, B, D, scale, loss, dout);
+                                 float* dout, float* gscale, int use_scaling, hipStream_t s) {
+    hipLaunchKernelGGL(fare_loss_kernel, dim3(1), dim3(256), 0, s, feat, anchor, B, D, scale, loss, dout, gscale,
+                       use_scaling);
     return hipGetLastError();
 }
 
 hipError_t leaf_launch_pool_project_bwd(const float* dout, const float* pooled, const float* x, const int32_t* eot_idx,
                                         const float* g, const float* b, float eps, const float* proj, float* dx,
-                                        float* dproj, float* dg, float* db, int n_seq, RowMap map, int d, int D,
-                                        hipStream_t s) {
+                                        float* dproj, float* dg, float* db, const float* gscale, int n_seq, RowMap map,
+                                        int d, int D, hipStream_t s) {
     (void)b;
     hipLaunchKernelGGL(proj_wgrad_kernel, dim3(d), dim3(256), 0, s, pooled, dout, dproj, n_seq, d, D);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     size_t lds = (size_t)(D + d + 8) * sizeof(float);
-    hipLaunchKernelGGL(pool_bwd_kernel, dim3(n_seq), dim3(256), lds, s, dout, x, eot_idx, g, eps, proj, dx, dg, db, map,
-                       d, D);
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3(n_seq), dim3(256), lds, s, dout, x, eot_idx, g, eps, proj, dx, dg, db, gscale,
+                       map, d, D);
     return hipGetLastError();
 }
 
 hipError_t leaf_launch_layernorm_bwd(const float* dy, const float* x, const float* g, float eps, float* dx_inout,
-                                     void* dx16, float* dg, float* db, int rows, int d, hipStream_t s) {
+                                     void* dx16, int gkind, const float* gscale, float* dg, float* db, int rows, int d,
+                                     hipStream_t s) {
     if (d % 4 || d > 256 * MAXCH) return hipErrorInvalidValue;
     int grid = (rows + 15) / 16;
     if (grid > 256) grid = 256;
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), (size_t)8 * d * sizeof(float), s, dy, x, g, eps, dx_inout,
-                       (__bf16*)dx16, dg, db, rows, d);
+                       dx16, gkind, gscale, dg, db, rows, d);
     return hipGetLastError();
 }
 
-hipError_t leaf_launch_colsum(const void* dy_bf16, int ld, int rows, int n, float* dbias, hipStream_t s) {
+hipError_t leaf_launch_colsum(const void* dy16, int gkind, const float* gscale, int ld, int rows, int n, float* dbias,
+                              hipStream_t s) {
     if (n % 4 || ld % 4) return hipErrorInvalidValue;
     int ry = (rows + 63) / 64;
     if (ry > 64) ry = 64;
     if (ry < 1) ry = 1;
-    hipLaunchKernelGGL(colsum_kernel, dim3((n + 255) / 256, ry), dim3(256), 0, s, (const u16*)dy_bf16, ld, rows, n,
-                       dbias);
+    hipLaunchKernelGGL(colsum_kernel, dim3((n + 255) / 256, ry), dim3(256), 0, s, (const u16*)dy16, gkind, gscale, ld,
+                       rows, n, dbias);
     return hipGetLastError();
 }
 
-hipError_t leaf_launch_attention_bwd(const void* qkv, int qkv_dtype, const void* dout_bf16, void* dqkv_bf16, int n_seq,
-                                     RowMap map, int heads, int d, hipStream_t s) {
+hipError_t leaf_launch_attention_bwd(const void* qkv, int qkv_dtype, const void* dout16, void* dqkv16, int gkind,
+                                     int n_seq, RowMap map, int heads, int d, hipStream_t s) {
     const int ctx = map.ctx;
     if (d != heads * HD || ctx > 128) return hipErrorInvalidValue;
     size_t lds = ((size_t)4 * ctx * HP + (size_t)2 * ctx * (ctx + 1)) * sizeof(float);
@@ -432,16 +461,16 @@ hipError_t leaf_launch_attention_bwd(const void* qkv, int qkv_dtype, const void*
     }
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     hipLaunchKernelGGL(attn_bwd_kernel, dim3(n_seq * heads), dim3(256), lds, s, (const u16*)qkv,
-                       qkv_dtype == LEAF_F16 ? 1 : 0, (const u16*)dout_bf16, (u16*)dqkv_bf16, map, heads, d);
+                       qkv_dtype == LEAF_F16 ? 1 : 0, (const u16*)dout16, (u16*)dqkv16, gkind, map, heads, d);
     return hipGetLastError();
 }
 
-hipError_t leaf_launch_embed_bwd(const float* dx, const int32_t* tokens, float* dtok, float* dpos, int rows, int n_seq,
-                                 RowMap map, int d, int vocab, hipStream_t s) {
-    hipLaunchKernelGGL(pos_bwd_kernel, dim3(map.ctx), dim3(256), 0, s, dx, dpos, n_seq, map, d);
+hipError_t leaf_launch_embed_bwd(const float* dx, const float* gscale, const int32_t* tokens, float* dtok, float* dpos,
+                                 int rows, int n_seq, RowMap map, int d, int vocab, hipStream_t s) {
+    hipLaunchKernelGGL(pos_bwd_kernel, dim3(map.ctx), dim3(256), 0, s, dx, gscale, dpos, n_seq, map, d);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(tok_bwd_kernel, dim3(rows), dim3(256), 0, s, dx, tokens, dtok, rows, n_seq, map, d, vocab);
+    hipLaunchKernelGGL(tok_bwd_kernel, dim3(rows), dim3(256), 0, s, dx, gscale, tokens, dtok, rows, n_seq, map, d, vocab);
     return hipGetLastError();
 }
 

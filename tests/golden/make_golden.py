@@ -137,7 +137,7 @@ def main():
             out = model.encode_text(torch.from_numpy(full)).numpy()
             outn = model.encode_text(torch.from_numpy(full), normalize=True).numpy()
         # loss + grads + AdamW step (a8, a9)
-        anchor = (out[:8] + 0.05 * np.random.default_rng(5).standard_normal(out[:8].shape)).astype(np.float32)
+        anchor = (out[:8] + 0.5 * np.random.default_rng(5).standard_normal(out[:8].shape)).astype(np.float32)  # ||f-a|| ~ ||f||: well-conditioned gradient comparison
         model.train()
         for p_ in model.visual.parameters():
             p_.requires_grad = False

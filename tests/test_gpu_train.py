@@ -41,10 +41,13 @@ def test_loss_and_grads_vs_golden(torch_mod, golden_dir, name, seed, model, qg):
         else:
             r = rel_l2(g, z["g:" + k])
         worst[k] = r
-    bad = {k: v for k, v in worst.items() if v > 6e-2}
+    tol = 1.2e-2 if os.environ.get("LEAF_GRAD_DTYPE", "").lower().startswith("b") else 6e-3
+    bad = {k: v for k, v in worst.items() if v > tol}
     print("max grad rel-L2", max(worst.values()))
-    # P4: bf16 gradient operands (8 significand bits): measured per-tensor rel-L2 3-4e-2 vs the fp32 reference;
-    # bound 6e-2 (an fp16 + loss-scale gradient path is the planned tightening)
+    # P4: default gradient path = fp16 operands + per-step power-of-two loss scale (11 significand bits, the
+    # reference's fp16-autocast regime): measured per-tensor rel-L2 3.5-4.0e-3 vs the fp32 reference (bound 6e-3);
+    # bf16 (LEAF_GRAD_DTYPE=bf16) measures 7-8e-3 (bound 1.2e-2).  The fixture's anchor sits ~||f|| away from f so the
+    # forward's own 1e-3 error is not amplified by cancellation in (f - anchor).
     assert not bad, bad
     # accumulate: a second backward doubles the gradient
     g1 = m.grads.clone()

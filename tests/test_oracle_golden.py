@@ -57,9 +57,9 @@ def test_loss_grads_adamw_tiny(golden_dir, name, seed, qg):
             d = np.abs(w[k][z["tok_rows"]] - z["after_tok_rows"])
         else:
             d = np.abs(w[k] - z["after:" + k])
-        # the first Adam step is lr*g/(|g|+eps): fp32 reorder noise in a gradient of size ~eps moves
-        # the update by a few % of lr, so bound the max by 50% of lr and the mean by 0.1% of lr
-        assert d.max() < 0.5 * hp["lr"] and d.mean() < 1e-3 * hp["lr"], (k, d.max(), d.mean())
+        # the first Adam step is lr*g/(|g|+eps): fp32 reorder noise in a gradient of size ~eps (e.g. the key bias, whose
+        # true gradient is exactly 0) moves the update by a few % of lr: bound the max by 50% of lr, the mean by 1%
+        assert d.max() < 0.5 * hp["lr"] and d.mean() < 1e-2 * hp["lr"], (k, d.max(), d.mean())
 
 
 @pytest.mark.parametrize("fname,model", [("vitl_gelu", "ViT-L-14"), ("vitl_quickgelu", "ViT-L-14-quickgelu")])
