@@ -180,13 +180,28 @@ def attack_text_leaf(model, tokenizer, sentences, anchor_features, device=None, 
         anchor_features /= anchor_features.norm(dim=-1, keepdim=True)   # in place, as the reference does
     best_feat = None
     Varr = np.asarray(V, dtype=np.int32)
+    reuse = hasattr(model, "encode_text_kv") and getattr(model, "trim_rows", False)
+
+    def prefix_lens(toks, base):
+        """leading positions where a candidate's ids equal its clean caption's (>= 1: SOT)"""
+        neq = toks.reshape(B, n, -1) != base[:, None, :]
+        first = neq.argmax(-1)
+        first[~neq.any(-1)] = toks.shape[-1]
+        return first.reshape(-1)
+
     for _ in range(k):
+        kv = base = None
+        if reuse:   # clean captions once per edit: their per-layer K/V serve both stages' candidates
+            base = tokenizer.encode_batch(sentences)
+            kv = model.encode_text_kv(base)
         # stage 1: rho random positions, insert / replace-with / delete a space
         z = np.stack([np.random.choice(range(2 * len(S) + 1), size=n, replace=n > 2 * len(S) + 1) for S in sentences]).astype(np.int32)
         c = np.full((B, n), ord(' '), dtype=np.int32)
         positions = z.copy()            # the reference reads the winner's position from the sampled ones (:351-353)
         toks, lens = _stage_candidates(tokenizer, sentences, z, c, constrain, return_trace)
-        ids_best, _ = model.score_candidates(toks, anchor_features, n, objective, want_features=False, seq_lens=lens)
+        pl = prefix_lens(toks, base) if reuse else None
+        ids_best, _ = model.score_candidates(toks, anchor_features, n, objective, want_features=False, seq_lens=lens,
+                                             prefix_lens=pl, kv=kv)
         ids_best = ids_best.cpu().numpy()
         best_pos = positions[np.arange(B), ids_best]
         # stage 2: rho random characters at the chosen position
@@ -194,7 +209,9 @@ def attack_text_leaf(model, tokenizer, sentences, anchor_features, device=None, 
         c = Varr[u]
         z = np.repeat(best_pos[:, None], n, axis=1).astype(np.int32)
         toks, lens = _stage_candidates(tokenizer, sentences, z, c, constrain, return_trace)
-        ids_best, best_feat = model.score_candidates(toks, anchor_features, n, objective, want_features=True, seq_lens=lens)
+        pl = prefix_lens(toks, base) if reuse else None
+        ids_best, best_feat = model.score_candidates(toks, anchor_features, n, objective, want_features=True, seq_lens=lens,
+                                                     prefix_lens=pl, kv=kv)
         ids_best = ids_best.cpu().numpy()
         sentences = [_apply_edit(S, int(z[b, ids_best[b]]), int(c[b, ids_best[b]])) for b, S in enumerate(sentences)]
         if debug:

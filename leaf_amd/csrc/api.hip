@@ -204,8 +204,17 @@ FwdBuf carve_fwd(const leaf_text* h, Carver& c, int cs) {
 }
 
 // run the layer stack on `cs` sequences (rows = their packed row count); features -> out [cs, D]
+// kv_write: per-layer qkv of this (single) chunk is produced INTO the cache (base captions, stride kv_stride elements per
+// layer).  kv_read: prefix mode, attention reads the prefix K/V of layer l from kv_read + l * kv_stride.
+struct KvPlan {
+    uint16_t* kv_write = nullptr;
+    const uint16_t* kv_read = nullptr;
+    size_t kv_stride = 0;
+};
+
 int forward_chunk(const leaf_text* h, const float* P, const uint16_t* W, const int32_t* tokens, int cs, int rows,
-                  RowMap map, float* out, int normalize, const FwdBuf& b, hipStream_t s) {
+                  RowMap map, float* out, int normalize, const FwdBuf& b_in, hipStream_t s, const KvPlan& kv = KvPlan()) {
+    FwdBuf b = b_in;
     const leaf_text_cfg& c = h->cfg;
     const int d = c.width, dt = h->fwd_dtype;
     const LayerOff& o0 = h->layer[0];
@@ -214,9 +223,11 @@ int forward_chunk(const leaf_text* h, const float* P, const uint16_t* W, const i
     for (int l = 0; l < c.layers; ++l) {
         const LayerOff& o = h->layer[l];
         if (l > 0) LEAF_TRY(leaf_launch_layernorm(b.x, P + o.ln1_w, P + o.ln1_b, c.ln_eps, b.a, rows, d, dt, s));
+        if (kv.kv_write) b.qkv = kv.kv_write + (size_t)l * kv.kv_stride;
         if (leaf_gemm(dt, EPI_STORE_T, b.a, d, W + h->w16_qkv(l), d, b.qkv, 3 * d, P + o.qkv_b, nullptr, rows, 3 * d, d, 0, s))
             return 1;
-        LEAF_TRY(leaf_launch_attention_fwd(b.qkv, b.a, cs, map, c.heads, d, dt, s));
+        LEAF_TRY(leaf_launch_attention_fwd(b.qkv, kv.kv_read ? kv.kv_read + (size_t)l * kv.kv_stride : nullptr, b.a, cs, map,
+                                           c.heads, d, dt, s));
         if (leaf_gemm(dt, EPI_RESID_F32, b.a, d, W + h->w16_out(l), d, b.x, d, P + o.out_b, nullptr, rows, d, d, 0, s))
             return 1;
         LEAF_TRY(leaf_launch_layernorm(b.x, P + o.ln2_w, P + o.ln2_b, c.ln_eps, b.a, rows, d, dt, s));
@@ -227,15 +238,25 @@ int forward_chunk(const leaf_text* h, const float* P, const uint16_t* W, const i
                       4 * d, 0, s))
             return 1;
     }
-    LEAF_TRY(leaf_launch_pool_project(b.x, tokens, P + h->lnf_w, P + h->lnf_b, c.ln_eps, P + h->text_proj, out, nullptr,
-                                      nullptr, cs, map, d, c.embed_dim, normalize, s));
+    if (out)
+        LEAF_TRY(leaf_launch_pool_project(b.x, tokens, P + h->lnf_w, P + h->lnf_b, c.ln_eps, P + h->text_proj, out, nullptr,
+                                          nullptr, cs, map, d, c.embed_dim, normalize, s));
     return 0;
 }
 
 // Sequences are processed in chunks bounded by a ROW budget (chunk * ctx rows): with EOT-trimmed (packed) rows a
 // chunk holds more sequences, so the GEMMs keep their M.  lens == nullptr -> dense (every sequence ctx rows).
+struct PrefixPlan {   // prefix reuse: see RowMap in common.h
+    const int32_t* prefix_dev = nullptr;
+    const int32_t* base_cu_dev = nullptr;
+    const uint16_t* kv = nullptr;
+    size_t kv_stride = 0;
+    int group = 1;
+};
+
 int forward_all(const leaf_text* h, const float* P, const void* W, const int32_t* tokens, const int32_t* lens,
-                const int32_t* cu_dev, int n_seq, float* out, int normalize, Carver& c, hipStream_t s) {
+                const int32_t* cu_dev, int n_seq, float* out, int normalize, Carver& c, hipStream_t s,
+                const PrefixPlan& pp = PrefixPlan()) {
     const int ctx = h->cfg.context_length;
     if ((lens == nullptr) != (cu_dev == nullptr)) { leaf_set_error("seq_lens (host) and cu_rows (device) go together"); return 1; }
     const size_t budget = (size_t)(n_seq < h->chunk ? n_seq : h->chunk) * ctx;
@@ -253,9 +274,13 @@ int forward_all(const leaf_text* h, const float* P, const void* W, const int32_t
             rows += L;
             ++s1;
         }
-        RowMap map{cu_dev, s0, (int)row0, ctx};
+        RowMap map{cu_dev, s0, (int)row0, ctx, pp.prefix_dev, pp.base_cu_dev, pp.group};
+        KvPlan kv;
+        kv.kv_read = pp.kv;
+        kv.kv_stride = pp.kv_stride;
+        if (s1 == s0) { leaf_set_error("a sequence does not fit the row budget"); return 1; }
         if (forward_chunk(h, P, (const uint16_t*)W, tokens, s1 - s0, (int)rows, map, out + (size_t)s0 * h->cfg.embed_dim,
-                          normalize, b, s))
+                          normalize, b, s, kv))
             return 1;
         s0 = s1;
         row0 += rows;
@@ -301,6 +326,60 @@ extern "C" int leaf_score_candidates(leaf_text_t h, const float* params, const v
     return 0;
 }
 
+// ------------------------------------------------------------------ prefix reuse
+extern "C" size_t leaf_text_kv_bytes(leaf_text_t h, int n_seq) {
+    if (!h || n_seq < 1) return 0;
+    return (size_t)h->cfg.layers * n_seq * h->cfg.context_length * 3 * h->cfg.width * 2;
+}
+
+extern "C" int leaf_text_forward_kv(leaf_text_t h, const float* params, const void* w16_fwd, const int32_t* tokens,
+                                    const int32_t* seq_lens, const int32_t* cu_rows, int n_seq, float* out,
+                                    int normalize, void* kv, size_t kv_bytes, void* ws, size_t ws_bytes, leaf_stream_t s) {
+    if (!h || !params || !w16_fwd || !tokens || !kv || !ws || n_seq < 1) { leaf_set_error("null/invalid argument"); return 1; }
+    if ((seq_lens == nullptr) != (cu_rows == nullptr)) { leaf_set_error("seq_lens (host) and cu_rows (device) go together"); return 1; }
+    const int ctx = h->cfg.context_length;
+    size_t rows = 0;
+    for (int i = 0; i < n_seq; ++i) rows += seq_lens ? seq_lens[i] : ctx;
+    const size_t stride = rows * 3 * h->cfg.width;
+    if (stride * 2 * h->cfg.layers > kv_bytes) { leaf_set_error("kv cache too small"); return 1; }
+    if (rows > (size_t)h->chunk * ctx) { leaf_set_error("forward_kv needs the captions to fit one chunk (%zu rows)", rows); return 1; }
+    Carver c(ws, ws_bytes);
+    FwdBuf b = carve_fwd(h, c, (int)((rows + ctx - 1) / ctx));
+    if (!c.ok()) { leaf_set_error("workspace too small: need %zu bytes, have %zu", c.off, c.cap); return 1; }
+    KvPlan kvp;
+    kvp.kv_write = (uint16_t*)kv;
+    kvp.kv_stride = stride;
+    RowMap map{cu_rows, 0, 0, ctx, nullptr, nullptr, 1};
+    return forward_chunk(h, params, (const uint16_t*)w16_fwd, tokens, n_seq, (int)rows, map, out, normalize, b,
+                         (hipStream_t)s, kvp);
+}
+
+extern "C" int leaf_score_candidates_prefix(leaf_text_t h, const float* params, const void* w16_fwd, const int32_t* tokens,
+                                            const int32_t* suffix_lens, const int32_t* cu_suffix, const int32_t* prefix,
+                                            const int32_t* base_cu, const void* kv, size_t base_rows, const float* anchor,
+                                            int B, int rho, int objective, int32_t* best_idx, float* best_feat, float* loss,
+                                            void* ws, size_t ws_bytes, leaf_stream_t s) {
+    if (!h || !params || !w16_fwd || !tokens || !suffix_lens || !cu_suffix || !prefix || !base_cu || !kv || !anchor ||
+        !best_idx || !ws || B < 1 || rho < 1) {
+        leaf_set_error("null/invalid argument");
+        return 1;
+    }
+    if (objective < 0 || objective > 3) { leaf_set_error("unknown objective %d", objective); return 1; }
+    Carver c(ws, ws_bytes);
+    const int n_seq = B * rho;
+    float* feat = (float*)c.take((size_t)n_seq * h->cfg.embed_dim * 4);
+    const int normalize = (objective == LEAF_OBJ_SIM || objective == LEAF_OBJ_DISSIM);
+    PrefixPlan pp;
+    pp.prefix_dev = prefix;
+    pp.base_cu_dev = base_cu;
+    pp.kv = (const uint16_t*)kv;
+    pp.kv_stride = base_rows * 3 * h->cfg.width;
+    pp.group = rho;
+    if (forward_all(h, params, w16_fwd, tokens, suffix_lens, cu_suffix, n_seq, feat, normalize, c, (hipStream_t)s, pp)) return 1;
+    LEAF_TRY(leaf_launch_score(feat, anchor, B, rho, h->cfg.embed_dim, objective, best_idx, best_feat, loss, (hipStream_t)s));
+    return 0;
+}
+
 // ------------------------------------------------------------------ single-kernel hooks for the parity tests
 extern "C" int leaf_op_gemm(int dtype, int epi, const void* A, const void* B, void* C, const float* bias, void* aux,
                             int M, int N, int K, int act, float beta, int aux_f16, leaf_stream_t s) {
@@ -314,7 +393,7 @@ extern "C" int leaf_op_gemm_ld(int dtype, int epi, const void* A, int lda, const
 extern "C" int leaf_debug_gemm_stamps(void* buf) { leaf_gemm_set_stamps(buf); return 0; }
 extern "C" int leaf_op_attention_fwd(const void* qkv, void* out, int n_seq, int ctx, int heads, int width, int dtype,
                                      leaf_stream_t s) {
-    return leaf_check(leaf_launch_attention_fwd(qkv, out, n_seq, RowMap{nullptr, 0, 0, ctx}, heads, width, dtype,
+    return leaf_check(leaf_launch_attention_fwd(qkv, nullptr, out, n_seq, RowMap{nullptr, 0, 0, ctx, nullptr, nullptr, 1}, heads, width, dtype,
                                                 (hipStream_t)s), "attention_fwd");
 }
 extern "C" int leaf_op_layernorm(const float* x, const float* g, const float* b, float eps, void* out16, int rows,
@@ -324,5 +403,5 @@ extern "C" int leaf_op_layernorm(const float* x, const float* g, const float* b,
 extern "C" int leaf_op_attention_bwd(const void* qkv, int qkv_dtype, const void* dout_bf16, void* dqkv_bf16, int n_seq,
                                      int ctx, int heads, int width, leaf_stream_t s) {
     return leaf_check(leaf_launch_attention_bwd(qkv, qkv_dtype, dout_bf16, dqkv_bf16, LEAF_BF16, n_seq,
-                                                RowMap{nullptr, 0, 0, ctx}, heads, width, (hipStream_t)s), "attention_bwd");
+                                                RowMap{nullptr, 0, 0, ctx, nullptr, nullptr, 1}, heads, width, (hipStream_t)s), "attention_bwd");
 }

@@ -55,8 +55,8 @@ __device__ __forceinline__ typename TT::vec8 load_vt_frag(const char* vlds, int 
 }
 
 template <class TT, bool USE_TR>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const u16* __restrict__ qkv, u16* __restrict__ out, int n_items,
-                                                       RowMap map, int heads, int d) {
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const u16* __restrict__ qkv, const u16* __restrict__ kv_base,
+                                                       u16* __restrict__ out, int n_items, RowMap map, int heads, int d) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int item = blockIdx.x * 4 + wid;
@@ -65,16 +65,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const u16* __restrict__ q
     char* plds = vlds + V_BYTES;
     const int n = item / heads, h = item % heads;
     const int ld = 3 * d;
-    const int row_s = seq_row(map, map.s0 + n), ctx = seq_len(map, map.s0 + n);
-    const u16* base = qkv + (size_t)row_s * ld + h * HD;
+    const int sg = map.s0 + n;
+    const int row_s = seq_row(map, sg);
+    const int pfx = seq_prefix(map, sg);            // positions < pfx: K/V from the clean caption's cache
+    const int ctx = pfx + seq_len(map, sg);         // total length of this sequence
+    const u16* own = qkv + (size_t)row_s * ld + h * HD;
+    const u16* cached = pfx ? kv_base + (size_t)map.base_cu[sg / map.group] * ld + h * HD : own;
+    auto rowptr = [&](int pos) { return pos < pfx ? cached + (size_t)pos * ld : own + (size_t)(pos - pfx) * ld; };
     const int r16 = lane & 15, g = lane >> 4;
     const int nt = (ctx + 15) >> 4;
+    const int qt0 = pfx >> 4;                       // query tiles below the prefix are not needed
 
     // ---- V rows -> LDS (row-major), rows ctx..95 zero
     for (int idx = lane; idx < 96 * 8; idx += 64) {
         const int key = idx >> 3, ch = idx & 7;
         uint4 v = uint4{0u, 0u, 0u, 0u};
-        if (key < ctx) v = *(const uint4*)(base + (size_t)key * ld + 2 * d + ch * 8);
+        if (key < ctx) v = *(const uint4*)(rowptr(key) + 2 * d + ch * 8);
         *(uint4*)(vlds + key * (V_LD * 2) + ch * 16) = v;
     }
     // ---- K fragments -> registers
@@ -83,7 +89,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const u16* __restrict__ q
     for (int kt = 0; kt < MAXT; ++kt) {
         if (kt < nt) {
             int row = kt * 16 + r16; row = row < ctx ? row : ctx - 1;
-            const u16* kp = base + (size_t)row * ld + d + g * 8;
+            const u16* kp = rowptr(row) + d + g * 8;
             kf[kt][0] = __builtin_bit_cast(typename TT::vec8, *(const uint4*)(kp));
             kf[kt][1] = __builtin_bit_cast(typename TT::vec8, *(const uint4*)(kp + 32));
         }
@@ -91,10 +97,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const u16* __restrict__ q
 
 #pragma unroll
     for (int qt = 0; qt < MAXT; ++qt) {
-        if (qt < nt) {
+        if (qt < nt && qt >= qt0) {
             const int qidx = qt * 16 + r16;
-            const int qv = qidx < ctx ? qidx : ctx - 1;
-            const u16* qp = base + (size_t)qv * ld + g * 8;
+            int qv = qidx < ctx ? qidx : ctx - 1;
+            qv = qv < pfx ? pfx : qv;
+            const u16* qp = rowptr(qv) + g * 8;
             typename TT::vec8 qf0 = __builtin_bit_cast(typename TT::vec8, *(const uint4*)(qp));
             typename TT::vec8 qf1 = __builtin_bit_cast(typename TT::vec8, *(const uint4*)(qp + 32));
             // S^T tiles for key tiles 0..qt
@@ -155,8 +162,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const u16* __restrict__ q
                     }
                 }
             }
-            if (qidx < ctx) {
-                u16* op = out + ((size_t)row_s + qidx) * d + h * HD + 4 * g;
+            if (qidx < ctx && qidx >= pfx) {
+                u16* op = out + ((size_t)row_s + qidx - pfx) * d + h * HD + 4 * g;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt)
                     *(uint2*)(op + dt * 16) = pack4<TT>(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
@@ -167,8 +174,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const u16* __restrict__ q
 
 }  // namespace
 
-hipError_t leaf_launch_attention_fwd(const void* qkv, void* out, int n_seq, RowMap map, int heads, int d, int dtype,
-                                     hipStream_t s) {
+hipError_t leaf_launch_attention_fwd(const void* qkv, const void* kv_base, void* out, int n_seq, RowMap map, int heads,
+                                     int d, int dtype, hipStream_t s) {
     if (d != heads * HD || map.ctx > 16 * MAXT || map.ctx < 1) return hipErrorInvalidValue;
     static int use_tr = -1;
     if (use_tr < 0) {
@@ -186,7 +193,7 @@ hipError_t leaf_launch_attention_fwd(const void* qkv, void* out, int n_seq, RowM
                                 (int)lds);                                                                  \
             attr = true;                                                                                    \
         }                                                                                                   \
-        hipLaunchKernelGGL((attn_fwd_kernel<TT, TR>), grid, blk, lds, s, (const u16*)qkv, (u16*)out, items, map, heads, d); \
+        hipLaunchKernelGGL((attn_fwd_kernel<TT, TR>), grid, blk, lds, s, (const u16*)qkv, (const u16*)kv_base, (u16*)out, items, map, heads, d); \
     } while (0)
     if (dtype == LEAF_F16) { if (use_tr) LEAF_ATTN(F16, true); else LEAF_ATTN(F16, false); }
     else                   { if (use_tr) LEAF_ATTN(BF16, true); else LEAF_ATTN(BF16, false); }

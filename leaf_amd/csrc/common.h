@@ -87,12 +87,22 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb) {
 // ---- packed (EOT-trimmed) row layout -------------------------------------------------------------------------
 // Sequences keep only their first len = eot + 1 rows; cu[s] is the global packed row of sequence s's first row
 // (cu == nullptr means dense: cu[s] = s * ctx).  A launch covers sequences [s0, s0 + n) whose rows start at row0.
+//
+// Prefix reuse: a search candidate shares every position before its first changed token with its
+// clean caption, and under the causal mask those rows are identical at every layer.  In prefix mode a sequence
+// computes only positions [prefix[s], prefix[s] + len) ("suffix rows", that is what cu counts); attention reads the
+// K/V of positions < prefix[s] from the clean caption's per-layer qkv cache (caption index s / group, rows at
+// base_cu[.] inside the cache).
 struct RowMap {
     const int32_t* cu;
     int s0, row0, ctx;
+    const int32_t* prefix;   // device, per sequence, or null
+    const int32_t* base_cu;  // device, packed row offsets of the clean captions inside the kv cache
+    int group;               // candidates per clean caption
 };
 __device__ __forceinline__ int seq_row(const RowMap& m, int s) { return (m.cu ? m.cu[s] : s * m.ctx) - m.row0; }
 __device__ __forceinline__ int seq_len(const RowMap& m, int s) { return m.cu ? m.cu[s + 1] - m.cu[s] : m.ctx; }
+__device__ __forceinline__ int seq_prefix(const RowMap& m, int s) { return m.prefix ? m.prefix[s] : 0; }
 // sequence owning local row r (n sequences in this launch)
 __device__ __forceinline__ int seq_of_row(const RowMap& m, int r, int n) {
     const int R = m.row0 + r;

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x_in,
     float4 v[MAXCH];
     if constexpr (EMBED) {
         const int sq = seq_of_row(map, row, n_seq);
-        const int pos = row - seq_row(map, sq);
+        const int pos = row - seq_row(map, sq) + seq_prefix(map, sq);
         int tok = tokens[(size_t)sq * map.ctx + pos];
         tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
         const float* te = tok_emb + (size_t)tok * d;
@@ -108,9 +108,9 @@ __global__ __launch_bounds__(256) void pool_project_kernel(const float* __restri
             continue;
         }
         // first index of the maximum token id (torch argmax) among the rows this sequence keeps
-        const int sg = map.s0 + n, ctx = seq_len(map, sg);
-        int bv = -2147483647 - 1, bi = 0;
-        for (int p = lane; p < ctx; p += 64) {
+        const int sg = map.s0 + n, pfx = seq_prefix(map, sg), ctx = pfx + seq_len(map, sg);
+        int bv = -2147483647 - 1, bi = pfx;
+        for (int p = pfx + lane; p < ctx; p += 64) {   // only kept positions; EOT (the row maximum) is among them
             int t = tokens[(size_t)sg * map.ctx + p];
             if (t > bv) { bv = t; bi = p; }
         }
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void pool_project_kernel(const float* __restri
             if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
         }
         if (eot_idx && lane == 0) eot_idx[n] = bi;
-        const float* xi = x + ((size_t)seq_row(map, sg) + bi) * d;
+        const float* xi = x + ((size_t)seq_row(map, sg) + bi - pfx) * d;
         float4 v[MAXCH];
         float s = 0.f;
 #pragma unroll
@@ -286,10 +286,10 @@ hipError_t leaf_launch_layernorm(const float* x, const float* g, const float* b,
     dim3 grid((rows + 3) / 4), blk(256);
     if (dtype == LEAF_F16)
         hipLaunchKernelGGL((ln_kernel<F16, false>), grid, blk, 0, s, x, nullptr, nullptr, nullptr, g, b, eps, nullptr,
-                           (u16*)xn, rows, 0, RowMap{nullptr, 0, 0, 1}, d, 0);
+                           (u16*)xn, rows, 0, RowMap{nullptr, 0, 0, 1, nullptr, nullptr, 1}, d, 0);
     else
         hipLaunchKernelGGL((ln_kernel<BF16, false>), grid, blk, 0, s, x, nullptr, nullptr, nullptr, g, b, eps, nullptr,
-                           (u16*)xn, rows, 0, RowMap{nullptr, 0, 0, 1}, d, 0);
+                           (u16*)xn, rows, 0, RowMap{nullptr, 0, 0, 1, nullptr, nullptr, 1}, d, 0);
     return hipGetLastError();
 }
 

@@ -54,8 +54,9 @@ hipError_t leaf_launch_score(const float* feat, const float* anchor, int B, int 
 hipError_t leaf_launch_cast(const float* src, void* dst, size_t n, int dtype, hipStream_t s);
 
 // ---- attention (attention.hip): qkv [rows, 3d] 16-bit (q | k | v, heads inside each), out [rows, d]
-hipError_t leaf_launch_attention_fwd(const void* qkv, void* out, int n_seq, RowMap map, int heads, int d, int dtype,
-                                     hipStream_t s);
+// kv_base: this layer's qkv rows of the clean captions (prefix mode, map.prefix != null) or null
+hipError_t leaf_launch_attention_fwd(const void* qkv, const void* kv_base, void* out, int n_seq, RowMap map, int heads,
+                                     int d, int dtype, hipStream_t s);
 
 // ---- training-only kernels (train.hip)
 // dst[c, r] = (16-bit) src[r, c], zero padded to rpad columns.  kinds: 0 bf16, 1 fp16, 2 fp32 (source only)

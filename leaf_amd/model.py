@@ -258,8 +258,41 @@ class LeafCLIPText:
                    "leaf_text_forward")
         return out
 
+    def encode_text_kv(self, text, seq_lens=None, want_features: bool = False):
+        """Forward of the clean captions that keeps every layer's q|k|v rows for prefix reuse by the search
+        (include/leaf_hip.h, "prefix reuse").  Returns an opaque cache (and the features when asked)."""
+        if not self._packed:
+            self.pack()
+        if seq_lens is None:
+            arr = text if isinstance(text, np.ndarray) else text.cpu().numpy()
+            seq_lens = arr.reshape(-1, arr.shape[-1]).argmax(-1) + 1
+        lens = np.ascontiguousarray(np.asarray(seq_lens).reshape(-1), dtype=np.int32)
+        cu = np.zeros(lens.size + 1, dtype=np.int32)
+        np.cumsum(lens, out=cu[1:])
+        cu_dev = torch.from_numpy(cu).pin_memory().to(self.device, non_blocking=True)
+        t = self._tokens(text)
+        n = t.shape[0]
+        need = int(cu[-1]) * 3 * self.cfg.width * 2 * self.cfg.layers
+        if getattr(self, "_kv", None) is None or self._kv.numel() < need:
+            self._kv = None
+            with torch.cuda.device(self.device):
+                self._kv = torch.empty(max(need, 1), dtype=torch.uint8, device=self.device)
+        out = torch.empty(n, self.cfg.embed_dim, dtype=torch.float32, device=self.device) if want_features else None
+        ws = self._workspace(0, n)
+        _lib.check(self._lib.leaf_text_forward_kv(self._h, _ptr(self.flat), _ptr(self.w16), _ptr(t),
+                                                  C.c_void_p(lens.ctypes.data), _ptr(cu_dev), n, _ptr(out), 0,
+                                                  _ptr(self._kv), self._kv.numel(), _ptr(ws), ws.numel(), self._stream()),
+                   "leaf_text_forward_kv")
+        cache = {"kv": self._kv, "base_cu": cu_dev, "base_rows": int(cu[-1]), "lens": lens, "n": n}
+        return (cache, out) if want_features else cache
+
     def score_candidates(self, tokens, anchor: torch.Tensor, rho: int, objective: str = "l2", want_features=True,
-                         want_loss=False, seq_lens=None):
+                         want_loss=False, seq_lens=None, prefix_lens=None, kv=None):
+        """``prefix_lens`` (host int array [B*rho], number of leading positions equal to the clean caption) together
+        with ``kv`` (from ``encode_text_kv`` of the clean captions) enables prefix reuse: only positions from the
+        first changed token on are recomputed.  ``seq_lens`` must then be the candidates' full lengths."""
+        if prefix_lens is not None and kv is not None and self.trim_rows:
+            return self._score_prefix(tokens, anchor, rho, objective, want_features, want_loss, seq_lens, prefix_lens, kv)
         """tokens [B*rho, ctx] (or [B,rho,ctx]); anchor [B,D] fp32 CUDA.  Returns (best_idx int32[B],
         best_feat [B,D] or None) (+ loss [B,rho] when want_loss)."""
         if not self._packed:
@@ -280,6 +313,38 @@ class LeafCLIPText:
                                                    _ptr(anchor), B, rho, _OBJ[objective], _ptr(idx), _ptr(feat),
                                                    _ptr(loss), _ptr(ws), ws.numel(), self._stream()),
                    "leaf_score_candidates")
+        return (idx, feat, loss) if want_loss else (idx, feat)
+
+    def _score_prefix(self, tokens, anchor, rho, objective, want_features, want_loss, seq_lens, prefix_lens, kv):
+        if not self._packed:
+            self.pack()
+        if seq_lens is None:
+            arr = tokens if isinstance(tokens, np.ndarray) else tokens.cpu().numpy()
+            seq_lens = arr.reshape(-1, arr.shape[-1]).argmax(-1) + 1
+        full = np.asarray(seq_lens, dtype=np.int64).reshape(-1)
+        pfx = np.minimum(np.asarray(prefix_lens, dtype=np.int64).reshape(-1), full - 1)      # keep at least the EOT row
+        pfx = np.minimum(pfx, np.repeat(kv["lens"].astype(np.int64), rho))                   # rows the cache really holds
+        suf = np.ascontiguousarray(full - pfx, dtype=np.int32)
+        cu = np.zeros(suf.size + 1, dtype=np.int32)
+        np.cumsum(suf, out=cu[1:])
+        host = np.concatenate([cu, pfx.astype(np.int32)])
+        dev = torch.from_numpy(host).pin_memory().to(self.device, non_blocking=True)
+        cu_dev, pfx_dev = dev[:suf.size + 1], dev[suf.size + 1:]
+        if isinstance(tokens, np.ndarray):
+            tokens = torch.from_numpy(tokens)
+        t = self._tokens(tokens.reshape(-1, tokens.shape[-1]))
+        B = anchor.shape[0]
+        if t.shape[0] != B * rho or kv["n"] != B:
+            raise ValueError("candidate rows / kv cache do not match B*rho")
+        anchor = anchor.to(device=self.device, dtype=torch.float32).contiguous()
+        idx = torch.empty(B, dtype=torch.int32, device=self.device)
+        feat = torch.empty(B, self.cfg.embed_dim, dtype=torch.float32, device=self.device) if want_features else None
+        loss = torch.empty(B, rho, dtype=torch.float32, device=self.device) if want_loss else None
+        ws = self._workspace(1, B * rho)
+        _lib.check(self._lib.leaf_score_candidates_prefix(
+            self._h, _ptr(self.flat), _ptr(self.w16), _ptr(t), C.c_void_p(suf.ctypes.data), _ptr(cu_dev), _ptr(pfx_dev),
+            _ptr(kv["base_cu"]), _ptr(kv["kv"]), kv["base_rows"], _ptr(anchor), B, rho, _OBJ[objective], _ptr(idx),
+            _ptr(feat), _ptr(loss), _ptr(ws), ws.numel(), self._stream()), "leaf_score_candidates_prefix")
         return (idx, feat, loss) if want_loss else (idx, feat)
 
     # ------------------------------------------------------------------ training

@@ -37,55 +37,63 @@ class StepConfig:
 
 
 class SyntheticCandidates:
-    """Device-side stand-in for the host string mutation: candidates are copies of the caption's token row with
-    one position resampled (stage 1: rho random positions; stage 2: rho random ids at the stage-1 winner's
-    position), generated with torch ops on the GPU so the step has the reference's data dependencies
-    (stage 2 depends on the stage-1 arg-max, the training batch on the stage-2 arg-max) without host syncs."""
+    """Stand-in for the host string mutation on token ids: candidates are copies of the caption's token row with one
+    position resampled (stage 1: rho random positions; stage 2: rho random ids at the stage-1 winner's position).
+    As in the real search the HOST draws the positions (it needs them to plan the rows to compute) and learns the
+    stage-1 winners through one small device-to-host copy per stage; the replacement ids are drawn on the device."""
 
-    def __init__(self, base: torch.Tensor, rho: int, vocab: int, seed: int):
-        self.base = base  # int32 [B, ctx]
+    def __init__(self, base: torch.Tensor, base_lens, rho: int, vocab: int, seed: int):
+        import numpy as np
         self.rho, self.vocab = rho, vocab
         self.gen = torch.Generator(device=base.device)
         self.gen.manual_seed(seed)
+        self.rng = np.random.default_rng(seed)
         self.B, self.ctx = base.shape
-        self.length = base.argmax(-1).to(torch.int64) - 1   # tokens between SOT and EOT
+        if base_lens is None:
+            base_lens = (base.argmax(-1) + 1).cpu().numpy()
+        self.inner = np.asarray(base_lens, dtype=np.int64) - 2          # ids between SOT and EOT
 
-    def stage1(self, cur: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    def _apply(self, cur, pos_host):
         B, rho = self.B, self.rho
-        u = torch.rand(B, rho, device=cur.device, generator=self.gen)
-        pos = 1 + (u * self.length[:, None]).to(torch.int64).clamp_(max=self.ctx - 2)
+        pos = torch.from_numpy(pos_host).pin_memory().to(cur.device, non_blocking=True)
         ids = torch.randint(1, self.vocab - 2, (B, rho), device=cur.device, generator=self.gen, dtype=torch.int32)
         cand = cur[:, None, :].repeat(1, rho, 1)
         cand.scatter_(2, pos[:, :, None], ids[:, :, None])
-        return cand, pos
-
-    def stage2(self, cur: torch.Tensor, pos: torch.Tensor, best1: torch.Tensor) -> torch.Tensor:
-        B, rho = self.B, self.rho
-        p = pos.gather(1, best1.to(torch.int64)[:, None])                 # [B,1]
-        ids = torch.randint(1, self.vocab - 2, (B, rho), device=cur.device, generator=self.gen, dtype=torch.int32)
-        cand = cur[:, None, :].repeat(1, rho, 1)
-        cand.scatter_(2, p[:, :, None].expand(B, rho, 1), ids[:, :, None])
         return cand
+
+    def stage1(self, cur: torch.Tensor):
+        import numpy as np
+        pos = 1 + (self.rng.random((self.B, self.rho)) * self.inner[:, None]).astype(np.int64)
+        return self._apply(cur, pos), pos
+
+    def stage2(self, cur: torch.Tensor, pos, best1_host):
+        import numpy as np
+        p = pos[np.arange(self.B), best1_host]
+        pos2 = np.repeat(p[:, None], self.rho, axis=1)
+        return self._apply(cur, pos2), pos2
 
 
 def search_synthetic(model, anchor: torch.Tensor, base: torch.Tensor, cfg: StepConfig, seed: int,
-                     base_lens=None) -> torch.Tensor:
+                     base_lens=None, prefix_reuse: bool = True) -> torch.Tensor:
     """2k calls of score_candidates on [B*rho, ctx] synthetic candidates; returns the adversarial ids [B, ctx].
-    ``base_lens`` (host int array, EOT position + 1 per caption) enables EOT trimming: the synthetic edits never move
-    EOT, so every candidate of caption b has the same length as b."""
+    ``base_lens`` (host int array, EOT position + 1 per caption) enables EOT trimming (the synthetic edits never move
+    EOT); with ``prefix_reuse`` the clean captions' per-layer K/V are cached once per edit and every candidate only
+    recomputes the positions from its edited token on (the edit position is the prefix length)."""
     import numpy as np
     cand_lens = None if base_lens is None else np.repeat(np.asarray(base_lens, dtype=np.int32), cfg.rho)
-    gen = SyntheticCandidates(base, cfg.rho, model.cfg.vocab_size, seed)
+    gen = SyntheticCandidates(base, base_lens, cfg.rho, model.cfg.vocab_size, seed)
+    reuse = prefix_reuse and base_lens is not None and getattr(model, "trim_rows", False)
     cur = base
     B = base.shape[0]
     ar = torch.arange(B, device=base.device)
     for _ in range(cfg.k_adv):
+        kv = model.encode_text_kv(cur, seq_lens=base_lens) if reuse else None
         cand, pos = gen.stage1(cur)
         best1, _ = model.score_candidates(cand.view(B * cfg.rho, -1), anchor, cfg.rho, "l2", want_features=False,
-                                          seq_lens=cand_lens)
-        cand = gen.stage2(cur, pos, best1)
+                                          seq_lens=cand_lens, prefix_lens=pos.reshape(-1) if reuse else None, kv=kv)
+        cand, pos2 = gen.stage2(cur, pos, best1.cpu().numpy())          # the search's device->host sync (B indices)
         best2, _ = model.score_candidates(cand.view(B * cfg.rho, -1), anchor, cfg.rho, "l2", want_features=False,
-                                          seq_lens=cand_lens)
+                                          seq_lens=cand_lens, prefix_lens=pos2.reshape(-1) if reuse else None, kv=kv)
         cur = cand[ar, best2.to(torch.int64)]
     return cur
 
@@ -100,11 +108,11 @@ def allreduce_grads(model) -> float:
 
 
 def train_step_tokens(model, frozen, base: torch.Tensor, cfg: StepConfig, seed: int, lr: Optional[float] = None,
-                      micro_index: int = 0, base_lens=None) -> torch.Tensor:
+                      micro_index: int = 0, base_lens=None, prefix_reuse: bool = True) -> torch.Tensor:
     """Full outer step on token ids (int32 [B, ctx] on the model's device).  Returns the TextFARE loss (0-d)."""
     model.eval()
     anchor = frozen.encode_text(base, seq_lens=base_lens)
-    adv = search_synthetic(model, anchor, base, cfg, seed, base_lens=base_lens)
+    adv = search_synthetic(model, anchor, base, cfg, seed, base_lens=base_lens, prefix_reuse=prefix_reuse)
     model.train()
     feat = model.forward_train(adv, seq_lens=base_lens)
     if micro_index % cfg.accum_freq == 0:

@@ -198,3 +198,26 @@ def test_encode_text_large_towers_vs_oracle(torch_mod, model):
     r = row_rel_l2(got, want)
     print(f"{model}: rel-L2 global {rel_l2(got, want):.3e} row max {r.max():.3e}")
     assert rel_l2(got, want) < TOL_GLOBAL and r.max() < TOL_ROW
+
+
+def test_prefix_reuse_is_bit_exact(torch_mod):
+    """Prefix reuse (K/V of the positions before the first changed token come from the clean caption's cache) returns
+    bit-identical losses, winners and features, also for candidates equal to the caption and edits at position 1."""
+    m = _model("tiny-test-quickgelu", 12)
+    B, rho = 7, 20
+    base = O.synthetic_tokens(B, seed=31, min_len=2, max_len=70)
+    cand = O.synthetic_candidates(base, rho, seed=32)
+    cand[:, 0] = base                      # no-op candidate: nothing changes -> only the EOT row is recomputed
+    cand[:, 1] = base
+    cand[:, 1, 1] = 7                      # first real token edited -> whole suffix recomputed
+    flat = cand.reshape(-1, 77)
+    neq = flat.reshape(B, rho, 77) != base[:, None, :]
+    pl = neq.argmax(-1)
+    pl[~neq.any(-1)] = 77
+    anchor = m.encode_text(base) + 0.3
+    lens = np.repeat(base.argmax(-1) + 1, rho)
+    i0, f0, l0 = m.score_candidates(flat, anchor, rho, "l2", want_loss=True, seq_lens=lens)
+    kv, feats = m.encode_text_kv(base, want_features=True)
+    assert torch_mod.equal(feats, m.encode_text(base))
+    i1, f1, l1 = m.score_candidates(flat, anchor, rho, "l2", want_loss=True, seq_lens=lens, prefix_lens=pl.reshape(-1), kv=kv)
+    assert torch_mod.equal(l0, l1) and torch_mod.equal(i0, i1) and torch_mod.equal(f0, f1)

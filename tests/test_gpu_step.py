@@ -21,11 +21,17 @@ def test_synthetic_step_runs_and_selects_argmax():
     diff = (adv != base).sum(-1).cpu().numpy()
     assert diff.max() <= sc.k_adv and (adv.argmax(-1) == base.argmax(-1)).all()   # <= k edits, EOT untouched
     # candidates differ from the current row in exactly <= 1 position, inside the caption
-    gen = SyntheticCandidates(base, 10, m.cfg.vocab_size, 0)
+    gen = SyntheticCandidates(base, None, 10, m.cfg.vocab_size, 0)
     cand, pos = gen.stage1(base)
     d = (cand != base[:, None, :])
     assert d.sum(-1).max() <= 1
-    assert (pos >= 1).all() and (pos < base.argmax(-1)[:, None]).all()
+    eot = base.argmax(-1).cpu().numpy()
+    assert (pos >= 1).all() and (pos < eot[:, None]).all()
+    # prefix reuse and plain EOT trimming pick the same adversarial ids (bit-identical scoring)
+    lens = eot + 1
+    a1 = search_synthetic(m, anchor, base, sc, seed=3, base_lens=lens, prefix_reuse=True)
+    a2 = search_synthetic(m, anchor, base, sc, seed=3, base_lens=lens, prefix_reuse=False)
+    assert torch.equal(a1, a2)
     l0 = float(train_step_tokens(m, frozen, base, sc, seed=1))
     l1 = float(train_step_tokens(m, frozen, base, sc, seed=1))
     assert np.isfinite([l0, l1]).all()
