@@ -327,7 +327,7 @@ template <class TT>
 hipError_t launch_t(const GemmArgs& p, int epi, hipStream_t s) {
     static int use256 = -1;
     if (use256 < 0) { const char* e = getenv("LEAF_GEMM256"); use256 = (e && e[0] == '0') ? 0 : 1; }
-    const bool big = use256 && p.N % BN2 == 0 && p.M >= 2048;
+    const bool big = use256 && p.N % BN2 == 0 && (long)((p.M + BM2 - 1) / BM2) * (p.N / BN2) >= 128;
     const int grid = big ? ((p.M + BM2 - 1) / BM2) * (p.N / BN2) : ((p.M + BM - 1) / BM) * (p.N / BN);
     const size_t lds = big ? 2 * STAGE2 : 4 * TILE_BYTES;
 #define LEAF_GEMM_CASE(E)                                                                    \

@@ -304,7 +304,9 @@ hipError_t launch256(const GemmArgs& p, int epi, hipStream_t s) {
 }  // namespace
 
 bool leaf_gemm256_eligible(const GemmArgs& p, int epi) {
-    return p.N % BN == 0 && p.M >= 2048 && p.K % (2 * BKS) == 0 && p.K >= 6 * BKS && p.ldc % 8 == 0 && epi != EPI_ACTGRAD_T;
+    // at least half a wave of 256^2 tiles over the 256 CUs, else the 128^2 kernel fills the chip better (weight gradients)
+    const long tiles = (long)((p.M + BM - 1) / BM) * (p.N / BN);
+    return p.N % BN == 0 && tiles >= 128 && p.K % (2 * BKS) == 0 && p.K >= 6 * BKS && p.ldc % 8 == 0 && epi != EPI_ACTGRAD_T;
 }
 
 hipError_t leaf_launch_gemm256(const GemmArgs& p, int dtype, int epi, hipStream_t s) {

@@ -24,7 +24,8 @@ def _round(x, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["fp16", "bf16"])
-@pytest.mark.parametrize("M,N,K", [(77 * 3, 128, 64), (300, 384, 128), (1000, 256, 512), (2100, 256, 128), (4096 + 77, 512, 192), (2048, 256, 768), (2500, 768, 3072)])
+@pytest.mark.parametrize("M,N,K", [(77 * 3, 128, 64), (300, 384, 128), (1000, 256, 512), (2100, 256, 128), (4096 + 77, 512, 192), (2048, 256, 768), (2500, 768, 3072),
+                                   (11085, 768, 256), (8300, 1024, 192)])   # >= 128 tiles of 256^2: the ring kernel
 def test_gemm_epilogues(env, dtype, M, N, K):
     lib, torch, dev = env
     from leaf_amd import _lib
