@@ -364,10 +364,12 @@ void leaf_gemm_set_stamps(void* p) { g_stamps = p; }
 hipError_t leaf_launch_gemm(const GemmArgs& p_in, int dtype, int epi, hipStream_t s) {
     GemmArgs p = p_in;
     p.stamps = g_stamps;
-    static int ver = -1;   // LEAF_GEMM_V=1 forces the previous-generation kernels (A/B runs)
+    // LEAF_GEMM_V: 1 = previous-generation kernels, 2 = ring kernel (default), 3 = persistent ring (gemm256p.hip;
+    // measured 3-4 % SLOWER than 2 on the text-tower shapes: kept for A/B runs)
+    static int ver = -1;
     if (ver < 0) { const char* e = getenv("LEAF_GEMM_V"); ver = e ? atoi(e) : 2; }
     if (ver >= 2 && p.M > 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && leaf_gemm256_eligible(p, epi))
-        return leaf_launch_gemm256(p, dtype, epi, s);
+        return ver >= 3 ? leaf_launch_gemm256p(p, dtype, epi, s) : leaf_launch_gemm256(p, dtype, epi, s);
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.N % BN || p.K % BK || p.lda % 8 || p.ldb % 8 || p.ldc % 4)
         return hipErrorInvalidValue;
     return dtype == LEAF_F16 ? launch_t<F16>(p, epi, s) : launch_t<BF16>(p, epi, s);

@@ -34,6 +34,8 @@ void leaf_gemm_set_stamps(void* p);
 // 256x256 4-stage LDS-DMA ring kernel (gemm256.hip); eligible() says whether a problem may use it
 bool leaf_gemm256_eligible(const GemmArgs& p, int epi);
 hipError_t leaf_launch_gemm256(const GemmArgs& p, int dtype, int epi, hipStream_t s);
+// same tile/pipeline with persistent workgroups (gemm256p.hip): the DMA ring runs across tile seams
+hipError_t leaf_launch_gemm256p(const GemmArgs& p, int dtype, int epi, hipStream_t s);
 
 // ---- forward elementwise / reduction kernels (elementwise.hip)
 // x[r,:] = tok_emb[tokens[r],:] + pos_emb[r % ctx,:]   and   xn = LN(x) (16-bit)
