@@ -145,11 +145,12 @@ def main():
 
     if rank == 0:
         nk = 16
-        ms, fl, cnt = (C.c_double * nk)(), (C.c_double * nk)(), (C.c_int64 * nk)()
-        _lib.check(lib.leaf_prof_end(ms, fl, cnt, nk), "leaf_prof_end")
+        ms, fl, by, cnt = (C.c_double * nk)(), (C.c_double * nk)(), (C.c_double * nk)(), (C.c_int64 * nk)()
+        _lib.check(lib.leaf_prof_end(ms, fl, by, cnt, nk), "leaf_prof_end")
         kinds = [(ms[i], fl[i], cnt[i], i) for i in range(nk) if cnt[i] > 0]
         kinds.sort(reverse=True)
         dom_ms, dom_fl, dom_cnt, dom_key = kinds[0]
+        dom_bytes = by[dom_key]
         dt_code = 1 if args.dtype == "fp16" else 0
         achieved = dom_fl / (dom_ms * 1e-3) / 1e12
         gemm_total_ms = sum(k[0] for k in kinds)
@@ -157,6 +158,15 @@ def main():
         F = fwd_flops_per_seq(cfg)
         flops_per_sample = (2 * args.rho * args.k_adv + 4) * F
         value = B * world * args.steps / dt
+        traffic = None     # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+                tj = json.load(f)
+            if tj["kernel"] == f"gemm_nt256_ring_kernel<{'F16' if dom_key // 8 == 1 else 'BF16'},{dom_key % 8}>" and not args.dense \
+                    and not args.no_prefix_reuse and args.model == "ViT-L-14-quickgelu" and B == 128:
+                traffic = tj["traffic_bytes_per_launch"]
+        except Exception:
+            pass
         out = {
             "metric": "adversarial text samples/sec", "value": value, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -168,8 +178,10 @@ def main():
                        "parallelism": f"dp{world}", "candidate_forwards_per_step_per_gpu": 2 * args.rho * args.k_adv * B},
             "roofline": {
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS_16BIT, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_TFLOPS_16BIT, "traffic": None,
-                "kernel": f"gemm_nt_kernel<{'F16' if dom_key // 8 == 1 else 'BF16'},{dom_key % 8}> {EPI_NAMES.get(dom_key % 8)}",
+                "frac": achieved / PEAK_TFLOPS_16BIT, "traffic": traffic,
+                "traffic_note": "HBM bytes per launch, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) * 1024, profiles/r01_traffic.json",
+                "kernel": f"gemm_nt256_ring_kernel<{'F16' if dom_key // 8 == 1 else 'BF16'},{dom_key % 8}> {EPI_NAMES.get(dom_key % 8)}",
+                "algorithmic_bytes_per_launch": dom_bytes / dom_cnt if dom_bytes else None,
                 "launches": int(dom_cnt), "avg_launch_ms": dom_ms / dom_cnt,
                 "algorithmic_gflop_per_launch": dom_fl / dom_cnt / 1e9,
                 "all_gemm_tflops": gemm_total_fl / (gemm_total_ms * 1e-3) / 1e12,

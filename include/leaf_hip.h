@@ -135,9 +135,9 @@ int leaf_tok_mutate_encode(leaf_tok_t tk, const char* const* sentences, const in
                            int n_threads);
 
 /* ---- per-launch GEMM timing (bench.py roofline): between begin/end every GEMM launch is bracketed by HIP events on
- * its stream; end() sums duration / algorithmic FLOPs / launches per key = operand_dtype*8 + epilogue id. */
+ * its stream; end() sums duration / algorithmic FLOPs / algorithmic bytes / launches per key = operand_dtype*8 + epilogue id. */
 int leaf_prof_begin(void);
-int leaf_prof_end(double* ms, double* flops, int64_t* count, int n_keys);
+int leaf_prof_end(double* ms, double* flops, double* bytes /* algorithmic, may be NULL */, int64_t* count, int n_keys);
 
 /* ---- single-kernel hooks (used by the parity tests to check each HIP kernel against the oracle) ---- */
 /* C[M,N] = epilogue(A[M,K] * B[N,K]^T): epi 0 store16(+bias), 1 act16(+bias, aux = pre-activation), 2 fp32 += ,

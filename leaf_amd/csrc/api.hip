@@ -130,7 +130,7 @@ extern "C" int leaf_text_pack_weights(leaf_text_t h, const float* params, void* 
 // ------------------------------------------------------------------ forward
 // ------------------------------------------------------------------ per-launch GEMM profiler (bench.py roofline)
 namespace {
-struct ProfRec { hipEvent_t a, b; int key; double flops; };
+struct ProfRec { hipEvent_t a, b; int key; double flops, bytes; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 }  // namespace
@@ -145,6 +145,11 @@ int leaf_gemm(int dtype, int epi, const void* A, int lda, const void* B, int ldb
     ProfRec r;
     r.key = dtype * 8 + epi;
     r.flops = 2.0 * (double)M * (double)N * (double)K;
+    {   // algorithmic bytes of the launch: both operands once + the output (+ the fp32 read of a residual/accumulate)
+        const double out_b = (epi == EPI_RESID_F32 || epi == EPI_STORE_F32) ? 4.0 : 2.0;
+        const double rmw = (epi == EPI_RESID_F32 || (epi == EPI_STORE_F32 && beta != 0.f)) ? 4.0 : 0.0;
+        r.bytes = 2.0 * ((double)M * K + (double)N * K) + (double)M * N * (out_b + rmw) + (epi == EPI_ACTGRAD_T ? 2.0 * M * N : 0.0);
+    }
     LEAF_TRY(hipEventCreate(&r.a));
     LEAF_TRY(hipEventCreate(&r.b));
     LEAF_TRY(hipEventRecord(r.a, s));
@@ -162,15 +167,15 @@ extern "C" int leaf_prof_begin(void) {
 }
 
 // Stops recording, waits for the recorded events and sums per key (= dtype*8 + epilogue id, < 16):
-// ms[key], flops[key], count[key].
-extern "C" int leaf_prof_end(double* ms, double* flops, int64_t* count, int n_keys) {
+// ms[key], flops[key], bytes[key] (algorithmic operand + output bytes, may be null), count[key].
+extern "C" int leaf_prof_end(double* ms, double* flops, double* bytes, int64_t* count, int n_keys) {
     g_prof_on = false;
-    for (int i = 0; i < n_keys; ++i) { ms[i] = 0; flops[i] = 0; count[i] = 0; }
+    for (int i = 0; i < n_keys; ++i) { ms[i] = 0; flops[i] = 0; count[i] = 0; if (bytes) bytes[i] = 0; }
     for (auto& r : g_prof) {
         LEAF_TRY(hipEventSynchronize(r.b));
         float t = 0.f;
         LEAF_TRY(hipEventElapsedTime(&t, r.a, r.b));
-        if (r.key >= 0 && r.key < n_keys) { ms[r.key] += t; flops[r.key] += r.flops; count[r.key] += 1; }
+        if (r.key >= 0 && r.key < n_keys) { ms[r.key] += t; flops[r.key] += r.flops; count[r.key] += 1; if (bytes) bytes[r.key] += r.bytes; }
         (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
     }
     g_prof.clear();
