@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS_16BIT = 2500.0  # MI355X dense bf16/fp16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
+FAMILY = {0: "gemm_nt_kernel", 1: "gemm_nt256_kernel", 2: "gemm_nt256_ring_kernel", 3: "gemm_nt256_persist_kernel"}
 EPI_NAMES = {0: "store16(qkv)", 1: "act16(c_fc)", 2: "resid32(out_proj+c_proj)", 3: "store32(wgrad/dgrad)", 4: "actgrad16"}
 
 
@@ -144,7 +145,7 @@ def main():
     dt = float(tmax.item())
 
     if rank == 0:
-        nk = 16
+        nk = 64
         ms, fl, by, cnt = (C.c_double * nk)(), (C.c_double * nk)(), (C.c_double * nk)(), (C.c_int64 * nk)()
         _lib.check(lib.leaf_prof_end(ms, fl, by, cnt, nk), "leaf_prof_end")
         kinds = [(ms[i], fl[i], cnt[i], i) for i in range(nk) if cnt[i] > 0]
@@ -162,7 +163,7 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
                 tj = json.load(f)
-            if tj["kernel"] == f"gemm_nt256_ring_kernel<{'F16' if dom_key // 8 == 1 else 'BF16'},{dom_key % 8}>" and not args.dense \
+            if tj["kernel"] == f"{FAMILY[dom_key // 16]}<{'F16' if (dom_key // 8) % 2 == 1 else 'BF16'},{dom_key % 8}>" and not args.dense \
                     and not args.no_prefix_reuse and args.model == "ViT-L-14-quickgelu" and B == 128:
                 traffic = tj["traffic_bytes_per_launch"]
         except Exception:
@@ -180,7 +181,7 @@ def main():
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS_16BIT, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_TFLOPS_16BIT, "traffic": traffic,
                 "traffic_note": "HBM bytes per launch, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) * 1024, profiles/r01_traffic.json",
-                "kernel": f"gemm_nt256_ring_kernel<{'F16' if dom_key // 8 == 1 else 'BF16'},{dom_key % 8}> {EPI_NAMES.get(dom_key % 8)}",
+                "kernel": f"{FAMILY[dom_key // 16]}<{'F16' if (dom_key // 8) % 2 == 1 else 'BF16'},{dom_key % 8}> {EPI_NAMES.get(dom_key % 8)}",
                 "algorithmic_bytes_per_launch": dom_bytes / dom_cnt if dom_bytes else None,
                 "launches": int(dom_cnt), "avg_launch_ms": dom_ms / dom_cnt,
                 "algorithmic_gflop_per_launch": dom_fl / dom_cnt / 1e9,

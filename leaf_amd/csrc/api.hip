@@ -143,7 +143,7 @@ int leaf_gemm(int dtype, int epi, const void* A, int lda, const void* B, int ldb
     g.act = act; g.aux_f16 = aux_f16; g.beta = beta; g.stamps = nullptr; g.alpha = alpha;
     if (!g_prof_on) return leaf_check(leaf_launch_gemm(g, dtype, epi, s), "gemm");
     ProfRec r;
-    r.key = dtype * 8 + epi;
+    r.key = leaf_gemm_family(g, epi) * 16 + dtype * 8 + epi;
     r.flops = 2.0 * (double)M * (double)N * (double)K;
     {   // algorithmic bytes of the launch: both operands once + the output (+ the fp32 read of a residual/accumulate)
         const double out_b = (epi == EPI_RESID_F32 || epi == EPI_STORE_F32) ? 4.0 : 2.0;
@@ -166,7 +166,7 @@ extern "C" int leaf_prof_begin(void) {
     return 0;
 }
 
-// Stops recording, waits for the recorded events and sums per key (= dtype*8 + epilogue id, < 16):
+// Stops recording, waits for the recorded events and sums per key (= kernel_family*16 + dtype*8 + epilogue id, < 64):
 // ms[key], flops[key], bytes[key] (algorithmic operand + output bytes, may be null), count[key].
 extern "C" int leaf_prof_end(double* ms, double* flops, double* bytes, int64_t* count, int n_keys) {
     g_prof_on = false;

@@ -358,6 +358,16 @@ hipError_t launch_t(const GemmArgs& p, int epi, hipStream_t s) {
 
 }  // namespace
 
+// which kernel leaf_launch_gemm will pick: 0 = gemm_nt_kernel (128^2), 1 = gemm_nt256_kernel, 2 = ring, 3 = persistent
+int leaf_gemm_family(const GemmArgs& p, int epi) {
+    static int ver = -1;
+    if (ver < 0) { const char* e = getenv("LEAF_GEMM_V"); ver = e ? atoi(e) : 2; }
+    if (ver >= 2 && p.M > 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && leaf_gemm256_eligible(p, epi)) return ver >= 3 ? 3 : 2;
+    static int use256 = -1;
+    if (use256 < 0) { const char* e = getenv("LEAF_GEMM256"); use256 = (e && e[0] == '0') ? 0 : 1; }
+    return (use256 && p.N % 256 == 0 && (long)((p.M + 255) / 256) * (p.N / 256) >= 128) ? 1 : 0;
+}
+
 static void* g_stamps = nullptr;
 void leaf_gemm_set_stamps(void* p) { g_stamps = p; }
 

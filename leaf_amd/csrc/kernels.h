@@ -31,6 +31,7 @@ struct GemmArgs {
 
 hipError_t leaf_launch_gemm(const GemmArgs& p, int dtype, int epi, hipStream_t s);
 void leaf_gemm_set_stamps(void* p);
+int leaf_gemm_family(const GemmArgs& p, int epi);   // 0 = 128^2, 1 = 256^2 two-stage, 2 = ring, 3 = persistent ring
 // 256x256 4-stage LDS-DMA ring kernel (gemm256.hip); eligible() says whether a problem may use it
 bool leaf_gemm256_eligible(const GemmArgs& p, int epi);
 hipError_t leaf_launch_gemm256(const GemmArgs& p, int dtype, int epi, hipStream_t s);
