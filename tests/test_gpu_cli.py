@@ -42,3 +42,17 @@ def test_hf_key_roundtrip_gives_same_embeddings():
     m2 = LeafCLIPText(get_config("tiny-test")).load_state_dict(hf)
     toks = O.synthetic_tokens(5, seed=1)
     assert np.array_equal(m.encode_text(toks).cpu().numpy(), m2.encode_text(toks).cpu().numpy())
+
+
+def test_eval_textfare_script(tmp_path, monkeypatch):
+    """eval_textfare.py equivalent (reference eval_textfare.py:112-149): clean loss is exactly 0 when the two models
+    coincide, the attack can only raise the loss, and the CSV has the reference's columns."""
+    import eval_textfare
+    monkeypatch.chdir(tmp_path)
+    (tmp_path / "caps.txt").write_text("a photo of a cat\nthe red car on the street\ntwo people in the park\nx\n")
+    rows = eval_textfare.main(["--model", "tiny-test-quickgelu", "--texts", str(tmp_path / "caps.txt"), "--rho", "12",
+                               "--k", "2", "--n-test", "4", "--batch-size", "3"])
+    assert len(rows) == 4 and all(r["textfare_clean"] == 0.0 for r in rows)
+    assert all(r["textfare_adv"] >= 0.0 for r in rows) and any(r["textfare_adv"] > 0.0 for r in rows)
+    out = list((tmp_path / "results_textfare").glob("*_leaf_k2_rho_12.csv"))
+    assert len(out) == 1 and out[0].read_text().splitlines()[0] == "sentence,adv_sentence,textfare_clean,textfare_adv"
