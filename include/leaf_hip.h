@@ -44,6 +44,9 @@ int leaf_version(void);
 int leaf_text_create(const leaf_text_cfg* cfg, int fwd_dtype, leaf_text_t* out);
 void leaf_text_destroy(leaf_text_t h);
 int leaf_text_set_chunk(leaf_text_t h, int seqs_per_chunk); /* sequences processed per pass through the layers */
+/* options: "chunk" (as above), "last_layer_trim" (0/1, default 1: the last block's attention output, out-projection and
+ * MLP are computed for the pooled EOT row only -- exact, every op after attention is row-wise) */
+int leaf_text_set_option(leaf_text_t h, const char* name, int value);
 
 /* flat parameter layout */
 size_t leaf_text_param_count(leaf_text_t h);

@@ -21,6 +21,7 @@ _SIGS = {
     "leaf_text_create": (C.c_int, [C.POINTER(TextCfgC), C.c_int, C.POINTER(C.c_void_p)]),
     "leaf_text_destroy": (None, [C.c_void_p]),
     "leaf_text_set_chunk": (C.c_int, [C.c_void_p, C.c_int]),
+    "leaf_text_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "leaf_text_param_count": (C.c_size_t, [C.c_void_p]),
     "leaf_text_decay_count": (C.c_size_t, [C.c_void_p]),
     "leaf_text_num_tensors": (C.c_int, [C.c_void_p]),

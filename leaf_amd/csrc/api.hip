@@ -38,6 +38,7 @@ extern "C" int leaf_text_create(const leaf_text_cfg* cfg, int fwd_dtype, leaf_te
     h->cfg = *cfg;
     h->fwd_dtype = fwd_dtype;
     h->chunk = 4096;
+    { const char* e = getenv("LEAF_LAST_TRIM"); h->last_trim = (e && e[0] == '0') ? 0 : 1; }
     {   // gradient path: fp16 + per-step power-of-two loss scale unless LEAF_GRAD_DTYPE=bf16
         const char* e = getenv("LEAF_GRAD_DTYPE");
         h->grad_dtype = (e && (e[0] == 'b' || e[0] == 'B')) ? LEAF_DTYPE_BF16 : LEAF_DTYPE_FP16;
@@ -88,6 +89,14 @@ extern "C" int leaf_text_set_chunk(leaf_text_t h, int seqs) {
     if (!h || seqs < 1) { leaf_set_error("bad chunk"); return 1; }
     h->chunk = seqs;
     return 0;
+}
+
+extern "C" int leaf_text_set_option(leaf_text_t h, const char* name, int value) {
+    if (!h || !name) { leaf_set_error("null argument"); return 1; }
+    if (!strcmp(name, "chunk")) return leaf_text_set_chunk(h, value);
+    if (!strcmp(name, "last_layer_trim")) { h->last_trim = value ? 1 : 0; return 0; }
+    leaf_set_error("unknown option '%s'", name);
+    return 1;
 }
 
 extern "C" size_t leaf_text_param_count(leaf_text_t h) { return h->n_params; }
@@ -189,12 +198,13 @@ struct FwdBuf {
     uint16_t* a;   // [rows,d]   LN output / attention output (aliased)
     uint16_t* qkv; // [rows,3d]
     uint16_t* hh;  // [rows,4d]
+    int32_t* eot;  // [seqs] pooled position per sequence (last-layer trimming)
 };
 
 size_t fwd_chunk_bytes(const leaf_text* h, int cs) {
     const size_t rows = (size_t)cs * h->cfg.context_length, d = h->cfg.width;
     Carver c(nullptr, 0);
-    c.take(rows * d * 4); c.take(rows * d * 2); c.take(rows * 3 * d * 2); c.take(rows * 4 * d * 2);
+    c.take(rows * d * 4); c.take(rows * d * 2); c.take(rows * 3 * d * 2); c.take(rows * 4 * d * 2); c.take(rows * 4);
     return align_up(c.off, 256);
 }
 
@@ -205,6 +215,7 @@ FwdBuf carve_fwd(const leaf_text* h, Carver& c, int cs) {
     b.a = (uint16_t*)c.take(rows * d * 2);
     b.qkv = (uint16_t*)c.take(rows * 3 * d * 2);
     b.hh = (uint16_t*)c.take(rows * 4 * d * 2);
+    b.eot = (int32_t*)c.take(rows * 4);   // one per sequence; a sequence has >= 1 row
     return b;
 }
 
@@ -231,8 +242,30 @@ int forward_chunk(const leaf_text* h, const float* P, const uint16_t* W, const i
         if (kv.kv_write) b.qkv = kv.kv_write + (size_t)l * kv.kv_stride;
         if (leaf_gemm(dt, EPI_STORE_T, b.a, d, W + h->w16_qkv(l), d, b.qkv, 3 * d, P + o.qkv_b, nullptr, rows, 3 * d, d, 0, s))
             return 1;
-        LEAF_TRY(leaf_launch_attention_fwd(b.qkv, kv.kv_read ? kv.kv_read + (size_t)l * kv.kv_stride : nullptr, b.a, cs, map,
-                                           c.heads, d, dt, s));
+        const void* kvl = kv.kv_read ? kv.kv_read + (size_t)l * kv.kv_stride : nullptr;
+        if (l == c.layers - 1 && !out) break;          // K/V-only pass (clean captions for the cache): nothing consumes the rest
+        if (l == c.layers - 1 && h->last_trim && !kv.kv_write) {
+            // Last block: only the pooled row (first maximum token id = EOT) of each sequence reaches the output, and every later op is
+            // row-wise, so attention output, out-projection, LN2 and the MLP run on ONE row per sequence (bit-identical).
+            // Scratch: after attention and the gather, the qkv and fc buffers (carved back to back, 14*d*rows bytes) are
+            // dead; the gathered residual rows xg (fp32 [cs,d]) and the MLP hidden rows hb (16-bit [cs,4d]) need
+            // 12*d*cs <= 14*d*rows bytes.
+            LEAF_TRY(leaf_launch_eot_positions(tokens, b.eot, cs, map, s));
+            LEAF_TRY(leaf_launch_attention_fwd(b.qkv, kvl, b.a, cs, map, c.heads, d, dt, s, b.eot));
+            float* xg = (float*)b.qkv;
+            uint16_t* hb = (uint16_t*)((char*)b.qkv + align_up((size_t)cs * d * 4, 256));
+            LEAF_TRY(leaf_launch_gather_rows(b.x, b.eot, xg, cs, map, d, s));
+            if (leaf_gemm(dt, EPI_RESID_F32, b.a, d, W + h->w16_out(l), d, xg, d, P + o.out_b, nullptr, cs, d, d, 0, s)) return 1;
+            LEAF_TRY(leaf_launch_layernorm(xg, P + o.ln2_w, P + o.ln2_b, c.ln_eps, b.a, cs, d, dt, s));
+            if (leaf_gemm(dt, EPI_ACT_T, b.a, d, W + h->w16_fc(l), d, hb, 4 * d, P + o.fc_b, nullptr, cs, 4 * d, d, c.activation, s))
+                return 1;
+            if (leaf_gemm(dt, EPI_RESID_F32, hb, 4 * d, W + h->w16_proj(l), 4 * d, xg, d, P + o.proj_b, nullptr, cs, d, 4 * d, 0, s))
+                return 1;
+            LEAF_TRY(leaf_launch_pool_project(xg, tokens, P + h->lnf_w, P + h->lnf_b, c.ln_eps, P + h->text_proj, out, nullptr,
+                                              nullptr, cs, map, d, c.embed_dim, normalize, s, /*rows_are_pooled=*/1));
+            return 0;
+        }
+        LEAF_TRY(leaf_launch_attention_fwd(b.qkv, kvl, b.a, cs, map, c.heads, d, dt, s));
         if (leaf_gemm(dt, EPI_RESID_F32, b.a, d, W + h->w16_out(l), d, b.x, d, P + o.out_b, nullptr, rows, d, d, 0, s))
             return 1;
         LEAF_TRY(leaf_launch_layernorm(b.x, P + o.ln2_w, P + o.ln2_b, c.ln_eps, b.a, rows, d, dt, s));

@@ -56,7 +56,8 @@ __device__ __forceinline__ typename TT::vec8 load_vt_frag(const char* vlds, int 
 
 template <class TT, bool USE_TR>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const u16* __restrict__ qkv, const u16* __restrict__ kv_base,
-                                                       u16* __restrict__ out, int n_items, RowMap map, int heads, int d) {
+                                                       u16* __restrict__ out, int n_items, RowMap map, int heads, int d,
+                                                       const int32_t* __restrict__ eot_pos) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int item = blockIdx.x * 4 + wid;
@@ -74,7 +75,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const u16* __restrict__ q
     auto rowptr = [&](int pos) { return pos < pfx ? cached + (size_t)pos * ld : own + (size_t)(pos - pfx) * ld; };
     const int r16 = lane & 15, g = lane >> 4;
     const int nt = (ctx + 15) >> 4;
-    const int qt0 = pfx >> 4;                       // query tiles below the prefix are not needed
+    // query tiles below the prefix are not needed; with eot_pos (last layer: only the pooled row is consumed downstream)
+    // just the tile holding that position, whose row is written to out[sequence]
+    const int eot = eot_pos ? eot_pos[n] : -1;
+    const int qt0 = eot >= 0 ? eot >> 4 : pfx >> 4;
+    const int qt1 = eot >= 0 ? eot >> 4 : nt - 1;
 
     // ---- V rows -> LDS (row-major), rows ctx..95 zero
     for (int idx = lane; idx < 96 * 8; idx += 64) {
@@ -97,7 +102,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const u16* __restrict__ q
 
 #pragma unroll
     for (int qt = 0; qt < MAXT; ++qt) {
-        if (qt < nt && qt >= qt0) {
+        if (qt < nt && qt >= qt0 && qt <= qt1) {
             const int qidx = qt * 16 + r16;
             int qv = qidx < ctx ? qidx : ctx - 1;
             qv = qv < pfx ? pfx : qv;
@@ -162,8 +167,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const u16* __restrict__ q
                     }
                 }
             }
-            if (qidx < ctx && qidx >= pfx) {
-                u16* op = out + ((size_t)row_s + qidx - pfx) * d + h * HD + 4 * g;
+            if (eot >= 0 ? qidx == eot : (qidx < ctx && qidx >= pfx)) {
+                u16* op = out + (eot >= 0 ? (size_t)n : (size_t)row_s + qidx - pfx) * d + h * HD + 4 * g;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt)
                     *(uint2*)(op + dt * 16) = pack4<TT>(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const u16* __restrict__ q
 }  // namespace
 
 hipError_t leaf_launch_attention_fwd(const void* qkv, const void* kv_base, void* out, int n_seq, RowMap map, int heads,
-                                     int d, int dtype, hipStream_t s) {
+                                     int d, int dtype, hipStream_t s, const int32_t* eot_pos) {
     if (d != heads * HD || map.ctx > 16 * MAXT || map.ctx < 1) return hipErrorInvalidValue;
     static int use_tr = -1;
     if (use_tr < 0) {
@@ -193,7 +198,7 @@ hipError_t leaf_launch_attention_fwd(const void* qkv, const void* kv_base, void*
                                 (int)lds);                                                                  \
             attr = true;                                                                                    \
         }                                                                                                   \
-        hipLaunchKernelGGL((attn_fwd_kernel<TT, TR>), grid, blk, lds, s, (const u16*)qkv, (const u16*)kv_base, (u16*)out, items, map, heads, d); \
+        hipLaunchKernelGGL((attn_fwd_kernel<TT, TR>), grid, blk, lds, s, (const u16*)qkv, (const u16*)kv_base, (u16*)out, items, map, heads, d, eot_pos); \
     } while (0)
     if (dtype == LEAF_F16) { if (use_tr) LEAF_ATTN(F16, true); else LEAF_ATTN(F16, false); }
     else                   { if (use_tr) LEAF_ATTN(BF16, true); else LEAF_ATTN(BF16, false); }

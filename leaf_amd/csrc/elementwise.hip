@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void pool_project_kernel(const float* __restri
                                                            float eps, const float* __restrict__ proj,
                                                            float* __restrict__ out, float* __restrict__ pooled,
                                                            int32_t* __restrict__ eot_idx, int n_seq, RowMap map, int d,
-                                                           int D, int normalize) {
+                                                           int D, int normalize, int rows_are_pooled) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* xs = (float*)smem;               // [PR][d]
     float* red = xs + PR * d;               // [4][PR]
@@ -120,7 +120,8 @@ __global__ __launch_bounds__(256) void pool_project_kernel(const float* __restri
             if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
         }
         if (eot_idx && lane == 0) eot_idx[n] = bi;
-        const float* xi = x + ((size_t)seq_row(map, sg) + bi - pfx) * d;
+        // rows_are_pooled: x already holds ONE row per sequence (the EOT row, last-layer trimming)
+        const float* xi = rows_are_pooled ? x + (size_t)n * d : x + ((size_t)seq_row(map, sg) + bi - pfx) * d;
         float4 v[MAXCH];
         float s = 0.f;
 #pragma unroll
@@ -254,6 +255,33 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ fe
         for (int j = tid; j < D; j += 256) best_feat[(size_t)b * D + j] = f[j];
 }
 
+__global__ __launch_bounds__(256) void eot_positions_kernel(const int32_t* __restrict__ tokens, int32_t* __restrict__ eot_pos,
+                                                            int n_seq, RowMap map) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= n_seq) return;
+    const int sg = map.s0 + n, pfx = seq_prefix(map, sg), end = pfx + seq_len(map, sg);
+    int bv = -2147483647 - 1, bi = pfx;
+    for (int p = pfx + lane; p < end; p += 64) {
+        int t = tokens[(size_t)sg * map.ctx + p];
+        if (t > bv) { bv = t; bi = p; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        int ov = __shfl_xor(bv, o, 64), oi = __shfl_xor(bi, o, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) eot_pos[n] = bi;
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ x, const int32_t* __restrict__ eot_pos,
+                                                          float* __restrict__ out, int n_seq, RowMap map, int d) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= n_seq) return;
+    const int sg = map.s0 + n;
+    const float* src = x + ((size_t)seq_row(map, sg) + eot_pos[n] - seq_prefix(map, sg)) * d;
+    for (int c = lane; c < (d >> 2); c += 64) *(float4*)(out + (size_t)n * d + 4 * c) = *(const float4*)(src + 4 * c);
+}
+
 template <class TT>
 __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, u16* __restrict__ dst, size_t n4) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -295,7 +323,7 @@ hipError_t leaf_launch_layernorm(const float* x, const float* g, const float* b,
 
 hipError_t leaf_launch_pool_project(const float* x, const int32_t* tokens, const float* g, const float* b, float eps,
                                     const float* proj, float* out, float* pooled, int32_t* eot_idx, int n_seq, RowMap map,
-                                    int d, int D, int normalize, hipStream_t s) {
+                                    int d, int D, int normalize, hipStream_t s, int rows_are_pooled) {
     if (d % 4 || d > 256 * MAXCH || D > 256 * JJMAX) return hipErrorInvalidValue;
     size_t lds = (size_t)(PR * d + 4 * PR) * sizeof(float);
     static bool attr = false;
@@ -304,7 +332,18 @@ hipError_t leaf_launch_pool_project(const float* x, const int32_t* tokens, const
         attr = true;
     }
     hipLaunchKernelGGL(pool_project_kernel, dim3((n_seq + PR - 1) / PR), dim3(256), lds, s, x, tokens, g, b, eps, proj,
-                       out, pooled, eot_idx, n_seq, map, d, D, normalize);
+                       out, pooled, eot_idx, n_seq, map, d, D, normalize, rows_are_pooled);
+    return hipGetLastError();
+}
+
+hipError_t leaf_launch_eot_positions(const int32_t* tokens, int32_t* eot_pos, int n_seq, RowMap map, hipStream_t s) {
+    hipLaunchKernelGGL(eot_positions_kernel, dim3((n_seq + 3) / 4), dim3(256), 0, s, tokens, eot_pos, n_seq, map);
+    return hipGetLastError();
+}
+
+hipError_t leaf_launch_gather_rows(const float* x, const int32_t* eot_pos, float* out, int n_seq, RowMap map, int d,
+                                   hipStream_t s) {
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((n_seq + 3) / 4), dim3(256), 0, s, x, eot_pos, out, n_seq, map, d);
     return hipGetLastError();
 }
 

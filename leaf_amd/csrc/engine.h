@@ -21,6 +21,7 @@ struct leaf_text {
     leaf_text_cfg cfg;
     int fwd_dtype;
     int chunk;  // sequences per pass
+    int last_trim;   // last transformer block: attention output / out-proj / MLP only for the pooled (EOT) row
     int grad_dtype;  // 16-bit type of the gradient path: LEAF_F16 (loss-scaled, default) or LEAF_BF16
     std::vector<TensorInfo> tensors;
     std::vector<LayerOff> layer;

@@ -49,7 +49,7 @@ hipError_t leaf_launch_layernorm(const float* x, const float* g, const float* b,
 // the normalised EOT row and eot_idx the pooled position (training stash).
 hipError_t leaf_launch_pool_project(const float* x, const int32_t* tokens, const float* g, const float* b, float eps,
                                     const float* proj, float* out, float* pooled, int32_t* eot_idx, int n_seq, RowMap map,
-                                    int d, int D, int normalize, hipStream_t s);
+                                    int d, int D, int normalize, hipStream_t s, int rows_are_pooled = 0);
 // loss[b,r] per objective, arg-max over rho (first maximum wins), best feature gather
 hipError_t leaf_launch_score(const float* feat, const float* anchor, int B, int rho, int D, int objective,
                              int32_t* best_idx, float* best_feat, float* loss, hipStream_t s);
@@ -58,8 +58,15 @@ hipError_t leaf_launch_cast(const float* src, void* dst, size_t n, int dtype, hi
 
 // ---- attention (attention.hip): qkv [rows, 3d] 16-bit (q | k | v, heads inside each), out [rows, d]
 // kv_base: this layer's qkv rows of the clean captions (prefix mode, map.prefix != null) or null
+// eot_pos (device, per sequence of the launch, absolute position) != null: compute only that query row of each sequence
+// and write it to out[sequence] (last-layer trimming)
 hipError_t leaf_launch_attention_fwd(const void* qkv, const void* kv_base, void* out, int n_seq, RowMap map, int heads,
-                                     int d, int dtype, hipStream_t s);
+                                     int d, int dtype, hipStream_t s, const int32_t* eot_pos = nullptr);
+// eot_pos[n] = first index of the maximum token id among the kept positions (torch argmax pooling)
+hipError_t leaf_launch_eot_positions(const int32_t* tokens, int32_t* eot_pos, int n_seq, RowMap map, hipStream_t s);
+// out[n,:] = x[row of position eot_pos[n] of sequence n,:]   (fp32)
+hipError_t leaf_launch_gather_rows(const float* x, const int32_t* eot_pos, float* out, int n_seq, RowMap map, int d,
+                                   hipStream_t s);
 
 // ---- training-only kernels (train.hip)
 // dst[c, r] = (16-bit) src[r, c], zero padded to rpad columns.  kinds: 0 bf16, 1 fp16, 2 fp32 (source only)

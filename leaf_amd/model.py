@@ -125,6 +125,11 @@ class LeafCLIPText:
         except Exception:
             pass
 
+    def set_option(self, name: str, value: int):
+        """Engine switches (leaf_text_set_option): 'chunk', 'last_layer_trim'."""
+        _lib.check(self._lib.leaf_text_set_option(self._h, name.encode(), int(value)), "leaf_text_set_option")
+        return self
+
     # ------------------------------------------------------------------ nn.Module look-alikes
     def eval(self):
         self.training = False

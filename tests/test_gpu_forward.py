@@ -221,3 +221,19 @@ def test_prefix_reuse_is_bit_exact(torch_mod):
     assert torch_mod.equal(feats, m.encode_text(base))
     i1, f1, l1 = m.score_candidates(flat, anchor, rho, "l2", want_loss=True, seq_lens=lens, prefix_lens=pl.reshape(-1), kv=kv)
     assert torch_mod.equal(l0, l1) and torch_mod.equal(i0, i1) and torch_mod.equal(f0, f1)
+
+
+def test_last_layer_trim_is_bit_exact(torch_mod):
+    """Computing the last block's attention output / out-projection / MLP only for the pooled row changes nothing."""
+    for model, seed in (("tiny-test-quickgelu", 12), ("ViT-L-14", 1)):
+        m = _model(model, seed)
+        toks = O.synthetic_tokens(23, seed=41, min_len=1, max_len=74)
+        on = m.encode_text(toks).cpu().numpy()
+        onn = m.encode_text(toks, normalize=True).cpu().numpy()
+        m.set_option("last_layer_trim", 0)
+        off = m.encode_text(toks).cpu().numpy()
+        offn = m.encode_text(toks, normalize=True).cpu().numpy()
+        assert np.array_equal(on, off) and np.array_equal(onn, offn)
+        m.trim_rows = False                      # dense rows + trimming
+        m.set_option("last_layer_trim", 1)
+        assert np.array_equal(m.encode_text(toks).cpu().numpy(), off)
