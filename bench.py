@@ -96,8 +96,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("LEAF_BENCH_FORCE_DIST") == "1"   # the latter rehearses the RCCL path on 1 GPU
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     cfg = get_config(args.model)
@@ -120,7 +122,7 @@ def main():
     base = base.to(dev)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -140,7 +142,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
@@ -202,7 +204,7 @@ def main():
             oracle_name = args.model if args.model in ("ViT-L-14", "ViT-L-14-quickgelu", "ViT-H-14", "ViT-g-14", "ViT-bigG-14") else "ViT-L-14"
             out["cpu_baseline"] = cpu_baseline(oracle_name, args.rho, args.k_adv, args.cpu_batch, seed=1234)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

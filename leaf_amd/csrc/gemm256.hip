@@ -22,7 +22,10 @@
 
 namespace {
 
-constexpr int BM = 256, BN = 256, BKS = 32, NSTAGE = 4;
+#ifndef LEAF_NSTAGE
+#define LEAF_NSTAGE 4
+#endif
+constexpr int BM = 256, BN = 256, BKS = 32, NSTAGE = LEAF_NSTAGE;   // ring slots (4: 128 KiB, 5: all 160 KiB of LDS)
 constexpr int PART = BM * BKS * 2;      // 16 KiB: one operand of one stage
 constexpr int STAGE = 2 * PART;         // 32 KiB
 constexpr int RING = NSTAGE * STAGE;    // 128 KiB
@@ -125,13 +128,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_ring_kernel(GemmArgs p) {
     // issuing them back to back right after the barrier makes all 8 waves queue on the CU's address unit at once and
     // the MFMAs behind them wait (an LDS-DMA issue costs 60-185 cycles in a busy phase, MI355X_MICROARCH.md).
 #define SB __builtin_amdgcn_sched_barrier(0);
+#define SLOT(x) (NSTAGE == 4 ? ((x) & 3) : ((x) % NSTAGE))
 #define STEP(PREV, CUR, tt, cnt, issue)                                                                      \
     SYNC_STAGE(cnt)                                                                                          \
-    READ_FRAGS(CUR, (tt) & 3)                                                                                \
+    READ_FRAGS(CUR, SLOT(tt))                                                                                \
     SB                                                                                                       \
     {                                                                                                        \
-        char* sa_ = smem + (((tt) + 3) & 3) * STAGE + piece;                                                 \
-        const int k0_ = ((tt) + 3) * BKS;                                                                    \
+        char* sa_ = smem + SLOT((tt) + NSTAGE - 1) * STAGE + piece;                                          \
+        const int k0_ = ((tt) + NSTAGE - 1) * BKS;                                                                    \
         MROW(PREV, 4, PREV##x4) SB                                                                           \
         if (issue) DMA16(a0 + k0_, sa_, LEAF_A_AUX);                                                         \
         SB MROW(PREV, 5, PREV##x5) SB                                                                        \
@@ -144,18 +148,38 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_ring_kernel(GemmArgs p) {
     }                                                                                                        \
     MFMA_H1(CUR)
 
-    const int nt = p.K / BKS;   // even, >= 6 (host-checked)
+    const int nt = p.K / BKS;   // even, >= 8 (host-checked)
     STAMP(0)
     ISSUE_STAGE(0, 0)
     ISSUE_STAGE(1, BKS)
     ISSUE_STAGE(2, 2 * BKS)
+#if LEAF_NSTAGE == 5
+    ISSUE_STAGE(3, 3 * BKS)
+    SYNC_STAGE(12)
+    STAMP(1)
+    ISSUE_STAGE(4, 4 * BKS)
+#else
     SYNC_STAGE(8)
     STAMP(1)
     ISSUE_STAGE(3, 3 * BKS)
+#endif
     READ_FRAGS(F, 0)
     __builtin_amdgcn_sched_barrier(0);
     MFMA_H1(F)
     int t = 1;
+#if LEAF_NSTAGE == 5
+    for (; t <= nt - 7; t += 2) {        // steps t, t+1 <= nt-6: four stages in flight, a new one issued each step
+        STEP(F, G, t, 12, true)
+        STEP(G, F, t + 1, 12, true)
+    }
+    STEP(F, G, t, 12, true)              // t = nt-5 (last issue)
+    STAMP(2)
+    STEP(G, F, t + 1, 12, false)         // nt-4
+    STEP(F, G, t + 2, 8, false)          // nt-3
+    STEP(G, F, t + 3, 4, false)          // nt-2
+    STEP(F, G, t + 4, 0, false)          // nt-1
+    MFMA_H2(G)
+#else
     for (; t <= nt - 5; t += 2) {        // steps t, t+1 <= nt-4: counted wait 8, a new stage issued each step
         STEP(F, G, t, 8, true)
         STEP(G, F, t + 1, 8, true)
@@ -165,6 +189,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_ring_kernel(GemmArgs p) {
     STEP(G, F, t + 1, 4, false)          // nt-2
     STEP(F, G, t + 2, 0, false)          // nt-1
     MFMA_H2(G)
+#endif
     STAMP(3)
 #undef DMA16
 #undef ISSUE_STAGE
@@ -175,6 +200,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_ring_kernel(GemmArgs p) {
 #undef SYNC_STAGE
 #undef STEP
 #undef SB
+#undef SLOT
 #undef LD
 
     // ---------------- epilogue through this wave's private LDS slice (ring is idle after one more barrier)
@@ -306,7 +332,7 @@ hipError_t launch256(const GemmArgs& p, int epi, hipStream_t s) {
 bool leaf_gemm256_eligible(const GemmArgs& p, int epi) {
     // at least half a wave of 256^2 tiles over the 256 CUs, else the 128^2 kernel fills the chip better (weight gradients)
     const long tiles = (long)((p.M + BM - 1) / BM) * (p.N / BN);
-    return p.N % BN == 0 && tiles >= 128 && p.K % (2 * BKS) == 0 && p.K >= 6 * BKS && p.ldc % 8 == 0 && epi != EPI_ACTGRAD_T;
+    return p.N % BN == 0 && tiles >= 128 && p.K % (2 * BKS) == 0 && p.K >= 8 * BKS && p.ldc % 8 == 0 && epi != EPI_ACTGRAD_T;
 }
 
 hipError_t leaf_launch_gemm256(const GemmArgs& p, int dtype, int epi, hipStream_t s) {

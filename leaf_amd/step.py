@@ -18,6 +18,7 @@ the AdamW kernel's ``grad_scale``).
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -101,7 +102,7 @@ def search_synthetic(model, anchor: torch.Tensor, base: torch.Tensor, cfg: StepC
 def allreduce_grads(model) -> float:
     """ONE flat all-reduce (sum) of the gradient buffer over RCCL; returns the factor AdamW must apply."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("LEAF_BENCH_FORCE_DIST") == "1"):
         dist.all_reduce(model.grads, op=dist.ReduceOp.SUM)
         return 1.0 / dist.get_world_size()
     return 1.0
