@@ -358,10 +358,12 @@ hipError_t launch_t(const GemmArgs& p, int epi, hipStream_t s) {
 
 }  // namespace
 
-// which kernel leaf_launch_gemm will pick: 0 = gemm_nt_kernel (128^2), 1 = gemm_nt256_kernel, 2 = ring, 3 = persistent
+// which kernel leaf_launch_gemm will pick: 0 = gemm_nt_kernel (128^2), 1 = gemm_nt256_kernel, 2 = ring, 3 = persistent,
+// 4 = half-stage ring (gemm256h.hip, the default where eligible)
 int leaf_gemm_family(const GemmArgs& p, int epi) {
     static int ver = -1;
-    if (ver < 0) { const char* e = getenv("LEAF_GEMM_V"); ver = e ? atoi(e) : 2; }
+    if (ver < 0) { const char* e = getenv("LEAF_GEMM_V"); ver = e ? atoi(e) : 4; }
+    if (ver == 4 && p.M > 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && leaf_gemm256h_eligible(p, epi)) return 4;
     if (ver >= 2 && p.M > 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && leaf_gemm256_eligible(p, epi)) return ver >= 3 ? 3 : 2;
     static int use256 = -1;
     if (use256 < 0) { const char* e = getenv("LEAF_GEMM256"); use256 = (e && e[0] == '0') ? 0 : 1; }
@@ -374,12 +376,15 @@ void leaf_gemm_set_stamps(void* p) { g_stamps = p; }
 hipError_t leaf_launch_gemm(const GemmArgs& p_in, int dtype, int epi, hipStream_t s) {
     GemmArgs p = p_in;
     p.stamps = g_stamps;
-    // LEAF_GEMM_V: 1 = previous-generation kernels, 2 = ring kernel (default), 3 = persistent ring (gemm256p.hip;
-    // measured 3-4 % SLOWER than 2 on the text-tower shapes: kept for A/B runs)
+    // LEAF_GEMM_V: 1 = previous-generation kernels, 2 = 32-deep ring kernel, 3 = persistent ring (gemm256p.hip; measured
+    // 3-4 % SLOWER than 2 on the text-tower shapes), 4 = 64-deep half-stage ring with full-line DMA pieces (gemm256h.hip,
+    // default: +8 % over 2 on the layer's four GEMMs); shapes a kernel cannot take fall through to the next one down
     static int ver = -1;
-    if (ver < 0) { const char* e = getenv("LEAF_GEMM_V"); ver = e ? atoi(e) : 2; }
+    if (ver < 0) { const char* e = getenv("LEAF_GEMM_V"); ver = e ? atoi(e) : 4; }
+    if (ver == 4 && p.M > 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && leaf_gemm256h_eligible(p, epi))
+        return leaf_launch_gemm256h(p, dtype, epi, s);
     if (ver >= 2 && p.M > 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && leaf_gemm256_eligible(p, epi))
-        return ver >= 3 ? leaf_launch_gemm256p(p, dtype, epi, s) : leaf_launch_gemm256(p, dtype, epi, s);
+        return ver == 3 ? leaf_launch_gemm256p(p, dtype, epi, s) : leaf_launch_gemm256(p, dtype, epi, s);
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.N % BN || p.K % BK || p.lda % 8 || p.ldb % 8 || p.ldc % 4)
         return hipErrorInvalidValue;
     return dtype == LEAF_F16 ? launch_t<F16>(p, epi, s) : launch_t<BF16>(p, epi, s);

@@ -1,0 +1,278 @@
+// NT GEMM, 256x256 output tile, FULL-LINE LDS-DMA pieces in a 5-slot half-stage ring -- experiment (LEAF_GEMM_V=4).
+//
+// Same wave tiling, software-pipelined fragment reads, spread DMA issue and LDS-staged epilogue as gemm256.hip, but K is
+// streamed as 64-deep HALF-stages: one half-stage = ONE operand panel of 256 rows x 64 k (32 KiB, rows of 128 B), so a
+// DMA piece is 8 rows x 128 B = whole 128-B lines (tools/dma_probe*.hip: 45 B/clk/CU L2-hit fill against 25 B/clk/CU
+// for the 16 x 64 B pieces of the 32-deep stages).  Five half-slots = all 160 KiB of LDS: while tile t (A_t, B_t) is
+// multiplied, A_{t+1}, B_{t+1} and A_{t+2} are in flight; ONE barrier per 64 k.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 64, NSLOT = 5;
+constexpr int HALF = BM * BK * 2;       // 32 KiB: one operand panel of one K tile
+constexpr int RING = NSLOT * HALF;      // 160 KiB
+constexpr int SLICE = 16384;            // epilogue staging per wave (inside the idle ring)
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+
+__device__ __forceinline__ int lds_off_h(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+template <class TT, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+    const int tiles_n = p.N / BN;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (logical / tiles_n) * BM, n0 = (logical % tiles_n) * BN;
+
+    // ---- DMA sources: wave w moves pieces 4w..4w+3 (8 rows x 128 B) of whichever panel a half-stage carries
+    const int prow = lane >> 3;
+    const int schunk = (lane & 7) ^ prow;
+    const char* __restrict__ A = (const char*)p.A;
+    const char* __restrict__ B = (const char*)p.B;
+    auto arow = [&](int j) { int r = m0 + wid * 32 + 8 * j + prow; return r < p.M ? r : p.M - 1; };
+    // 32-bit byte offsets from the (uniform) operand bases: saddr + voffset addressing, 5 VGPRs instead of 10
+    const unsigned a0 = (unsigned)arow(0) * (unsigned)p.lda * 2u + schunk * 16;
+    const unsigned a1 = (unsigned)arow(1) * (unsigned)p.lda * 2u + schunk * 16;
+    const unsigned a2 = (unsigned)arow(2) * (unsigned)p.lda * 2u + schunk * 16;
+    const unsigned a3 = (unsigned)arow(3) * (unsigned)p.lda * 2u + schunk * 16;
+    const unsigned b0 = (unsigned)(n0 + wid * 32 + prow) * (unsigned)p.ldb * 2u + schunk * 16;
+    const unsigned bstep = 16u * (unsigned)p.ldb;   // 8 rows, bytes
+    const int piece = wid * 4096;
+#define DMA16(src, dst) __builtin_amdgcn_global_load_lds((glb_void_t*)(src), (lds_void_t*)(dst), 16, 0, 0)
+    // piece q (0..3) of half-stage u: u even = A panel of K tile u/2, u odd = B panel
+    // (so = byte offset of the ring slot that half-stage lands in, kt = its K tile)
+#define ISSUE_A(so, kt, q) DMA16(A + (size_t)((kt) * (BK * 2)) + ((q) == 0 ? a0 : (q) == 1 ? a1 : (q) == 2 ? a2 : a3), smem + (so) + piece + (q) * 1024)
+#define ISSUE_B(so, kt, q) DMA16(B + (size_t)((kt) * (BK * 2) + (q) * bstep) + b0, smem + (so) + piece + (q) * 1024)
+#define ISSUE_HALF_A(so, kt) ISSUE_A(so, kt, 0); ISSUE_A(so, kt, 1); ISSUE_A(so, kt, 2); ISSUE_A(so, kt, 3);
+#define ISSUE_HALF_B(so, kt) ISSUE_B(so, kt, 0); ISSUE_B(so, kt, 1); ISSUE_B(so, kt, 2); ISSUE_B(so, kt, 3);
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fkc = lane >> 4;
+    const int fo0 = lds_off_h(frow, fkc), fo1 = lds_off_h(frow, 4 + fkc);   // k-step 0 / 1 inside a 64-deep tile
+    const int xbase = wm * 128 * 128, wbase = wn * 64 * 128;
+    typedef typename TT::vec8 frag_t;
+    frag_t Fx0, Fx1, Fx2, Fx3, Fx4, Fx5, Fx6, Fx7, Fw0, Fw1, Fw2, Fw3;
+    frag_t Gx0, Gx1, Gx2, Gx3, Gx4, Gx5, Gx6, Gx7, Gw0, Gw1, Gw2, Gw3;
+#define LD(ptr) (*(const frag_t*)(ptr))
+    // fragments of one 32-deep k-step: A panel at ring offset sa, B panel at sb
+#define READ_FRAGS(P, sa, sb, fo)                                                                            \
+    {                                                                                                        \
+        const char* sa_ = smem + (sa) + xbase + (fo);                                                        \
+        const char* sb_ = smem + (sb) + wbase + (fo);                                                        \
+        P##w0 = LD(sb_); P##w1 = LD(sb_ + 2048); P##w2 = LD(sb_ + 4096); P##w3 = LD(sb_ + 6144);             \
+        P##x0 = LD(sa_); P##x1 = LD(sa_ + 2048); P##x2 = LD(sa_ + 4096); P##x3 = LD(sa_ + 6144);             \
+        P##x4 = LD(sa_ + 8192); P##x5 = LD(sa_ + 10240); P##x6 = LD(sa_ + 12288); P##x7 = LD(sa_ + 14336);   \
+    }
+#define MROW(P, i, xi)                                                                                       \
+    acc[i][0] = TT::mfma(P##w0, xi, acc[i][0]); acc[i][1] = TT::mfma(P##w1, xi, acc[i][1]);                   \
+    acc[i][2] = TT::mfma(P##w2, xi, acc[i][2]); acc[i][3] = TT::mfma(P##w3, xi, acc[i][3]);
+#define MFMA_H1(P) MROW(P, 0, P##x0) MROW(P, 1, P##x1) MROW(P, 2, P##x2) MROW(P, 3, P##x3)
+#define MFMA_H2(P) MROW(P, 4, P##x4) MROW(P, 5, P##x5) MROW(P, 6, P##x6) MROW(P, 7, P##x7)
+#define SB __builtin_amdgcn_sched_barrier(0);
+#define SYNC_TILE(cnt)                                                                                       \
+    SB                                                                                                       \
+    asm volatile("s_waitcnt vmcnt(" #cnt ") lgkmcnt(0)" ::: "memory");                                       \
+    __builtin_amdgcn_s_barrier();                                                                            \
+    asm volatile("" ::: "memory");
+    // one 32-deep k-step: fragments of (T, ks) are read first, the second half of the previous k-step's MFMAs covers
+    // their latency with the four DMA pieces of half-stage u spread in between (IS = issue macro or nothing)
+#define KSTEP(PREV, CUR, sa, sb, fo, IS0, IS1, IS2, IS3)                                                     \
+    READ_FRAGS(CUR, sa, sb, fo)                                                                              \
+    SB MROW(PREV, 4, PREV##x4) SB IS0                                                                        \
+    SB MROW(PREV, 5, PREV##x5) SB IS1                                                                        \
+    SB MROW(PREV, 6, PREV##x6) SB IS2                                                                        \
+    SB MROW(PREV, 7, PREV##x7) SB IS3                                                                        \
+    SB MFMA_H1(CUR)
+#define NOP_
+
+    const int nt = p.K / BK;   // K tiles, >= 4 (host-checked)
+    // half-stage u lives in ring slot u % 5; the offsets below are uniform and advance by two slots per K tile
+#define ADV(x) { x += 2 * HALF; if (x >= RING) x -= RING; }
+    int sa = 0, sb = HALF;               // slots of (A, B) of the tile being multiplied: half-stages 2T, 2T+1
+    int i0 = 3 * HALF, i1 = 4 * HALF;    // slots of the half-stages requested during tile T: 2T+3 (B), 2T+4 (A)
+    ISSUE_HALF_A(0, 0) ISSUE_HALF_B(HALF, 0) ISSUE_HALF_A(2 * HALF, 1)
+    // ---- tile 0
+    SYNC_TILE(4)
+    READ_FRAGS(G, sa, sb, fo0)
+    SB ISSUE_B(i0, 1, 0); ISSUE_B(i0, 1, 1); SB
+    MROW(G, 0, Gx0) MROW(G, 1, Gx1) SB ISSUE_B(i0, 1, 2); ISSUE_B(i0, 1, 3); SB MROW(G, 2, Gx2) MROW(G, 3, Gx3)
+    KSTEP(G, F, sa, sb, fo1, ISSUE_A(i1, 2, 0);, ISSUE_A(i1, 2, 1);, ISSUE_A(i1, 2, 2);, ISSUE_A(i1, 2, 3);)
+    ADV(sa) ADV(sb) ADV(i0) ADV(i1)
+    // ---- tiles 1 .. nt-3: request B of tile T+1 and A of tile T+2
+    int T = 1;
+    for (; T <= nt - 3; ++T) {
+        SYNC_TILE(4)
+        KSTEP(F, G, sa, sb, fo0, ISSUE_B(i0, T + 1, 0);, ISSUE_B(i0, T + 1, 1);, ISSUE_B(i0, T + 1, 2);, ISSUE_B(i0, T + 1, 3);)
+        KSTEP(G, F, sa, sb, fo1, ISSUE_A(i1, T + 2, 0);, ISSUE_A(i1, T + 2, 1);, ISSUE_A(i1, T + 2, 2);, ISSUE_A(i1, T + 2, 3);)
+        ADV(sa) ADV(sb) ADV(i0) ADV(i1)
+    }
+    // ---- tile nt-2: only the B panel of the last tile is left to request
+    SYNC_TILE(4)
+    KSTEP(F, G, sa, sb, fo0, ISSUE_B(i0, T + 1, 0);, ISSUE_B(i0, T + 1, 1);, ISSUE_B(i0, T + 1, 2);, ISSUE_B(i0, T + 1, 3);)
+    KSTEP(G, F, sa, sb, fo1, NOP_, NOP_, NOP_, NOP_)
+    ADV(sa) ADV(sb)
+    // ---- tile nt-1
+    SYNC_TILE(0)
+    KSTEP(F, G, sa, sb, fo0, NOP_, NOP_, NOP_, NOP_)
+    KSTEP(G, F, sa, sb, fo1, NOP_, NOP_, NOP_, NOP_)
+    SB MFMA_H2(F) SB
+#undef ADV
+#undef DMA16
+#undef ISSUE_A
+#undef ISSUE_B
+#undef ISSUE_HALF_A
+#undef ISSUE_HALF_B
+#undef READ_FRAGS
+#undef MROW
+#undef MFMA_H1
+#undef MFMA_H2
+#undef SYNC_TILE
+#undef KSTEP
+#undef NOP_
+#undef SB
+#undef LD
+
+    // ---------------- epilogue through this wave's private LDS slice (ring is idle after one more barrier)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (p.alpha) {   // gradient un-scaling (weight gradients of the fp16 loss-scaled backward)
+        const float al = *p.alpha;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] *= al;
+    }
+    char* sl = smem + wid * SLICE;
+    const int fq = lane >> 4;
+    const int nb = n0 + wn * 64;          // first column of this wave's sub-tile
+    const int mb = m0 + wm * 128;         // first row
+    float4 bias4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        bias4[j] = p.bias ? *(const float4*)(p.bias + nb + 16 * j + 4 * fq) : float4{0.f, 0.f, 0.f, 0.f};
+
+    if constexpr (EPI == EPI_STORE_T || EPI == EPI_ACT_T) {
+        // two passes of 64 rows x 64 cols of 16-bit: LDS rows of 128 B, 16-B chunks XOR-swizzled by (row & 7)
+        auto stage16 = [&](int pass, bool activated) {
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int i = 4 * pass + ii;
+                const int row = 16 * ii + frow;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v[4] = {acc[i][j][0] + bias4[j].x, acc[i][j][1] + bias4[j].y, acc[i][j][2] + bias4[j].z,
+                                  acc[i][j][3] + bias4[j].w};
+                    if (activated) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], p.act);
+                    }
+                    const int c = 2 * j + (fq >> 1);
+                    *(uint2*)(sl + row * 128 + ((c ^ (row & 7)) << 4) + (fq & 1) * 8) = pack4<TT>(v[0], v[1], v[2], v[3]);
+                }
+            }
+        };
+        auto flush16 = [&](int pass, u16* dst) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = 8 * it + (lane >> 3), pc = lane & 7;
+                const uint4 v = *(const uint4*)(sl + row * 128 + (pc << 4));
+                const int m = mb + 64 * pass + row;
+                if (m < p.M) *(uint4*)(dst + (size_t)m * p.ldc + nb + ((pc ^ (row & 7)) << 3)) = v;
+            }
+        };
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            if (EPI == EPI_ACT_T && p.aux) {   // training forward: pre-activation stash first
+                stage16(pass, false);
+                flush16(pass, (u16*)p.aux);
+            }
+            stage16(pass, EPI == EPI_ACT_T);
+            flush16(pass, (u16*)p.C);
+        }
+    } else {
+        // fp32 outputs: four passes of 32 rows x 64 cols: LDS rows of 256 B, 16-B chunks XOR-swizzled by (row & 15)
+        const float beta = (EPI == EPI_RESID_F32) ? 1.f : p.beta;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            float4 res[8];
+            if (beta != 0.f) {   // fetch the residual rows of this pass first: 8 coalesced 16-B loads in flight
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int row = 4 * it + (lane >> 4), pc = lane & 15;
+                    const int m = mb + 32 * pass + row;
+                    res[it] = m < p.M ? *(const float4*)((const float*)p.C + (size_t)m * p.ldc + nb + ((pc ^ (row & 15)) << 2))
+                                      : float4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                const int i = 2 * pass + ii;
+                const int row = 16 * ii + frow;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = 4 * j + fq;
+                    *(float4*)(sl + row * 256 + ((c ^ (row & 15)) << 4)) =
+                        float4{acc[i][j][0] + bias4[j].x, acc[i][j][1] + bias4[j].y, acc[i][j][2] + bias4[j].z,
+                               acc[i][j][3] + bias4[j].w};
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = 4 * it + (lane >> 4), pc = lane & 15;
+                float4 v = *(const float4*)(sl + row * 256 + (pc << 4));
+                const int m = mb + 32 * pass + row;
+                if (beta != 0.f) {
+                    v.x += res[it].x * beta; v.y += res[it].y * beta; v.z += res[it].z * beta; v.w += res[it].w * beta;
+                }
+                if (m < p.M) *(float4*)((float*)p.C + (size_t)m * p.ldc + nb + ((pc ^ (row & 15)) << 2)) = v;
+            }
+        }
+    }
+}
+
+template <class TT>
+hipError_t launch256h(const GemmArgs& p, int epi, hipStream_t s) {
+    const int grid = ((p.M + BM - 1) / BM) * (p.N / BN);
+#define LEAF_CASE(E)                                                                                         \
+    case E: {                                                                                                \
+        static bool attr_done = false;                                                                       \
+        if (!attr_done) {                                                                                    \
+            (void)hipFuncSetAttribute((const void*)gemm_nt256_half_kernel<TT, E>,                            \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, RING);                     \
+            attr_done = true;                                                                                \
+        }                                                                                                    \
+        hipLaunchKernelGGL((gemm_nt256_half_kernel<TT, E>), dim3(grid), dim3(512), RING, s, p);              \
+        break;                                                                                               \
+    }
+    switch (epi) {
+        LEAF_CASE(EPI_STORE_T)
+        LEAF_CASE(EPI_ACT_T)
+        LEAF_CASE(EPI_RESID_F32)
+        LEAF_CASE(EPI_STORE_F32)
+        default: return hipErrorInvalidValue;
+    }
+#undef LEAF_CASE
+    return hipGetLastError();
+}
+
+}  // namespace
+
+bool leaf_gemm256h_eligible(const GemmArgs& p, int epi) {
+    const long tiles = (long)((p.M + BM - 1) / BM) * (p.N / BN);
+    return p.N % BN == 0 && tiles >= 128 && p.K % BK == 0 && p.K >= 4 * BK && p.ldc % 8 == 0 && epi != EPI_ACTGRAD_T;
+}
+
+hipError_t leaf_launch_gemm256h(const GemmArgs& p, int dtype, int epi, hipStream_t s) {
+    return dtype == LEAF_F16 ? launch256h<F16>(p, epi, s) : launch256h<BF16>(p, epi, s);
+}

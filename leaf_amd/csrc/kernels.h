@@ -37,6 +37,9 @@ bool leaf_gemm256_eligible(const GemmArgs& p, int epi);
 hipError_t leaf_launch_gemm256(const GemmArgs& p, int dtype, int epi, hipStream_t s);
 // same tile/pipeline with persistent workgroups (gemm256p.hip): the DMA ring runs across tile seams
 hipError_t leaf_launch_gemm256p(const GemmArgs& p, int dtype, int epi, hipStream_t s);
+// 64-deep half-stage ring with full-line DMA pieces (gemm256h.hip)
+bool leaf_gemm256h_eligible(const GemmArgs& p, int epi);
+hipError_t leaf_launch_gemm256h(const GemmArgs& p, int dtype, int epi, hipStream_t s);
 
 // ---- forward elementwise / reduction kernels (elementwise.hip)
 // x[r,:] = tok_emb[tokens[r],:] + pos_emb[r % ctx,:]   and   xn = LN(x) (16-bit)

@@ -1,0 +1,64 @@
+"""Summarise rocprofv3 PMC passes into the per-kernel CSV / traffic JSON kept under profiles/.
+
+    python tools/pmc_summary.py FETCH_DIR WRITE_DIR OUT_PREFIX [KERNEL_SUBSTR]
+
+FETCH_DIR / WRITE_DIR are the `-d` directories of two SEPARATE passes
+(`rocprofv3 --pmc FETCH_SIZE --kernel-trace …` and `--pmc WRITE_SIZE --kernel-trace …`) of the same bench command.
+Writes OUT_PREFIX_pmc_fetch.csv, OUT_PREFIX_pmc_write.csv (mean KB per dispatch, per kernel) and OUT_PREFIX_traffic.json
+for the kernel with the largest summed fetch (or the one matching KERNEL_SUBSTR).  gfx950 correction
+(MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts 128-B requests at 64 B, so fetch bytes are doubled.
+"""
+import csv
+import glob
+import json
+import re
+import sys
+from collections import defaultdict
+
+
+def per_kernel(d, counter):
+    acc = defaultdict(lambda: [0.0, 0])
+    for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                a = acc[r["Kernel_Name"]]
+                a[0] += float(r["Counter_Value"])
+                a[1] += 1
+    return acc
+
+
+def write_csv(path, acc, counter):
+    rows = sorted(acc.items(), key=lambda kv: -kv[1][0])
+    with open(path, "w") as f:
+        f.write("kernel,counter,mean_value_KB,dispatches,sum_KB\n")
+        for k, (s, n) in rows:
+            f.write(f'"{k}",{counter},{s / n:.1f},{n},{s:.1f}\n')
+
+
+def short(name):
+    m = re.search(r"(\w+)<(\w+), (\d+)>", name)
+    return f"{m.group(1)}<{m.group(2)},{m.group(3)}>" if m else name
+
+
+def main():
+    fd, wd, out = sys.argv[1:4]
+    want = sys.argv[4] if len(sys.argv) > 4 else None
+    fe, wr = per_kernel(fd, "FETCH_SIZE"), per_kernel(wd, "WRITE_SIZE")
+    write_csv(out + "_pmc_fetch.csv", fe, "FETCH_SIZE")
+    write_csv(out + "_pmc_write.csv", wr, "WRITE_SIZE")
+    gemms = {k: v for k, v in fe.items() if "gemm_nt" in k and (want is None or want in k)}
+    k = max(gemms, key=lambda x: gemms[x][0])
+    fkb, wkb = fe[k][0] / fe[k][1], wr[k][0] / wr[k][1]
+    json.dump({
+        "kernel": short(k),
+        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --steps 2 --warmup 1 "
+                  "--no-cpu-baseline`, mean over that kernel's dispatches (tools/pmc_summary.py)",
+        "fetch_kb_mean": fkb, "write_kb_mean": wkb,
+        "correction": "gfx950: FETCH_SIZE counts 128-B requests at 64 B -> doubled (MI355X_MICROARCH.md, HBM)",
+        "traffic_bytes_per_launch": (2 * fkb + wkb) * 1024,
+    }, open(out + "_traffic.json", "w"), indent=1)
+    print(short(k), "fetch KB", fkb, "write KB", wkb, "traffic B/launch", (2 * fkb + wkb) * 1024)
+
+
+if __name__ == "__main__":
+    main()
