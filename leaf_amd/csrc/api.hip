@@ -38,6 +38,7 @@ extern "C" int leaf_text_create(const leaf_text_cfg* cfg, int fwd_dtype, leaf_te
     h->cfg = *cfg;
     h->fwd_dtype = fwd_dtype;
     h->chunk = 4096;
+    h->streams = 1;   // 2 measured no faster on MI355X: the option stays for A/B runs
     { const char* e = getenv("LEAF_LAST_TRIM"); h->last_trim = (e && e[0] == '0') ? 0 : 1; }
     {   // gradient path: fp16 + per-step power-of-two loss scale unless LEAF_GRAD_DTYPE=bf16
         const char* e = getenv("LEAF_GRAD_DTYPE");
@@ -83,7 +84,13 @@ extern "C" int leaf_text_create(const leaf_text_cfg* cfg, int fwd_dtype, leaf_te
     return 0;
 }
 
-extern "C" void leaf_text_destroy(leaf_text_t h) { delete h; }
+extern "C" void leaf_text_destroy(leaf_text_t h) {
+    if (!h) return;
+    if (h->side) (void)hipStreamDestroy(h->side);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    delete h;
+}
 
 extern "C" int leaf_text_set_chunk(leaf_text_t h, int seqs) {
     if (!h || seqs < 1) { leaf_set_error("bad chunk"); return 1; }
@@ -95,6 +102,7 @@ extern "C" int leaf_text_set_option(leaf_text_t h, const char* name, int value) 
     if (!h || !name) { leaf_set_error("null argument"); return 1; }
     if (!strcmp(name, "chunk")) return leaf_text_set_chunk(h, value);
     if (!strcmp(name, "last_layer_trim")) { h->last_trim = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "streams")) { h->streams = value >= 2 ? 2 : 1; return 0; }
     leaf_set_error("unknown option '%s'", name);
     return 1;
 }
@@ -292,22 +300,50 @@ struct PrefixPlan {   // prefix reuse: see RowMap in common.h
     int group = 1;
 };
 
-int forward_all(const leaf_text* h, const float* P, const void* W, const int32_t* tokens, const int32_t* lens,
+// rows below which a pass is not split across the two streams (the halves would not fill the chip anyway)
+constexpr size_t SPLIT_MIN_ROWS = 16384;
+
+int ensure_side_stream(leaf_text* h) {
+    if (h->side) return 0;
+    LEAF_TRY(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+    LEAF_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    LEAF_TRY(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    return 0;
+}
+
+int forward_all(leaf_text* h, const float* P, const void* W, const int32_t* tokens, const int32_t* lens,
                 const int32_t* cu_dev, int n_seq, float* out, int normalize, Carver& c, hipStream_t s,
                 const PrefixPlan& pp = PrefixPlan()) {
     const int ctx = h->cfg.context_length;
     if ((lens == nullptr) != (cu_dev == nullptr)) { leaf_set_error("seq_lens (host) and cu_rows (device) go together"); return 1; }
     const size_t budget = (size_t)(n_seq < h->chunk ? n_seq : h->chunk) * ctx;
-    FwdBuf b = carve_fwd(h, c, (int)(budget / ctx));
+    size_t total = 0;
+    for (int i = 0; i < n_seq; ++i) {
+        const int L = lens ? lens[i] : ctx;
+        if (L < 1 || L > ctx) { leaf_set_error("seq_lens[%d] = %d out of range 1..%d", i, L, ctx); return 1; }
+        total += L;
+    }
+    const int nsets = (h->streams >= 2 && total >= SPLIT_MIN_ROWS && n_seq >= 2) ? 2 : 1;
+    size_t nchunks = (total + budget - 1) / budget;
+    if (nsets == 2) nchunks = (nchunks + 1) / 2 * 2;                 // an even number of near-equal chunks
+    const size_t target = (total + nchunks - 1) / nchunks;           // <= budget
+    FwdBuf bufs[2];
+    bufs[0] = carve_fwd(h, c, (int)(budget / ctx));
+    if (nsets == 2) bufs[1] = carve_fwd(h, c, (int)(budget / ctx));
     if (!c.ok()) { leaf_set_error("workspace too small: need %zu bytes, have %zu", c.off, c.cap); return 1; }
-    int s0 = 0;
+    if (nsets == 2) {
+        if (ensure_side_stream(h)) return 1;
+        LEAF_TRY(hipEventRecord(h->ev_fork, s));
+        LEAF_TRY(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+    }
+    int s0 = 0, ci = 0;
     size_t row0 = 0;
     while (s0 < n_seq) {
         int s1 = s0;
         size_t rows = 0;
         while (s1 < n_seq) {
             const int L = lens ? lens[s1] : ctx;
-            if (L < 1 || L > ctx) { leaf_set_error("seq_lens[%d] = %d out of range 1..%d", s1, L, ctx); return 1; }
+            if (rows + L > target && s1 > s0) break;
             if (rows + L > budget) break;
             rows += L;
             ++s1;
@@ -317,11 +353,17 @@ int forward_all(const leaf_text* h, const float* P, const void* W, const int32_t
         kv.kv_read = pp.kv;
         kv.kv_stride = pp.kv_stride;
         if (s1 == s0) { leaf_set_error("a sequence does not fit the row budget"); return 1; }
+        const int set = nsets == 2 ? (ci & 1) : 0;
         if (forward_chunk(h, P, (const uint16_t*)W, tokens, s1 - s0, (int)rows, map, out + (size_t)s0 * h->cfg.embed_dim,
-                          normalize, b, s, kv))
+                          normalize, bufs[set], set ? h->side : s, kv))
             return 1;
         s0 = s1;
         row0 += rows;
+        ++ci;
+    }
+    if (nsets == 2) {
+        LEAF_TRY(hipEventRecord(h->ev_join, h->side));
+        LEAF_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
     }
     return 0;
 }
@@ -331,7 +373,7 @@ int forward_all(const leaf_text* h, const float* P, const void* W, const int32_t
 extern "C" size_t leaf_text_workspace_bytes(leaf_text_t h, int n_seq, int mode) {
     if (!h || n_seq < 1) return 0;
     const int cs = n_seq < h->chunk ? n_seq : h->chunk;
-    size_t b = fwd_chunk_bytes(h, cs) + 256;
+    size_t b = (h->streams >= 2 ? 2 : 1) * (fwd_chunk_bytes(h, cs) + 256) + 256;   // one buffer set per stream
     if (mode == 1) b += align_up((size_t)n_seq * h->cfg.embed_dim * 4, 256) + 256;
     if (mode == 2) return leaf_train_ws_bytes(h, n_seq);
     return b;

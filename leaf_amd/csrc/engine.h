@@ -23,6 +23,13 @@ struct leaf_text {
     int chunk;  // sequences per pass
     int last_trim;   // last transformer block: attention output / out-proj / MLP only for the pooled (EOT) row
     int grad_dtype;  // 16-bit type of the gradient path: LEAF_F16 (loss-scaled, default) or LEAF_BF16
+    // Two-stream chunk pipeline of the forward-only passes (api.hip forward_all): sequence chunks alternate between the
+    // caller's stream and a side stream owned by the handle, so one chunk's HBM-bound kernels (LN, attention, the
+    // residual epilogues) and grid tails overlap the other chunk's MFMA-bound K loops.  Measured: kernels of the two
+    // streams do run concurrently, but the search pass is no faster (57.4 vs 56.0 ms), so the default is streams = 1.
+    int streams;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<TensorInfo> tensors;
     std::vector<LayerOff> layer;
     size_t tok_emb, pos_emb, text_proj, lnf_w, lnf_b;

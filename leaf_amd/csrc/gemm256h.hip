@@ -15,6 +15,19 @@ constexpr int HALF = BM * BK * 2;       // 32 KiB: one operand panel of one K ti
 constexpr int RING = NSLOT * HALF;      // 160 KiB
 constexpr int SLICE = 16384;            // epilogue staging per wave (inside the idle ring)
 
+// In-kernel stamps (diagnostic builds only: -DLEAF_GEMM_STAMPS): s_memtime at phase boundaries, one 8-slot record per
+// workgroup in a caller-supplied buffer that nothing else reads.
+#ifdef LEAF_GEMM_STAMPS
+#define STAMP(i)                                                                                          \
+    if (p.stamps && tid == 0) {                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        ((unsigned long long*)p.stamps)[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime();    \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+    }
+#else
+#define STAMP(i)
+#endif
+
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
 
@@ -101,9 +114,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
 #define ADV(x) { x += 2 * HALF; if (x >= RING) x -= RING; }
     int sa = 0, sb = HALF;               // slots of (A, B) of the tile being multiplied: half-stages 2T, 2T+1
     int i0 = 3 * HALF, i1 = 4 * HALF;    // slots of the half-stages requested during tile T: 2T+3 (B), 2T+4 (A)
+    STAMP(0)
     ISSUE_HALF_A(0, 0) ISSUE_HALF_B(HALF, 0) ISSUE_HALF_A(2 * HALF, 1)
     // ---- tile 0
     SYNC_TILE(4)
+    STAMP(1)
     READ_FRAGS(G, sa, sb, fo0)
     SB ISSUE_B(i0, 1, 0); ISSUE_B(i0, 1, 1); SB
     MROW(G, 0, Gx0) MROW(G, 1, Gx1) SB ISSUE_B(i0, 1, 2); ISSUE_B(i0, 1, 3); SB MROW(G, 2, Gx2) MROW(G, 3, Gx3)
@@ -118,6 +133,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
         ADV(sa) ADV(sb) ADV(i0) ADV(i1)
     }
     // ---- tile nt-2: only the B panel of the last tile is left to request
+    STAMP(2)
     SYNC_TILE(4)
     KSTEP(F, G, sa, sb, fo0, ISSUE_B(i0, T + 1, 0);, ISSUE_B(i0, T + 1, 1);, ISSUE_B(i0, T + 1, 2);, ISSUE_B(i0, T + 1, 3);)
     KSTEP(G, F, sa, sb, fo1, NOP_, NOP_, NOP_, NOP_)
@@ -127,6 +143,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
     KSTEP(F, G, sa, sb, fo0, NOP_, NOP_, NOP_, NOP_)
     KSTEP(G, F, sa, sb, fo1, NOP_, NOP_, NOP_, NOP_)
     SB MFMA_H2(F) SB
+    STAMP(3)
 #undef ADV
 #undef DMA16
 #undef ISSUE_A
@@ -239,6 +256,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
             }
         }
     }
+    STAMP(4)
 }
 
 template <class TT>

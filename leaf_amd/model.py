@@ -126,7 +126,8 @@ class LeafCLIPText:
             pass
 
     def set_option(self, name: str, value: int):
-        """Engine switches (leaf_text_set_option): 'chunk', 'last_layer_trim'."""
+        """Engine switches (leaf_text_set_option): 'chunk', 'last_layer_trim', 'streams' (1 | 2: two-stream
+        chunk pipeline of the forward-only passes)."""
         _lib.check(self._lib.leaf_text_set_option(self._h, name.encode(), int(value)), "leaf_text_set_option")
         return self
 
