@@ -94,6 +94,8 @@ hipError_t leaf_launch_layernorm_bwd(const float* dy, const float* x, const floa
 hipError_t leaf_launch_colsum(const void* dy16, int gkind, const float* gscale, int ld, int rows, int n, float* dbias,
                               hipStream_t s);
 // attention backward: q,k,v from qkv (fwd dtype), dO [rows,d] -> dqkv [rows,3d], both 16-bit of kind gkind
+hipError_t leaf_launch_attention_bwd_mfma(const void* qkv, int qkv_dtype, const void* dout16, void* dqkv16, int gkind,
+                                          int n_seq, RowMap map, int heads, int d, hipStream_t s);   // attention_bwd.hip
 hipError_t leaf_launch_attention_bwd(const void* qkv, int qkv_dtype, const void* dout16, void* dqkv16, int gkind,
                                      int n_seq, RowMap map, int heads, int d, hipStream_t s);
 // dtok[tokens[r],:] += dx[r,:] ; dpos[r % ctx,:] += dx[r,:]

@@ -452,6 +452,12 @@ hipError_t leaf_launch_colsum(const void* dy16, int gkind, const float* gscale, 
 hipError_t leaf_launch_attention_bwd(const void* qkv, int qkv_dtype, const void* dout16, void* dqkv16, int gkind,
                                      int n_seq, RowMap map, int heads, int d, hipStream_t s) {
     const int ctx = map.ctx;
+    // LEAF_ATTN_BWD=0 selects the fp32 VALU kernel below (the first implementation, kept for A/B and ctx 97..128);
+    // default is the MFMA kernel of attention_bwd.hip
+    static int use_mfma = -1;
+    if (use_mfma < 0) { const char* e = getenv("LEAF_ATTN_BWD"); use_mfma = (e && e[0] == '0') ? 0 : 1; }
+    if (use_mfma && ctx <= 96 && !map.prefix)
+        return leaf_launch_attention_bwd_mfma(qkv, qkv_dtype, dout16, dqkv16, gkind, n_seq, map, heads, d, s);
     if (d != heads * HD || ctx > 128) return hipErrorInvalidValue;
     size_t lds = ((size_t)4 * ctx * HP + (size_t)2 * ctx * (ctx + 1)) * sizeof(float);
     static bool attr = false;
