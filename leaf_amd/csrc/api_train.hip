@@ -42,7 +42,8 @@ Stash carve_stash(const leaf_text* h, Carver& c, int n_seq, size_t rows) {
 
 struct BwdBuf {
     float* dx;        // [rows,d]
-    uint16_t* dx16;   // [rows,d] bf16
+    uint16_t* dx16;   // [rows,d] 16-bit gradient at the block output (dY of c_proj)
+    uint16_t* dx16b;  // [rows,d] 16-bit gradient after the MLP branch (dY of out_proj)
     float* dxn;       // [rows,d]
     uint16_t* big16;  // [rows,4d] bf16
     uint16_t* dqkv;   // [rows,3d] bf16
@@ -59,6 +60,7 @@ BwdBuf carve_bwd(const leaf_text* h, Carver& c, int n_seq, size_t rows) {
     BwdBuf b;
     b.dx = (float*)c.take(rows * d * 4);
     b.dx16 = (uint16_t*)c.take(rows * d * 2);
+    b.dx16b = (uint16_t*)c.take(rows * d * 2);
     b.dxn = (float*)c.take(rows * d * 4);
     b.big16 = (uint16_t*)c.take(rows * 4 * d * 2);
     b.dqkv = (uint16_t*)c.take(rows * 3 * d * 2);
@@ -165,29 +167,51 @@ extern "C" int leaf_textfare_backward(leaf_text_t h, const float* P, const void*
                                           G + h->lnf_b, b.gscale, n_seq, map, d, D, s));
     LEAF_TRY(leaf_launch_cast16(b.dx, 2, b.dx16, gk, rd, s));
 
+    // LEAF_WGRAD=0: first implementation (two transposes + NT GEMM per weight, atomics column sums), kept for A/B
+    static int grouped = -1;
+    if (grouped < 0) { const char* e = getenv("LEAF_WGRAD"); grouped = (e && e[0] == '0') ? 0 : 1; }
+
     for (int l = L - 1; l >= 0; --l) {
         const LayerOff& o = h->layer[l];
         const float* xin = st.xin + l * rd; const float* x1 = st.x1 + l * rd;
         const uint16_t* xn1 = st.xn1 + l * rd; const uint16_t* qkv = st.qkv + 3 * l * rd; const uint16_t* ao = st.ao + l * rd;
         const uint16_t* xn2 = st.xn2 + l * rd; const uint16_t* pre = st.pre + 4 * l * rd; const uint16_t* hh = st.hh + 4 * l * rd;
         // ---- MLP
-        if (wgrad(b.dx16, d, hh, fk, 4 * d, G + o.proj_w)) return 1;
-        LEAF_TRY(leaf_launch_colsum(b.dx16, gk, b.gscale, d, rows, d, G + o.proj_b, s));
+        if (!grouped) {
+            if (wgrad(b.dx16, d, hh, fk, 4 * d, G + o.proj_w)) return 1;
+            LEAF_TRY(leaf_launch_colsum(b.dx16, gk, b.gscale, d, rows, d, G + o.proj_b, s));
+        }
         if (leaf_gemm(gk, EPI_ACTGRAD_T, b.dx16, d, WT + h->w16_proj(l), d, b.big16, 4 * d, nullptr, (void*)pre, rows,
                  4 * d, d, cf.activation, s, 0.f, fk)) return 1;
-        if (wgrad(b.big16, 4 * d, xn2, fk, d, G + o.fc_w)) return 1;
-        LEAF_TRY(leaf_launch_colsum(b.big16, gk, b.gscale, 4 * d, rows, 4 * d, G + o.fc_b, s));
+        if (!grouped) {
+            if (wgrad(b.big16, 4 * d, xn2, fk, d, G + o.fc_w)) return 1;
+            LEAF_TRY(leaf_launch_colsum(b.big16, gk, b.gscale, 4 * d, rows, 4 * d, G + o.fc_b, s));
+        }
         if (leaf_gemm(gk, EPI_STORE_F32, b.big16, 4 * d, WT + h->w16_fc(l), 4 * d, b.dxn, d, nullptr, nullptr, rows, d,
                  4 * d, 0, s)) return 1;
-        LEAF_TRY(leaf_launch_layernorm_bwd(b.dxn, x1, P + o.ln2_w, cf.ln_eps, b.dx, b.dx16, gk, b.gscale, G + o.ln2_w,
+        LEAF_TRY(leaf_launch_layernorm_bwd(b.dxn, x1, P + o.ln2_w, cf.ln_eps, b.dx, b.dx16b, gk, b.gscale, G + o.ln2_w,
                                            G + o.ln2_b, rows, d, s));
         // ---- attention
-        if (wgrad(b.dx16, d, ao, fk, d, G + o.out_w)) return 1;
-        LEAF_TRY(leaf_launch_colsum(b.dx16, gk, b.gscale, d, rows, d, G + o.out_b, s));
-        if (leaf_gemm(gk, EPI_STORE_T, b.dx16, d, WT + h->w16_out(l), d, b.do16, d, nullptr, nullptr, rows, d, d, 0, s)) return 1;
+        if (!grouped) {
+            if (wgrad(b.dx16b, d, ao, fk, d, G + o.out_w)) return 1;
+            LEAF_TRY(leaf_launch_colsum(b.dx16b, gk, b.gscale, d, rows, d, G + o.out_b, s));
+        }
+        if (leaf_gemm(gk, EPI_STORE_T, b.dx16b, d, WT + h->w16_out(l), d, b.do16, d, nullptr, nullptr, rows, d, d, 0, s)) return 1;
         LEAF_TRY(leaf_launch_attention_bwd(qkv, h->fwd_dtype, b.do16, b.dqkv, gk, n_seq, map, cf.heads, d, s));
-        if (wgrad(b.dqkv, 3 * d, xn1, fk, d, G + o.qkv_w)) return 1;
-        LEAF_TRY(leaf_launch_colsum(b.dqkv, gk, b.gscale, 3 * d, rows, 3 * d, G + o.qkv_b, s));
+        if (!grouped) {
+            if (wgrad(b.dqkv, 3 * d, xn1, fk, d, G + o.qkv_w)) return 1;
+            LEAF_TRY(leaf_launch_colsum(b.dqkv, gk, b.gscale, 3 * d, rows, 3 * d, G + o.qkv_b, s));
+        } else {
+            // all four weight + bias gradients of the block in one launch (wgrad.hip); must run before ln1's backward
+            // overwrites dx16, the dY of c_proj
+            WgradArgs wa{};
+            wa.p[0] = WgradProb{b.dx16, hh, G + o.proj_w, G + o.proj_b, d, 4 * d, d, 4 * d, 0, 0};
+            wa.p[1] = WgradProb{b.big16, xn2, G + o.fc_w, G + o.fc_b, 4 * d, d, 4 * d, d, 0, 0};
+            wa.p[2] = WgradProb{b.dx16b, ao, G + o.out_w, G + o.out_b, d, d, d, d, 0, 0};
+            wa.p[3] = WgradProb{b.dqkv, xn1, G + o.qkv_w, G + o.qkv_b, 3 * d, d, 3 * d, d, 0, 0};
+            wa.nprob = 4; wa.rows = rows; wa.alpha = inv_s;
+            LEAF_TRY(leaf_launch_wgrad_group(wa, fk, gk, s));
+        }
         if (leaf_gemm(gk, EPI_STORE_F32, b.dqkv, 3 * d, WT + h->w16_qkv(l), 3 * d, b.dxn, d, nullptr, nullptr, rows, d,
                  3 * d, 0, s)) return 1;
         LEAF_TRY(leaf_launch_layernorm_bwd(b.dxn, xin, P + o.ln1_w, cf.ln_eps, b.dx, b.dx16, gk, b.gscale, G + o.ln1_w,

@@ -94,6 +94,22 @@ hipError_t leaf_launch_layernorm_bwd(const float* dy, const float* x, const floa
 hipError_t leaf_launch_colsum(const void* dy16, int gkind, const float* gscale, int ld, int rows, int n, float* dbias,
                               hipStream_t s);
 // attention backward: q,k,v from qkv (fwd dtype), dO [rows,d] -> dqkv [rows,3d], both 16-bit of kind gkind
+// grouped TN weight/bias gradient launch (wgrad.hip): up to 4 problems dW[Nw,Kw] += alpha dY^T X, db[Nw] += alpha colsum(dY)
+struct WgradProb {
+    const uint16_t* dY;   // [rows, Nw] 16-bit gradient type, row stride ldy
+    const uint16_t* X;    // [rows, Kw] 16-bit x_dtype, row stride ldx
+    float* dW;            // [Nw, Kw] fp32, accumulated into
+    float* db;            // [Nw] fp32 or null
+    int Nw, Kw, ldy, ldx;
+    int tile0, tiles_k;   // filled by the launcher
+};
+struct WgradArgs {
+    WgradProb p[4];
+    int nprob, rows;
+    const float* alpha;   // device scalar or null (1.0)
+};
+bool leaf_wgrad_tn_ok(int Nw, int Kw, int ldy, int ldx);
+hipError_t leaf_launch_wgrad_group(WgradArgs a, int x_dtype, int g_dtype, hipStream_t s);
 hipError_t leaf_launch_attention_bwd_mfma(const void* qkv, int qkv_dtype, const void* dout16, void* dqkv16, int gkind,
                                           int n_seq, RowMap map, int heads, int d, hipStream_t s);   // attention_bwd.hip
 hipError_t leaf_launch_attention_bwd(const void* qkv, int qkv_dtype, const void* dout16, void* dqkv16, int gkind,
