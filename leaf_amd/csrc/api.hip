@@ -269,6 +269,11 @@ int forward_chunk(const leaf_text* h, const float* P, const uint16_t* W, const i
                 return 1;
             if (leaf_gemm(dt, EPI_RESID_F32, hb, 4 * d, W + h->w16_proj(l), 4 * d, xg, d, P + o.proj_b, nullptr, cs, d, 4 * d, 0, s))
                 return 1;
+            if (leaf_project_rows_ok(d, c.embed_dim)) {   // hb is dead after the c_proj GEMM: its space takes LN(xg)
+                LEAF_TRY(leaf_launch_project_rows(xg, P + h->lnf_w, P + h->lnf_b, c.ln_eps, P + h->text_proj, (float*)hb, out,
+                                                  cs, d, c.embed_dim, normalize, s));
+                return 0;
+            }
             LEAF_TRY(leaf_launch_pool_project(xg, tokens, P + h->lnf_w, P + h->lnf_b, c.ln_eps, P + h->text_proj, out, nullptr,
                                               nullptr, cs, map, d, c.embed_dim, normalize, s, /*rows_are_pooled=*/1));
             return 0;
@@ -283,6 +288,17 @@ int forward_chunk(const leaf_text* h, const float* P, const uint16_t* W, const i
         if (leaf_gemm(dt, EPI_RESID_F32, b.hh, 4 * d, W + h->w16_proj(l), 4 * d, b.x, d, P + o.proj_b, nullptr, rows, d,
                       4 * d, 0, s))
             return 1;
+    }
+    if (out && leaf_project_rows_ok(d, c.embed_dim)) {
+        // same op sequence as the trimmed path (bit-identical features): gather the pooled rows, LN, fp32 projection.
+        // qkv / fc scratch is dead here.
+        float* xg = (float*)b.qkv;
+        float* xn = (float*)((char*)b.qkv + align_up((size_t)cs * d * 4, 256));
+        LEAF_TRY(leaf_launch_eot_positions(tokens, b.eot, cs, map, s));
+        LEAF_TRY(leaf_launch_gather_rows(b.x, b.eot, xg, cs, map, d, s));
+        LEAF_TRY(leaf_launch_project_rows(xg, P + h->lnf_w, P + h->lnf_b, c.ln_eps, P + h->text_proj, xn, out, cs, d,
+                                          c.embed_dim, normalize, s));
+        return 0;
     }
     if (out)
         LEAF_TRY(leaf_launch_pool_project(b.x, tokens, P + h->lnf_w, P + h->lnf_b, c.ln_eps, P + h->text_proj, out, nullptr,

@@ -50,6 +50,10 @@ hipError_t leaf_launch_layernorm(const float* x, const float* g, const float* b,
                                  int dtype, hipStream_t s);
 // out[n,:] = LN_final(x[n*ctx + eot(n),:]) @ P  (fp32 math), optional L2 normalisation; pooled (optional) keeps
 // the normalised EOT row and eot_idx the pooled position (training stash).
+// project.hip: out[M,D] = [normalize](LN(xg[M,d]) @ proj[d,D]) on the fp32 matrix-core path; xn = [M,d] fp32 scratch
+bool leaf_project_rows_ok(int d, int D);
+hipError_t leaf_launch_project_rows(const float* xg, const float* g, const float* b, float eps, const float* proj,
+                                    float* xn, float* out, int M, int d, int D, int normalize, hipStream_t s);
 hipError_t leaf_launch_pool_project(const float* x, const int32_t* tokens, const float* g, const float* b, float eps,
                                     const float* proj, float* out, float* pooled, int32_t* eot_idx, int n_seq, RowMap map,
                                     int d, int D, int normalize, hipStream_t s, int rows_are_pooled = 0);
