@@ -90,15 +90,16 @@ int leaf_score_candidates(leaf_text_t h, const float* params, const void* w16_fw
  * leaf_score_candidates_prefix then computes, for candidate i of caption i / rho, only positions
  * [prefix[i], prefix[i] + suffix_lens[i]) and reads the K/V of earlier positions from the cache.  cu_suffix = exclusive
  * prefix sum of suffix_lens (device), base_cu = packed row offsets of the captions inside the cache (device, [B+1]),
- * base_rows = total cached rows per layer.  Results are bit-identical to leaf_score_candidates. */
+ * base_rows = total cached rows per layer, max_len = an upper bound of prefix[i] + suffix_lens[i] over the candidates
+ * (sizes the attention kernel's LDS; 0 = context_length).  Results are bit-identical to leaf_score_candidates. */
 size_t leaf_text_kv_bytes(leaf_text_t h, int n_seq);
 int leaf_text_forward_kv(leaf_text_t h, const float* params, const void* w16_fwd, const int32_t* tokens,
                          const int32_t* seq_lens, const int32_t* cu_rows, int n_seq, float* out /* may be NULL */,
                          int normalize, void* kv, size_t kv_bytes, void* ws, size_t ws_bytes, leaf_stream_t s);
 int leaf_score_candidates_prefix(leaf_text_t h, const float* params, const void* w16_fwd, const int32_t* tokens,
                                  const int32_t* suffix_lens, const int32_t* cu_suffix, const int32_t* prefix,
-                                 const int32_t* base_cu, const void* kv, size_t base_rows, const float* anchor, int B,
-                                 int rho, int objective, int32_t* best_idx, float* best_feat, float* loss, void* ws,
+                                 const int32_t* base_cu, const void* kv, size_t base_rows, int max_len,
+                                 const float* anchor, int B, int rho, int objective, int32_t* best_idx, float* best_feat, float* loss, void* ws,
                                  size_t ws_bytes, leaf_stream_t s);
 
 /* training forward (utils_AT.py:317-319) keeping activations in `stash` for the backward pass */

@@ -237,7 +237,8 @@ struct KvPlan {
 };
 
 int forward_chunk(const leaf_text* h, const float* P, const uint16_t* W, const int32_t* tokens, int cs, int rows,
-                  RowMap map, float* out, int normalize, const FwdBuf& b_in, hipStream_t s, const KvPlan& kv = KvPlan()) {
+                  RowMap map, float* out, int normalize, const FwdBuf& b_in, hipStream_t s, const KvPlan& kv = KvPlan(),
+                  int max_len = 0 /* longest sequence (prefix + computed rows); 0 = context_length */) {
     FwdBuf b = b_in;
     const leaf_text_cfg& c = h->cfg;
     const int d = c.width, dt = h->fwd_dtype;
@@ -259,7 +260,7 @@ int forward_chunk(const leaf_text* h, const float* P, const uint16_t* W, const i
             // dead; the gathered residual rows xg (fp32 [cs,d]) and the MLP hidden rows hb (16-bit [cs,4d]) need
             // 12*d*cs <= 14*d*rows bytes.
             LEAF_TRY(leaf_launch_eot_positions(tokens, b.eot, cs, map, s));
-            LEAF_TRY(leaf_launch_attention_fwd(b.qkv, kvl, b.a, cs, map, c.heads, d, dt, s, b.eot));
+            LEAF_TRY(leaf_launch_attention_fwd(b.qkv, kvl, b.a, cs, map, c.heads, d, dt, s, b.eot, max_len));
             float* xg = (float*)b.qkv;
             uint16_t* hb = (uint16_t*)((char*)b.qkv + align_up((size_t)cs * d * 4, 256));
             LEAF_TRY(leaf_launch_gather_rows(b.x, b.eot, xg, cs, map, d, s));
@@ -278,7 +279,7 @@ int forward_chunk(const leaf_text* h, const float* P, const uint16_t* W, const i
                                               nullptr, cs, map, d, c.embed_dim, normalize, s, /*rows_are_pooled=*/1));
             return 0;
         }
-        LEAF_TRY(leaf_launch_attention_fwd(b.qkv, kvl, b.a, cs, map, c.heads, d, dt, s));
+        LEAF_TRY(leaf_launch_attention_fwd(b.qkv, kvl, b.a, cs, map, c.heads, d, dt, s, nullptr, max_len));
         if (leaf_gemm(dt, EPI_RESID_F32, b.a, d, W + h->w16_out(l), d, b.x, d, P + o.out_b, nullptr, rows, d, d, 0, s))
             return 1;
         LEAF_TRY(leaf_launch_layernorm(b.x, P + o.ln2_w, P + o.ln2_b, c.ln_eps, b.a, rows, d, dt, s));
@@ -314,6 +315,7 @@ struct PrefixPlan {   // prefix reuse: see RowMap in common.h
     const uint16_t* kv = nullptr;
     size_t kv_stride = 0;
     int group = 1;
+    int max_len = 0;   // upper bound of prefix + suffix length over the candidates (0 = context_length)
 };
 
 // rows below which a pass is not split across the two streams (the halves would not fill the chip anyway)
@@ -334,10 +336,16 @@ int forward_all(leaf_text* h, const float* P, const void* W, const int32_t* toke
     if ((lens == nullptr) != (cu_dev == nullptr)) { leaf_set_error("seq_lens (host) and cu_rows (device) go together"); return 1; }
     const size_t budget = (size_t)(n_seq < h->chunk ? n_seq : h->chunk) * ctx;
     size_t total = 0;
+    int max_len = 0;
     for (int i = 0; i < n_seq; ++i) {
         const int L = lens ? lens[i] : ctx;
         if (L < 1 || L > ctx) { leaf_set_error("seq_lens[%d] = %d out of range 1..%d", i, L, ctx); return 1; }
         total += L;
+        max_len = L > max_len ? L : max_len;
+    }
+    if (pp.prefix_dev) {   // computed rows are suffixes: the bound comes from the caller
+        if (pp.max_len > 0 && pp.max_len < max_len) { leaf_set_error("max_len %d below a suffix length %d", pp.max_len, max_len); return 1; }
+        max_len = pp.max_len > 0 && pp.max_len <= ctx ? pp.max_len : ctx;
     }
     const int nsets = (h->streams >= 2 && total >= SPLIT_MIN_ROWS && n_seq >= 2) ? 2 : 1;
     size_t nchunks = (total + budget - 1) / budget;
@@ -371,7 +379,7 @@ int forward_all(leaf_text* h, const float* P, const void* W, const int32_t* toke
         if (s1 == s0) { leaf_set_error("a sequence does not fit the row budget"); return 1; }
         const int set = nsets == 2 ? (ci & 1) : 0;
         if (forward_chunk(h, P, (const uint16_t*)W, tokens, s1 - s0, (int)rows, map, out + (size_t)s0 * h->cfg.embed_dim,
-                          normalize, bufs[set], set ? h->side : s, kv))
+                          normalize, bufs[set], set ? h->side : s, kv, max_len))
             return 1;
         s0 = s1;
         row0 += rows;
@@ -435,7 +443,12 @@ extern "C" int leaf_text_forward_kv(leaf_text_t h, const float* params, const vo
     if ((seq_lens == nullptr) != (cu_rows == nullptr)) { leaf_set_error("seq_lens (host) and cu_rows (device) go together"); return 1; }
     const int ctx = h->cfg.context_length;
     size_t rows = 0;
-    for (int i = 0; i < n_seq; ++i) rows += seq_lens ? seq_lens[i] : ctx;
+    int max_len = 0;
+    for (int i = 0; i < n_seq; ++i) {
+        const int L = seq_lens ? seq_lens[i] : ctx;
+        rows += L;
+        max_len = L > max_len ? L : max_len;
+    }
     const size_t stride = rows * 3 * h->cfg.width;
     if (stride * 2 * h->cfg.layers > kv_bytes) { leaf_set_error("kv cache too small"); return 1; }
     if (rows > (size_t)h->chunk * ctx) { leaf_set_error("forward_kv needs the captions to fit one chunk (%zu rows)", rows); return 1; }
@@ -447,13 +460,13 @@ extern "C" int leaf_text_forward_kv(leaf_text_t h, const float* params, const vo
     kvp.kv_stride = stride;
     RowMap map{cu_rows, 0, 0, ctx, nullptr, nullptr, 1};
     return forward_chunk(h, params, (const uint16_t*)w16_fwd, tokens, n_seq, (int)rows, map, out, normalize, b,
-                         (hipStream_t)s, kvp);
+                         (hipStream_t)s, kvp, max_len);
 }
 
 extern "C" int leaf_score_candidates_prefix(leaf_text_t h, const float* params, const void* w16_fwd, const int32_t* tokens,
                                             const int32_t* suffix_lens, const int32_t* cu_suffix, const int32_t* prefix,
-                                            const int32_t* base_cu, const void* kv, size_t base_rows, const float* anchor,
-                                            int B, int rho, int objective, int32_t* best_idx, float* best_feat, float* loss,
+                                            const int32_t* base_cu, const void* kv, size_t base_rows, int max_len,
+                                            const float* anchor, int B, int rho, int objective, int32_t* best_idx, float* best_feat, float* loss,
                                             void* ws, size_t ws_bytes, leaf_stream_t s) {
     if (!h || !params || !w16_fwd || !tokens || !suffix_lens || !cu_suffix || !prefix || !base_cu || !kv || !anchor ||
         !best_idx || !ws || B < 1 || rho < 1) {
@@ -468,6 +481,7 @@ extern "C" int leaf_score_candidates_prefix(leaf_text_t h, const float* params, 
     PrefixPlan pp;
     pp.prefix_dev = prefix;
     pp.base_cu_dev = base_cu;
+    pp.max_len = max_len;
     pp.kv = (const uint16_t*)kv;
     pp.kv_stride = base_rows * 3 * h->cfg.width;
     pp.group = rho;

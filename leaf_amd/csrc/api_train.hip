@@ -100,6 +100,8 @@ extern "C" int leaf_text_forward_train(leaf_text_t h, const float* P, const void
     Stash st = carve_stash(h, c, n_seq, rows);
     if (!c.ok()) { leaf_set_error("stash too small: need %zu bytes, have %zu", c.off, c.cap); return 1; }
     const RowMap map{cu_rows, 0, 0, cf.context_length, nullptr, nullptr, 1};
+    int max_len = 0;
+    for (int i = 0; i < n_seq; ++i) { const int Ls = seq_lens ? seq_lens[i] : cf.context_length; max_len = Ls > max_len ? Ls : max_len; }
     const int d = cf.width, dt = h->fwd_dtype, L = cf.layers;
     const size_t rd = (size_t)rows * d;
     const uint16_t* W = (const uint16_t*)w16_fwd;
@@ -112,7 +114,7 @@ extern "C" int leaf_text_forward_train(leaf_text_t h, const float* P, const void
         uint16_t* xn2 = st.xn2 + l * rd; uint16_t* pre = st.pre + 4 * l * rd; uint16_t* hh = st.hh + 4 * l * rd;
         if (l > 0) LEAF_TRY(leaf_launch_layernorm(xin, P + o.ln1_w, P + o.ln1_b, cf.ln_eps, xn1, rows, d, dt, s));
         if (leaf_gemm(dt, EPI_STORE_T, xn1, d, W + h->w16_qkv(l), d, qkv, 3 * d, P + o.qkv_b, nullptr, rows, 3 * d, d, 0, s)) return 1;
-        LEAF_TRY(leaf_launch_attention_fwd(qkv, nullptr, ao, n_seq, map, cf.heads, d, dt, s));
+        LEAF_TRY(leaf_launch_attention_fwd(qkv, nullptr, ao, n_seq, map, cf.heads, d, dt, s, nullptr, max_len));
         LEAF_TRY(hipMemcpyAsync(x1, xin, rd * 4, hipMemcpyDeviceToDevice, s));
         if (leaf_gemm(dt, EPI_RESID_F32, ao, d, W + h->w16_out(l), d, x1, d, P + o.out_b, nullptr, rows, d, d, 0, s)) return 1;
         LEAF_TRY(leaf_launch_layernorm(x1, P + o.ln2_w, P + o.ln2_b, cf.ln_eps, xn2, rows, d, dt, s));

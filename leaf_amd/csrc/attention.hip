@@ -22,9 +22,10 @@ constexpr int HD = 64;          // head dim (all CLIP text towers)
 constexpr int MAXT = 6;         // 16-row tiles -> ctx <= 96
 constexpr int V_LD = 72;        // LDS V row stride (elements): 144 B, 16-B aligned
 constexpr int P_LD = 104;       // LDS P row stride (elements): 208 B, 16-B aligned
-constexpr int V_BYTES = 96 * V_LD * 2;
 constexpr int P_BYTES = 16 * P_LD * 2;
-constexpr int WAVE_LDS = V_BYTES + P_BYTES;  // 17,152 B
+// per-wave LDS: V image of `vrows` rows (a multiple of 32 covering the longest sequence of the launch, <= 96) + P tile;
+// 17,152 B at 96 rows, 12,544 B at 64: sizing it by the launch's longest sequence keeps more waves resident per CU
+__host__ __device__ constexpr int wave_lds_bytes(int vrows) { return vrows * V_LD * 2 + P_BYTES; }
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -57,19 +58,20 @@ __device__ __forceinline__ typename TT::vec8 load_vt_frag(const char* vlds, int 
 template <class TT, bool USE_TR>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const u16* __restrict__ qkv, const u16* __restrict__ kv_base,
                                                        u16* __restrict__ out, int n_items, RowMap map, int heads, int d,
-                                                       const int32_t* __restrict__ eot_pos) {
+                                                       const int32_t* __restrict__ eot_pos, int vrows) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int item = blockIdx.x * 4 + wid;
     if (item >= n_items) return;   // whole wave exits together (item is wave-uniform)
-    char* vlds = smem + wid * WAVE_LDS;
-    char* plds = vlds + V_BYTES;
+    char* vlds = smem + wid * wave_lds_bytes(vrows);
+    char* plds = vlds + vrows * (V_LD * 2);
     const int n = item / heads, h = item % heads;
     const int ld = 3 * d;
     const int sg = map.s0 + n;
     const int row_s = seq_row(map, sg);
     const int pfx = seq_prefix(map, sg);            // positions < pfx: K/V from the clean caption's cache
-    const int ctx = pfx + seq_len(map, sg);         // total length of this sequence
+    int ctx = pfx + seq_len(map, sg);               // total length of this sequence
+    ctx = ctx < vrows ? ctx : vrows;                // never past the LDS image (the host sizes vrows from the true maximum)
     const u16* own = qkv + (size_t)row_s * ld + h * HD;
     const u16* cached = pfx ? kv_base + (size_t)map.base_cu[sg / map.group] * ld + h * HD : own;
     auto rowptr = [&](int pos) { return pos < pfx ? cached + (size_t)pos * ld : own + (size_t)(pos - pfx) * ld; };
@@ -81,8 +83,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const u16* __restrict__ q
     const int qt0 = eot >= 0 ? eot >> 4 : pfx >> 4;
     const int qt1 = eot >= 0 ? eot >> 4 : nt - 1;
 
-    // ---- V rows -> LDS (row-major), rows ctx..95 zero
-    for (int idx = lane; idx < 96 * 8; idx += 64) {
+    // ---- V rows -> LDS (row-major), rows ctx..vrows-1 zero
+    for (int idx = lane; idx < vrows * 8; idx += 64) {
         const int key = idx >> 3, ch = idx & 7;
         uint4 v = uint4{0u, 0u, 0u, 0u};
         if (key < ctx) v = *(const uint4*)(rowptr(key) + 2 * d + ch * 8);
@@ -180,8 +182,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const u16* __restrict__ q
 }  // namespace
 
 hipError_t leaf_launch_attention_fwd(const void* qkv, const void* kv_base, void* out, int n_seq, RowMap map, int heads,
-                                     int d, int dtype, hipStream_t s, const int32_t* eot_pos) {
+                                     int d, int dtype, hipStream_t s, const int32_t* eot_pos, int max_len) {
     if (d != heads * HD || map.ctx > 16 * MAXT || map.ctx < 1) return hipErrorInvalidValue;
+    if (max_len <= 0 || max_len > map.ctx) max_len = map.ctx;
+    const int vrows = (max_len + 31) / 32 * 32;
     static int use_tr = -1;
     if (use_tr < 0) {
         const char* e = getenv("LEAF_ATTN_TR");
@@ -189,16 +193,17 @@ hipError_t leaf_launch_attention_fwd(const void* qkv, const void* kv_base, void*
     }
     const int items = n_seq * heads;
     const dim3 grid((items + 3) / 4), blk(256);
-    const size_t lds = 4 * WAVE_LDS;
+    const size_t lds = 4 * (size_t)wave_lds_bytes(vrows);
+    const size_t lds_max = 4 * (size_t)wave_lds_bytes(96);
 #define LEAF_ATTN(TT, TR)                                                                                   \
     do {                                                                                                    \
         static bool attr = false;                                                                           \
         if (!attr) {                                                                                        \
             (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<TT, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                (int)lds);                                                                  \
+                                (int)lds_max);                                                                \
             attr = true;                                                                                    \
         }                                                                                                   \
-        hipLaunchKernelGGL((attn_fwd_kernel<TT, TR>), grid, blk, lds, s, (const u16*)qkv, (const u16*)kv_base, (u16*)out, items, map, heads, d, eot_pos); \
+        hipLaunchKernelGGL((attn_fwd_kernel<TT, TR>), grid, blk, lds, s, (const u16*)qkv, (const u16*)kv_base, (u16*)out, items, map, heads, d, eot_pos, vrows); \
     } while (0)
     if (dtype == LEAF_F16) { if (use_tr) LEAF_ATTN(F16, true); else LEAF_ATTN(F16, false); }
     else                   { if (use_tr) LEAF_ATTN(BF16, true); else LEAF_ATTN(BF16, false); }

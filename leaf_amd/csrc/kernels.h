@@ -68,7 +68,7 @@ hipError_t leaf_launch_cast(const float* src, void* dst, size_t n, int dtype, hi
 // eot_pos (device, per sequence of the launch, absolute position) != null: compute only that query row of each sequence
 // and write it to out[sequence] (last-layer trimming)
 hipError_t leaf_launch_attention_fwd(const void* qkv, const void* kv_base, void* out, int n_seq, RowMap map, int heads,
-                                     int d, int dtype, hipStream_t s, const int32_t* eot_pos = nullptr);
+                                     int d, int dtype, hipStream_t s, const int32_t* eot_pos = nullptr, int max_len = 0);
 // eot_pos[n] = first index of the maximum token id among the kept positions (torch argmax pooling)
 hipError_t leaf_launch_eot_positions(const int32_t* tokens, int32_t* eot_pos, int n_seq, RowMap map, hipStream_t s);
 // out[n,:] = x[row of position eot_pos[n] of sequence n,:]   (fp32)

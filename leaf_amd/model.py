@@ -349,7 +349,7 @@ class LeafCLIPText:
         ws = self._workspace(1, B * rho)
         _lib.check(self._lib.leaf_score_candidates_prefix(
             self._h, _ptr(self.flat), _ptr(self.w16), _ptr(t), C.c_void_p(suf.ctypes.data), _ptr(cu_dev), _ptr(pfx_dev),
-            _ptr(kv["base_cu"]), _ptr(kv["kv"]), kv["base_rows"], _ptr(anchor), B, rho, _OBJ[objective], _ptr(idx),
+            _ptr(kv["base_cu"]), _ptr(kv["kv"]), kv["base_rows"], int(full.max()), _ptr(anchor), B, rho, _OBJ[objective], _ptr(idx),
             _ptr(feat), _ptr(loss), _ptr(ws), ws.numel(), self._stream()), "leaf_score_candidates_prefix")
         return (idx, feat, loss) if want_loss else (idx, feat)
 
