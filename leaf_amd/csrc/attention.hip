@@ -10,8 +10,9 @@
 //     gfx950 transposing read ds_read_b64_tr_b16 (no software transpose).
 //   * scores are computed TRANSPOSED (S^T = K Q^T, MFMA 16x16x32): a lane then holds 4 consecutive
 //     keys of ONE query per tile, so the row softmax is in-lane plus two wave shuffles (xor 16, 32).
-//   * P goes through a 3 KiB LDS tile as the B operand of O^T = V^T P^T; the accumulator then holds
-//     4 consecutive head dims of one query -> 8-byte stores.
+//   * O^T = V^T P^T runs on the k = 16 MFMA (16x16x16): its B operand wants, per lane, 4 consecutive keys of one
+//     query - exactly what the S^T accumulators hold - so P goes from registers straight into the MFMA (no LDS
+//     round trip); the accumulator then holds 4 consecutive head dims of one query -> 8-byte stores.
 // Causality skips key tiles above the diagonal; rows >= ctx are clamped on load and never stored.
 #include "common.h"
 #include "kernels.h"
@@ -21,37 +22,28 @@ namespace {
 constexpr int HD = 64;          // head dim (all CLIP text towers)
 constexpr int MAXT = 6;         // 16-row tiles -> ctx <= 96
 constexpr int V_LD = 72;        // LDS V row stride (elements): 144 B, 16-B aligned
-constexpr int P_LD = 104;       // LDS P row stride (elements): 208 B, 16-B aligned
-constexpr int P_BYTES = 16 * P_LD * 2;
-// per-wave LDS: V image of `vrows` rows (a multiple of 32 covering the longest sequence of the launch, <= 96) + P tile;
-// 17,152 B at 96 rows, 12,544 B at 64: sizing it by the launch's longest sequence keeps more waves resident per CU
-__host__ __device__ constexpr int wave_lds_bytes(int vrows) { return vrows * V_LD * 2 + P_BYTES; }
+// per-wave LDS: the V image of `vrows` rows (a multiple of 16 covering the longest sequence of the launch, <= 96):
+// 13,824 B at 96 rows, 6,912 B at 48 - sizing it by the launch's longest sequence keeps more waves resident per CU
+__host__ __device__ constexpr int wave_lds_bytes(int vrows) { return vrows * V_LD * 2; }
 
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
 
-template <class TT, bool USE_TR>
-__device__ __forceinline__ typename TT::vec8 load_vt_frag(const char* vlds, int key0, int dim0, int lane) {
-    // A-operand fragment of V^T: lane holds V[key0 + 8*(lane>>4) + j][dim0 + (lane&15)], j = 0..7
+template <bool USE_TR>
+__device__ __forceinline__ s16x4 load_vt_frag(const char* vlds, int key0, int dim0, int lane) {
+    // A-operand fragment (k = 16) of V^T: lane holds V[key0 + 4*(lane>>4) + j][dim0 + (lane&15)], j = 0..3
     const int g = lane >> 4, i = lane & 15;
     if constexpr (USE_TR) {
         // ds_read_b64_tr_b16: per 16-lane group a 4x16 block; lane 4q+p supplies row q, cols 4p..4p+3,
         // lane i receives column i of the 4 rows.
         const int q = i >> 2, p = i & 3;
-        const char* a0 = vlds + (key0 + 8 * g + q) * (V_LD * 2) + (dim0 + 4 * p) * 2;
         typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * V_LD * 2));
-        s16x8 r;
-        r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-        r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-        return __builtin_bit_cast(typename TT::vec8, r);
+        return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (lds_s16x4*)(vlds + (key0 + 4 * g + q) * (V_LD * 2) + (dim0 + 4 * p) * 2));
     } else {
-        s16x8 r;
-        const short* base = (const short*)vlds + (key0 + 8 * g) * V_LD + dim0 + i;
+        s16x4 r;
+        const short* base = (const short*)vlds + (key0 + 4 * g) * V_LD + dim0 + i;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = base[j * V_LD];
-        return __builtin_bit_cast(typename TT::vec8, r);
+        for (int j = 0; j < 4; ++j) r[j] = base[j * V_LD];
+        return r;
     }
 }
 
@@ -64,7 +56,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const u16* __restrict__ q
     const int item = blockIdx.x * 4 + wid;
     if (item >= n_items) return;   // whole wave exits together (item is wave-uniform)
     char* vlds = smem + wid * wave_lds_bytes(vrows);
-    char* plds = vlds + vrows * (V_LD * 2);
     const int n = item / heads, h = item % heads;
     const int ld = 3 * d;
     const int sg = map.s0 + n;
@@ -143,30 +134,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const u16* __restrict__ q
             sum += __shfl_xor(sum, 16, 64);
             sum += __shfl_xor(sum, 32, 64);
             const float inv = 1.0f / sum;
-            // P -> LDS [16 q][keys], zero-filled up to the k-step boundary
-            const int nks = (qt + 2) >> 1;
-#pragma unroll
-            for (int kt = 0; kt < MAXT; ++kt) {
-                if (kt < 2 * nks) {
-                    uint2 pk = uint2{0u, 0u};
-                    if (kt <= qt) pk = pack4<TT>(sc[kt][0] * inv, sc[kt][1] * inv, sc[kt][2] * inv, sc[kt][3] * inv);
-                    *(uint2*)(plds + r16 * (P_LD * 2) + (kt * 16 + 4 * g) * 2) = pk;
-                }
-            }
-            // O^T[dim][q] = sum_k V^T[dim][k] P^T[k][q]
+            // O^T[dim][q] = sum_key V^T[dim][key] P^T[key][q], 16 keys per MFMA, P from the S^T accumulators
             f32x4 o[4];
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < 3; ++ks) {
-                if (ks < nks) {
-                    typename TT::vec8 pf =
-                        *(const typename TT::vec8*)(plds + r16 * (P_LD * 2) + (ks * 32 + 8 * g) * 2);
+            for (int kt = 0; kt < MAXT; ++kt) {
+                if (kt <= qt) {
+                    const s16x4 pf = __builtin_bit_cast(
+                        s16x4, pack4<TT>(sc[kt][0] * inv, sc[kt][1] * inv, sc[kt][2] * inv, sc[kt][3] * inv));
 #pragma unroll
-                    for (int dt = 0; dt < 4; ++dt) {
-                        typename TT::vec8 vf = load_vt_frag<TT, USE_TR>(vlds, ks * 32, dt * 16, lane);
-                        o[dt] = TT::mfma(vf, pf, o[dt]);
-                    }
+                    for (int dt = 0; dt < 4; ++dt)
+                        o[dt] = TT::mfma16(load_vt_frag<USE_TR>(vlds, kt * 16, dt * 16, lane), pf, o[dt]);
                 }
             }
             if (eot >= 0 ? qidx == eot : (qidx < ctx && qidx >= pfx)) {
@@ -185,7 +164,7 @@ hipError_t leaf_launch_attention_fwd(const void* qkv, const void* kv_base, void*
                                      int d, int dtype, hipStream_t s, const int32_t* eot_pos, int max_len) {
     if (d != heads * HD || map.ctx > 16 * MAXT || map.ctx < 1) return hipErrorInvalidValue;
     if (max_len <= 0 || max_len > map.ctx) max_len = map.ctx;
-    const int vrows = (max_len + 31) / 32 * 32;
+    const int vrows = (max_len + 15) / 16 * 16;
     static int use_tr = -1;
     if (use_tr < 0) {
         const char* e = getenv("LEAF_ATTN_TR");

@@ -27,8 +27,6 @@ constexpr int X_BYTES = 16 * MAXT * X_LD * 2;
 constexpr int P_BYTES = 16 * P_LD * 2;
 constexpr int WAVE_LDS = 3 * X_BYTES + 2 * P_BYTES;   // 48,128 B
 
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 // transposing read of a 4-row x 16-column block of a row-major 16-bit LDS image: lane i of each 16-lane group gets
@@ -43,18 +41,6 @@ __device__ __forceinline__ s16x8 tr8(const char* img, int ld_bytes, int row0, in
     r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
     return r;
 }
-
-template <class GT> struct Mfma16;
-template <> struct Mfma16<F16> {
-    static __device__ __forceinline__ f32x4 run(s16x4 a, s16x4 b, f32x4 c) {
-        return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, a), __builtin_bit_cast(f16x4, b), c, 0, 0, 0);
-    }
-};
-template <> struct Mfma16<BF16> {
-    static __device__ __forceinline__ f32x4 run(s16x4 a, s16x4 b, f32x4 c) {
-        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
-    }
-};
 
 template <class FT, class GT>
 __device__ __forceinline__ uint4 cvt8(uint4 v) {
@@ -228,8 +214,8 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const u16* __restrict
                 const s16x4 pb = tr4(plds, P_LD * 2, 4 * g, kt * 16, lane);
 #pragma unroll
                 for (int ct = 0; ct < 4; ++ct) {
-                    dk[kt][ct] = Mfma16<GT>::run(qa[ct], sb, dk[kt][ct]);
-                    dv[kt][ct] = Mfma16<GT>::run(oa[ct], pb, dv[kt][ct]);
+                    dk[kt][ct] = GT::mfma16(qa[ct], sb, dk[kt][ct]);
+                    dv[kt][ct] = GT::mfma16(oa[ct], pb, dv[kt][ct]);
                 }
             }
         }

@@ -8,6 +8,8 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef uint16_t u16;
 
 // 16-bit MFMA operand traits.  Both run v_mfma_f32_16x16x32_* at the same rate; F16 carries
@@ -18,6 +20,10 @@ struct F16 {
     using vec4 = f16x4;
     static __device__ __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+    // k = 16 form (operands as raw 16-bit lanes): lane holds A[m = l & 15][k = 4 (l >> 4) + j], B[k = 4 (l >> 4) + j][n = l & 15]
+    static __device__ __forceinline__ f32x4 mfma16(s16x4 a, s16x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, a), __builtin_bit_cast(f16x4, b), c, 0, 0, 0);
     }
     static __device__ __forceinline__ elem from_f32(float x) {
         x = __builtin_fminf(__builtin_fmaxf(x, -65504.f), 65504.f);  // saturate, never inf
@@ -31,6 +37,9 @@ struct BF16 {
     using vec4 = bf16x4;
     static __device__ __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 mfma16(s16x4 a, s16x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
     }
     static __device__ __forceinline__ elem from_f32(float x) { return (__bf16)x; }  // RTN-even, NaN kept
     static __device__ __forceinline__ float to_f32(elem x) { return (float)x; }

@@ -23,8 +23,6 @@ constexpr int SLAB = KS * LD * 2;               // 8,704 B
 constexpr int LDS_BYTES = 4 * SLAB;             // dY and X slabs, double-buffered: 34,816 B
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native vector: HIP's uint4 struct under ?: lands in scratch
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 __device__ __forceinline__ s16x8 tr8(const char* img, int row0, int col0, int lane) {
