@@ -61,7 +61,7 @@ BwdBuf carve_bwd(const leaf_text* h, Carver& c, int n_seq, size_t rows) {
     b.dx = (float*)c.take(rows * d * 4);
     b.dx16 = (uint16_t*)c.take(rows * d * 2);
     b.dx16b = (uint16_t*)c.take(rows * d * 2);
-    b.dxn = (float*)c.take(rows * d * 4);
+    b.dxn = (float*)c.take(rows * d * 4 + (size_t)n_seq * 8);   // + {mu, rstd} per sequence (pool backward scratch)
     b.big16 = (uint16_t*)c.take(rows * 4 * d * 2);
     b.dqkv = (uint16_t*)c.take(rows * 3 * d * 2);
     b.do16 = (uint16_t*)c.take(rows * d * 2);
@@ -166,7 +166,7 @@ extern "C" int leaf_textfare_backward(leaf_text_t h, const float* P, const void*
     LEAF_TRY(hipMemsetAsync(b.dx, 0, rd * 4, s));
     LEAF_TRY(leaf_launch_pool_project_bwd(b.dout, st.pooled, st.xin + (size_t)L * rd, st.eot, P + h->lnf_w, P + h->lnf_b,
                                           cf.ln_eps, P + h->text_proj, b.dx, G + h->text_proj, G + h->lnf_w,
-                                          G + h->lnf_b, b.gscale, n_seq, map, d, D, s));
+                                          G + h->lnf_b, b.gscale, n_seq, map, d, D, b.dxn /* free until the first dgrad */, s));
     LEAF_TRY(leaf_launch_cast16(b.dx, 2, b.dx16, gk, rd, s));
 
     // LEAF_WGRAD=0: first implementation (two transposes + NT GEMM per weight, atomics column sums), kept for A/B

@@ -89,7 +89,7 @@ hipError_t leaf_launch_fare_loss(const float* feat, const float* anchor, int B, 
 hipError_t leaf_launch_pool_project_bwd(const float* dout, const float* pooled, const float* x, const int32_t* eot_idx,
                                         const float* g, const float* b, float eps, const float* proj, float* dx,
                                         float* dproj, float* dg, float* db, const float* gscale, int n_seq, RowMap map,
-                                        int d, int D, hipStream_t s);
+                                        int d, int D, float* scratch /* [n_seq, d + 2] fp32 */, hipStream_t s);
 // dx_out = dx_in + LNbwd(dy, x, g);  dg += .../S, db += .../S;  dx16 = 16-bit(dx_out) of kind gkind (optional)
 hipError_t leaf_launch_layernorm_bwd(const float* dy, const float* x, const float* g, float eps, float* dx_inout,
                                      void* dx16, int gkind, const float* gscale, float* dg, float* db, int rows, int d,

@@ -102,63 +102,100 @@ __global__ __launch_bounds__(256) void proj_wgrad_kernel(const float* __restrict
     }
 }
 
-// per sequence: dpooled = dout @ proj^T ; LN_final backward on the EOT row -> dx row, dg/db atomics
-__global__ __launch_bounds__(256) void pool_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ x,
-                                                       const int32_t* __restrict__ eot_idx, const float* __restrict__ g,
-                                                       float eps, const float* __restrict__ proj, float* __restrict__ dx,
-                                                       float* __restrict__ dg, float* __restrict__ db,
-                                                       const float* __restrict__ gscale, RowMap map, int d, int D) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* sdo = (float*)smem;   // [D]
-    float* sdp = sdo + D;        // [d] dpooled
-    float* red = sdp + d;        // [8]
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    for (int j = tid; j < D; j += 256) sdo[j] = dout[(size_t)b * D + j];
-    __syncthreads();
-    for (int k = wid; k < d; k += 4) {
-        const float* pr = proj + (size_t)k * D;
-        float s = 0.f;
-        for (int j = lane; j < D; j += 64) s = fmaf(sdo[j], pr[j], s);
-        s = wave_sum(s);
-        if (lane == 0) sdp[k] = s;
+// ---- backward of projection + ln_final on the pooled (EOT) rows, three small launches (the first version did all of it
+// in one block per sequence: 128 blocks x 768 serial wave dot products = 0.85 ms)
+// dpooled[b][k] = sum_j dout[b][j] * proj[k][j];   grid (n_seq, d / 32): a wave owns 8 k with 8 independent sums
+__global__ __launch_bounds__(256) void dpooled_kernel(const float* __restrict__ dout, const float* __restrict__ proj,
+                                                      float* __restrict__ dpooled, int d, int D) {
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int k0 = blockIdx.y * 32 + wid * 8;
+    float acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+    for (int j = lane; j < D; j += 64) {
+        const float dj = dout[(size_t)b * D + j];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] = fmaf(dj, proj[(size_t)(k0 + u) * D + j], acc[u]);
     }
-    __syncthreads();
-    const size_t row = (size_t)seq_row(map, map.s0 + b) + eot_idx[b];
-    const float* xr = x + row * d;
-    // block-wide LN backward for one row
-    float s1 = 0.f;
-    for (int c = tid; c < d; c += 256) s1 += xr[c];
-    s1 = wave_sum(s1);
-    if (lane == 0) red[wid] = s1;
-    __syncthreads();
-    const float mu = (red[0] + red[1] + red[2] + red[3]) / (float)d;
-    __syncthreads();
-    float s2 = 0.f;
-    for (int c = tid; c < d; c += 256) { float a = xr[c] - mu; s2 = fmaf(a, a, s2); }
-    s2 = wave_sum(s2);
-    if (lane == 0) red[wid] = s2;
-    __syncthreads();
-    const float rstd = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)d + eps);
-    __syncthreads();
-    float m1 = 0.f, m2 = 0.f;
-    for (int c = tid; c < d; c += 256) {
-        float xh = (xr[c] - mu) * rstd, dxh = sdp[c] * g[c];
-        m1 += dxh; m2 = fmaf(dxh, xh, m2);
-    }
-    m1 = wave_sum(m1); m2 = wave_sum(m2);
-    if (lane == 0) { red[wid] = m1; red[4 + wid] = m2; }
-    __syncthreads();
-    const float mean1 = (red[0] + red[1] + red[2] + red[3]) / (float)d;
-    const float mean2 = (red[4] + red[5] + red[6] + red[7]) / (float)d;
-    for (int c = tid; c < d; c += 256) {
-        float xh = (xr[c] - mu) * rstd, dy = sdp[c], dxh = dy * g[c];
-        dx[row * d + c] = rstd * (dxh - mean1 - xh * mean2) * gscale[0];   // the gradient stream carries the loss scale
-        atomicAdd(dg + c, dy * xh);
-        atomicAdd(db + c, dy);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const float v = wave_sum(acc[u]);
+        if (lane == 0) dpooled[(size_t)b * d + k0 + u] = v;
     }
 }
 
 constexpr int MAXCH = 8;
+
+// LN_final backward of one pooled row per wave: dx row (carries the loss scale) and the row's {mu, rstd}
+__global__ __launch_bounds__(256) void pool_ln_bwd_kernel(const float* __restrict__ dpooled, const float* __restrict__ x,
+                                                          const int32_t* __restrict__ eot_idx, const float* __restrict__ g,
+                                                          float eps, float* __restrict__ dx, float* __restrict__ stats,
+                                                          const float* __restrict__ gscale, int n_seq, RowMap map, int d) {
+    const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= n_seq) return;
+    const int nq = d >> 2;
+    const size_t row = (size_t)seq_row(map, map.s0 + b) + eot_idx[b];
+    const float* xr = x + row * d;
+    float4 v[MAXCH], dyv[MAXCH];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nq) { v[i] = *(const float4*)(xr + 4 * c); s += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
+    }
+    const float mu = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nq) {
+            v[i].x -= mu; v[i].y -= mu; v[i].z -= mu; v[i].w -= mu;
+            q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nq) {
+            const float4 dy = *(const float4*)(dpooled + (size_t)b * d + 4 * c), gg = *(const float4*)(g + 4 * c);
+            v[i].x *= rstd; v[i].y *= rstd; v[i].z *= rstd; v[i].w *= rstd;                 // x_hat
+            dyv[i] = float4{dy.x * gg.x, dy.y * gg.y, dy.z * gg.z, dy.w * gg.w};           // d x_hat
+            m1 += (dyv[i].x + dyv[i].y) + (dyv[i].z + dyv[i].w);
+            m2 += (dyv[i].x * v[i].x + dyv[i].y * v[i].y) + (dyv[i].z * v[i].z + dyv[i].w * v[i].w);
+        }
+    }
+    const float mean1 = wave_sum(m1) / (float)d, mean2 = wave_sum(m2) / (float)d;
+    const float sc = rstd * gscale[0];
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nq)
+            *(float4*)(dx + row * d + 4 * c) =
+                float4{sc * (dyv[i].x - mean1 - v[i].x * mean2), sc * (dyv[i].y - mean1 - v[i].y * mean2),
+                       sc * (dyv[i].z - mean1 - v[i].z * mean2), sc * (dyv[i].w - mean1 - v[i].w * mean2)};
+    }
+    if (lane == 0) { stats[2 * b] = mu; stats[2 * b + 1] = rstd; }
+}
+
+// dg[c] += sum_b dpooled[b][c] * x_hat[b][c], db[c] += sum_b dpooled[b][c]: one thread per column, fixed order
+__global__ __launch_bounds__(256) void pool_ln_wgrad_kernel(const float* __restrict__ dpooled, const float* __restrict__ x,
+                                                            const int32_t* __restrict__ eot_idx,
+                                                            const float* __restrict__ stats, float* __restrict__ dg,
+                                                            float* __restrict__ db, int n_seq, RowMap map, int d) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= d) return;
+    float sg = 0.f, sb = 0.f;
+    for (int b = 0; b < n_seq; ++b) {
+        const size_t row = (size_t)seq_row(map, map.s0 + b) + eot_idx[b];
+        const float dy = dpooled[(size_t)b * d + c];
+        sg = fmaf(dy, (x[row * d + c] - stats[2 * b]) * stats[2 * b + 1], sg);
+        sb += dy;
+    }
+    dg[c] += sg;
+    db[c] += sb;
+}
 
 // grid-stride over rows, one wave per row; per-lane column partials for dg/db reduced at the end
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
@@ -416,14 +453,17 @@ hipError_t leaf_launch_fare_loss(const float* feat, const float* anchor, int B, 
 hipError_t leaf_launch_pool_project_bwd(const float* dout, const float* pooled, const float* x, const int32_t* eot_idx,
                                         const float* g, const float* b, float eps, const float* proj, float* dx,
                                         float* dproj, float* dg, float* db, const float* gscale, int n_seq, RowMap map,
-                                        int d, int D, hipStream_t s) {
+                                        int d, int D, float* scratch /* [n_seq, d + 2] fp32 */, hipStream_t s) {
     (void)b;
+    if (d % 32 || d > 256 * MAXCH) return hipErrorInvalidValue;
+    float* dpooled = scratch;
+    float* stats = scratch + (size_t)n_seq * d;
     hipLaunchKernelGGL(proj_wgrad_kernel, dim3(d), dim3(256), 0, s, pooled, dout, dproj, n_seq, d, D);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    size_t lds = (size_t)(D + d + 8) * sizeof(float);
-    hipLaunchKernelGGL(pool_bwd_kernel, dim3(n_seq), dim3(256), lds, s, dout, x, eot_idx, g, eps, proj, dx, dg, db, gscale,
-                       map, d, D);
+    hipLaunchKernelGGL(dpooled_kernel, dim3(n_seq, d / 32), dim3(256), 0, s, dout, proj, dpooled, d, D);
+    hipLaunchKernelGGL(pool_ln_bwd_kernel, dim3((n_seq + 3) / 4), dim3(256), 0, s, dpooled, x, eot_idx, g, eps, dx, stats,
+                       gscale, n_seq, map, d);
+    hipLaunchKernelGGL(pool_ln_wgrad_kernel, dim3((d + 255) / 256), dim3(256), 0, s, dpooled, x, eot_idx, stats, dg, db,
+                       n_seq, map, d);
     return hipGetLastError();
 }
 
