@@ -75,7 +75,7 @@ class SyntheticCandidates:
 
 
 def search_synthetic(model, anchor: torch.Tensor, base: torch.Tensor, cfg: StepConfig, seed: int,
-                     base_lens=None, prefix_reuse: bool = True) -> torch.Tensor:
+                     base_lens=None, prefix_reuse: bool = True, anchor_ready=None) -> torch.Tensor:
     """2k calls of score_candidates on [B*rho, ctx] synthetic candidates; returns the adversarial ids [B, ctx].
     ``base_lens`` (host int array, EOT position + 1 per caption) enables EOT trimming (the synthetic edits never move
     EOT); with ``prefix_reuse`` the clean captions' per-layer K/V are cached once per edit and every candidate only
@@ -90,6 +90,9 @@ def search_synthetic(model, anchor: torch.Tensor, base: torch.Tensor, cfg: StepC
     for _ in range(cfg.k_adv):
         kv = model.encode_text_kv(cur, seq_lens=base_lens) if reuse else None
         cand, pos = gen.stage1(cur)
+        if anchor_ready is not None:
+            torch.cuda.current_stream().wait_event(anchor_ready)
+            anchor_ready = None
         best1, _ = model.score_candidates(cand.view(B * cfg.rho, -1), anchor, cfg.rho, "l2", want_features=False,
                                           seq_lens=cand_lens, prefix_lens=pos.reshape(-1) if reuse else None, kv=kv)
         cand, pos2 = gen.stage2(cur, pos, best1.cpu().numpy())          # the search's device->host sync (B indices)
@@ -97,6 +100,16 @@ def search_synthetic(model, anchor: torch.Tensor, base: torch.Tensor, cfg: StepC
                                           seq_lens=cand_lens, prefix_lens=pos2.reshape(-1) if reuse else None, kv=kv)
         cur = cand[ar, best2.to(torch.int64)]
     return cur
+
+
+_SIDE = {}
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    key = torch.device(device).index
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
 
 
 def allreduce_grads(model) -> float:
@@ -112,8 +125,19 @@ def train_step_tokens(model, frozen, base: torch.Tensor, cfg: StepConfig, seed: 
                       micro_index: int = 0, base_lens=None, prefix_reuse: bool = True) -> torch.Tensor:
     """Full outer step on token ids (int32 [B, ctx] on the model's device).  Returns the TextFARE loss (0-d)."""
     model.eval()
-    anchor = frozen.encode_text(base, seq_lens=base_lens)
-    adv = search_synthetic(model, anchor, base, cfg, seed, base_lens=base_lens, prefix_reuse=prefix_reuse)
+    # The frozen model's anchor forward and the trained model's clean-caption K/V pass are independent B-sequence passes
+    # (grids that fill about half the chip each): the anchor runs on a side stream and the search waits for it right
+    # before its first scoring call.
+    cur = torch.cuda.current_stream()
+    side = _side_stream(base.device)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        anchor = frozen.encode_text(base, seq_lens=base_lens)
+        ready = torch.cuda.Event()
+        ready.record(side)
+    anchor.record_stream(cur)
+    adv = search_synthetic(model, anchor, base, cfg, seed, base_lens=base_lens, prefix_reuse=prefix_reuse,
+                           anchor_ready=ready)
     model.train()
     feat = model.forward_train(adv, seq_lens=base_lens)
     if micro_index % cfg.accum_freq == 0:
