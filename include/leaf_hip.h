@@ -161,6 +161,16 @@ int leaf_op_layernorm(const float* x, const float* g, const float* b, float eps,
                       int dtype, leaf_stream_t s);
 int leaf_op_attention_bwd(const void* qkv, int qkv_dtype, const void* dout_bf16, void* dqkv_bf16, int n_seq, int ctx,
                           int heads, int width, leaf_stream_t s);
+/* attention backward with an explicit gradient dtype (LEAF_DTYPE_*) for dout / dqkv */
+int leaf_op_attention_bwd_t(const void* qkv, int qkv_dtype, const void* dout16, void* dqkv16, int g_dtype, int n_seq,
+                            int ctx, int heads, int width, leaf_stream_t s);
+/* one problem of the grouped weight-gradient kernel: dW[Nw,Kw] += alpha dY^T X, db[Nw] += alpha colsum(dY)
+ * (dY [rows,Nw] in g_dtype, X [rows,Kw] in x_dtype, alpha a device scalar or NULL = 1; Nw, Kw multiples of 128) */
+int leaf_op_wgrad(const void* dY, const void* X, float* dW, float* db, int rows, int Nw, int Kw, int x_dtype,
+                  int g_dtype, const float* alpha_dev, leaf_stream_t s);
+/* out[M,D] = [normalize](LayerNorm(xg[M,d]; g, b) @ proj[d,D]) in fp32 on the matrix cores; xn_scratch = fp32 [M,d] */
+int leaf_op_project_rows(const float* xg, const float* g, const float* b, float eps, const float* proj,
+                         float* xn_scratch, float* out, int M, int d, int D, int normalize, leaf_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -515,3 +515,21 @@ extern "C" int leaf_op_attention_bwd(const void* qkv, int qkv_dtype, const void*
     return leaf_check(leaf_launch_attention_bwd(qkv, qkv_dtype, dout_bf16, dqkv_bf16, LEAF_BF16, n_seq,
                                                 RowMap{nullptr, 0, 0, ctx, nullptr, nullptr, 1}, heads, width, (hipStream_t)s), "attention_bwd");
 }
+extern "C" int leaf_op_attention_bwd_t(const void* qkv, int qkv_dtype, const void* dout16, void* dqkv16, int g_dtype,
+                                       int n_seq, int ctx, int heads, int width, leaf_stream_t s) {
+    return leaf_check(leaf_launch_attention_bwd(qkv, qkv_dtype, dout16, dqkv16, g_dtype, n_seq,
+                                                RowMap{nullptr, 0, 0, ctx, nullptr, nullptr, 1}, heads, width, (hipStream_t)s), "attention_bwd");
+}
+extern "C" int leaf_op_wgrad(const void* dY, const void* X, float* dW, float* db, int rows, int Nw, int Kw, int x_dtype,
+                             int g_dtype, const float* alpha_dev, leaf_stream_t s) {
+    if (!leaf_wgrad_tn_ok(Nw, Kw, Nw, Kw)) { leaf_set_error("wgrad needs Nw, Kw multiples of 128"); return 1; }
+    WgradArgs wa{};
+    wa.p[0] = WgradProb{(const uint16_t*)dY, (const uint16_t*)X, dW, db, Nw, Kw, Nw, Kw, 0, 0};
+    wa.nprob = 1; wa.rows = rows; wa.alpha = alpha_dev;
+    return leaf_check(leaf_launch_wgrad_group(wa, x_dtype, g_dtype, (hipStream_t)s), "wgrad_group");
+}
+extern "C" int leaf_op_project_rows(const float* xg, const float* g, const float* b, float eps, const float* proj,
+                                    float* xn_scratch, float* out, int M, int d, int D, int normalize, leaf_stream_t s) {
+    if (!leaf_project_rows_ok(d, D)) { leaf_set_error("project_rows needs D %% 128 == 0 and d %% 16 == 0"); return 1; }
+    return leaf_check(leaf_launch_project_rows(xg, g, b, eps, proj, xn_scratch, out, M, d, D, normalize, (hipStream_t)s), "project_rows");
+}

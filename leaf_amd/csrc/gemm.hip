@@ -50,9 +50,13 @@ __device__ __forceinline__ void epilogue_block(const GemmArgs& p, const int (&m)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 if (m[i] >= p.M) continue;
+                // (acc + bias) first, then ONE fused multiply-add with the residual: the same association in every GEMM
+                // kernel, so a row's result does not depend on which kernel the tile-count dispatch picked
                 float4 o;
-                o.x = r[i][j].x * beta + acc[i][j][0] + bias[j].x; o.y = r[i][j].y * beta + acc[i][j][1] + bias[j].y;
-                o.z = r[i][j].z * beta + acc[i][j][2] + bias[j].z; o.w = r[i][j].w * beta + acc[i][j][3] + bias[j].w;
+                o.x = __builtin_fmaf(r[i][j].x, beta, acc[i][j][0] + bias[j].x);
+                o.y = __builtin_fmaf(r[i][j].y, beta, acc[i][j][1] + bias[j].y);
+                o.z = __builtin_fmaf(r[i][j].z, beta, acc[i][j][2] + bias[j].z);
+                o.w = __builtin_fmaf(r[i][j].w, beta, acc[i][j][3] + bias[j].w);
                 *(float4*)((float*)p.C + (size_t)m[i] * p.ldc + nbase + 16 * j) = o;
             }
     } else if constexpr (EPI == EPI_ACTGRAD_T) {

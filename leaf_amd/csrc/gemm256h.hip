@@ -250,7 +250,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
                 float4 v = *(const float4*)(sl + row * 256 + (pc << 4));
                 const int m = mb + 32 * pass + row;
                 if (beta != 0.f) {
-                    v.x += res[it].x * beta; v.y += res[it].y * beta; v.z += res[it].z * beta; v.w += res[it].w * beta;
+                    v.x = __builtin_fmaf(res[it].x, beta, v.x); v.y = __builtin_fmaf(res[it].y, beta, v.y);
+                    v.z = __builtin_fmaf(res[it].z, beta, v.z); v.w = __builtin_fmaf(res[it].w, beta, v.w);
                 }
                 if (m < p.M) *(float4*)((float*)p.C + (size_t)m * p.ldc + nb + ((pc ^ (row & 15)) << 2)) = v;
             }

@@ -237,3 +237,42 @@ def test_last_layer_trim_is_bit_exact(torch_mod):
         m.trim_rows = False                      # dense rows + trimming
         m.set_option("last_layer_trim", 1)
         assert np.array_equal(m.encode_text(toks).cpu().numpy(), off)
+
+
+def test_two_stream_pipeline_is_bit_exact(torch_mod):
+    """The optional two-stream chunk pipeline (set_option('streams', 2)) splits a pass into two chunks that run on the
+    caller's stream and the handle's side stream: same rows, same kernels, identical results."""
+    m = _model("ViT-L-14", 1)
+    B, rho = 12, 50
+    base = O.synthetic_tokens(B, seed=51, min_len=20, max_len=60)
+    cand = O.synthetic_candidates(base, rho, seed=52).reshape(-1, 77)
+    lens = np.repeat(base.argmax(-1) + 1, rho)
+    assert lens.sum() >= 16384                    # enough rows for the split to engage
+    anchor = m.encode_text(base) + 0.1
+    i1, f1, l1 = m.score_candidates(cand, anchor, rho, "l2", want_loss=True, seq_lens=lens)
+    e1 = m.encode_text(cand[:700], seq_lens=lens[:700])
+    m.set_option("streams", 2)
+    i2, f2, l2 = m.score_candidates(cand, anchor, rho, "l2", want_loss=True, seq_lens=lens)
+    e2 = m.encode_text(cand[:700], seq_lens=lens[:700])
+    m.set_option("streams", 1)
+    assert torch_mod.equal(i1, i2) and torch_mod.equal(f1, f2) and torch_mod.equal(l1, l2) and torch_mod.equal(e1, e2)
+
+
+def test_prefix_reuse_is_bit_exact_across_kernels(torch_mod):
+    """ViT-L shapes: the clean captions' K/V cache comes from a 12-sequence launch (128^2 GEMM kernel), the candidate
+    rows from a 600-sequence launch (256^2 LDS-DMA kernel); prefix reuse must still equal the full recomputation bit
+    for bit (tests/test_gpu_kernels.py::test_gemm_rows_do_not_depend_on_the_kernel is the per-GEMM statement)."""
+    m = _model("ViT-L-14", 1)
+    B, rho = 12, 50
+    base = O.synthetic_tokens(B, seed=61, min_len=25, max_len=60)
+    cand = O.synthetic_candidates(base, rho, seed=62)
+    flat = cand.reshape(-1, 77)
+    neq = cand != base[:, None, :]
+    pl = neq.argmax(-1)
+    pl[~neq.any(-1)] = 77
+    anchor = m.encode_text(base) + 0.2
+    lens = np.repeat(base.argmax(-1) + 1, rho)
+    i0, f0, l0 = m.score_candidates(flat, anchor, rho, "l2", want_loss=True, seq_lens=lens)
+    kv = m.encode_text_kv(base)
+    i1, f1, l1 = m.score_candidates(flat, anchor, rho, "l2", want_loss=True, seq_lens=lens, prefix_lens=pl.reshape(-1), kv=kv)
+    assert torch_mod.equal(l0, l1) and torch_mod.equal(i0, i1) and torch_mod.equal(f0, f1)

@@ -152,3 +152,114 @@ def test_attention_bwd(env, L, H, n):
     _lib.check(lib.leaf_op_attention_bwd(ptr(tq), 1, ptr(tdo), ptr(out), n, L, H, d, stream()), "attn_bwd")
     torch.cuda.synchronize()
     assert rel_l2(out.float().cpu().numpy(), want) < 5e-3
+
+
+@pytest.mark.parametrize("fdt,gdt", [("fp16", "fp16"), ("fp16", "bf16"), ("bf16", "bf16")])
+@pytest.mark.parametrize("L,H,n", [(77, 2, 2), (20, 12, 3), (48, 2, 1), (96, 2, 1)])
+def test_attention_bwd_mfma(env, fdt, gdt, L, H, n):
+    """MFMA attention backward (attention_bwd.hip) for every forward / gradient dtype pair."""
+    lib, torch, dev = env
+    from leaf_amd import _lib
+    d = H * 64
+    rng = np.random.default_rng(L + H)
+    qkv = rng.standard_normal((n * L, 3 * d)).astype(np.float32)
+    do = rng.standard_normal((n * L, d)).astype(np.float32)
+    qr, dor = _round(qkv, fdt), _round(do, gdt)
+    _, p, q, k, v = _attention_ref(qr, n, L, H)
+    dO = dor.reshape(n, L, H, 64).transpose(0, 2, 1, 3).astype(np.float64)
+    dv = p.transpose(0, 1, 3, 2) @ dO
+    dp = dO @ v.transpose(0, 1, 3, 2)
+    ds = p * (dp - (dp * p).sum(-1, keepdims=True)) / 8.0
+    dq, dk = ds @ k, ds.transpose(0, 1, 3, 2) @ q
+    want = np.stack([dq, dk, dv], 0).transpose(1, 3, 0, 2, 4).reshape(n * L, 3 * d)
+    tq, tdo = to16(qkv, fdt, dev), to16(do, gdt, dev)
+    out = torch.zeros(n * L, 3 * d, dtype=tdo.dtype, device=dev)
+    _lib.check(lib.leaf_op_attention_bwd_t(ptr(tq), DT[fdt], ptr(tdo), ptr(out), DT[gdt], n, L, H, d, stream()), "attn_bwd")
+    torch.cuda.synchronize()
+    got = out.float().cpu().numpy()
+    assert np.isfinite(got).all()
+    assert rel_l2(got, want) < (2e-3 if gdt == "fp16" else 1.2e-2)
+
+
+@pytest.mark.parametrize("xdt,gdt", [("fp16", "fp16"), ("fp16", "bf16")])
+@pytest.mark.parametrize("rows,Nw,Kw", [(77 * 3, 256, 128), (3200, 768, 3072), (1000, 3072, 768), (33, 128, 128)])
+def test_wgrad_group(env, xdt, gdt, rows, Nw, Kw):
+    """dW += alpha dY^T X and db += alpha colsum(dY) (wgrad.hip) against float64 numpy on the rounded operands."""
+    lib, torch, dev = env
+    from leaf_amd import _lib
+    rng = np.random.default_rng(rows + Nw)
+    dy = rng.standard_normal((rows, Nw)).astype(np.float32)
+    x = rng.standard_normal((rows, Kw)).astype(np.float32)
+    w0 = rng.standard_normal((Nw, Kw)).astype(np.float32)
+    b0 = rng.standard_normal(Nw).astype(np.float32)
+    alpha = 0.25
+    dyr = _round(dy, gdt).astype(np.float64)
+    xr = _round(_round(x, xdt), gdt).astype(np.float64)     # X is converted to the gradient type when they differ
+    want_w = w0 + alpha * (dyr.T @ xr)
+    want_b = b0 + alpha * dyr.sum(0)
+    tdy, tx = to16(dy, gdt, dev), to16(x, xdt, dev)
+    tw, tb = torch.from_numpy(w0).to(dev), torch.from_numpy(b0).to(dev)
+    ta = torch.tensor([alpha], dtype=torch.float32, device=dev)
+    _lib.check(lib.leaf_op_wgrad(ptr(tdy), ptr(tx), ptr(tw), ptr(tb), rows, Nw, Kw, DT[xdt], DT[gdt], ptr(ta), stream()), "wgrad")
+    torch.cuda.synchronize()
+    assert rel_l2(tw.cpu().numpy(), want_w) < 2e-6
+    assert rel_l2(tb.cpu().numpy(), want_b) < 2e-6
+
+
+@pytest.mark.parametrize("normalize", [0, 1])
+@pytest.mark.parametrize("M,d,D", [(300, 768, 768), (64, 1024, 1024), (1, 1280, 1280), (130, 128, 128)])
+def test_project_rows(env, normalize, M, d, D):
+    """ln_final + text projection of pooled rows on the fp32 matrix cores (project.hip) against float64 numpy."""
+    lib, torch, dev = env
+    from leaf_amd import _lib
+    rng = np.random.default_rng(M + d)
+    x = (rng.standard_normal((M, d)) * 3 + 0.5).astype(np.float32)
+    g = (1 + 0.1 * rng.standard_normal(d)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(d)).astype(np.float32)
+    proj = (rng.standard_normal((d, D)) * d ** -0.5).astype(np.float32)
+    x64 = x.astype(np.float64)
+    xn = (x64 - x64.mean(-1, keepdims=True)) / np.sqrt(x64.var(-1, keepdims=True) + 1e-5) * g + b
+    want = xn @ proj.astype(np.float64)
+    if normalize:
+        want /= np.maximum(np.linalg.norm(want, axis=-1, keepdims=True), 1e-12)
+    tx, tg, tb, tp = (torch.from_numpy(a).to(dev) for a in (x, g, b, proj))
+    scratch = torch.empty(M, d, dtype=torch.float32, device=dev)
+    out = torch.zeros(M, D, dtype=torch.float32, device=dev)
+    _lib.check(lib.leaf_op_project_rows(ptr(tx), ptr(tg), ptr(tb), 1e-5, ptr(tp), ptr(scratch), ptr(out), M, d, D, normalize,
+                                        stream()), "project_rows")
+    torch.cuda.synchronize()
+    assert rel_l2(out.cpu().numpy(), want) < 3e-6
+
+
+@pytest.mark.parametrize("N,K", [(768, 768), (768, 3072), (3072, 768)])
+def test_gemm_rows_do_not_depend_on_the_kernel(env, N, K):
+    """The tile-count dispatch picks the 256^2 LDS-DMA kernel for big launches and the 128^2 kernel for small ones.
+    Every kernel accumulates k in ascending 32-steps into one fp32 accumulator per element and applies the same epilogue
+    arithmetic, so a row's result must be BIT-identical whichever kernel computed it: the exactness of the prefix reuse
+    (cache rows from a small launch, candidate rows from a big one) and of chunked passes rests on this."""
+    lib, torch, dev = env
+    from leaf_amd import _lib
+    M, CH = 12000, 2000                       # 47 x N/256 >= 128 tiles in one launch; 8 x N/256 < 128 per chunk
+    rng = np.random.default_rng(N + K)
+    a16 = to16(rng.standard_normal((M, K), dtype=np.float32), "fp16", dev)
+    b16 = to16(rng.standard_normal((N, K), dtype=np.float32) * 0.05, "fp16", dev)
+    bias = torch.from_numpy(rng.standard_normal(N).astype(np.float32)).to(dev)
+    x0 = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).to(dev)
+
+    def run(epi, rows, act=0):
+        outs = []
+        for r0 in range(0, M, rows):
+            r1 = min(M, r0 + rows)
+            a = a16[r0:r1]
+            if epi in (0, 1):
+                c = torch.zeros(r1 - r0, N, dtype=torch.float16, device=dev)
+            else:
+                c = x0[r0:r1].clone()
+            _lib.check(lib.leaf_op_gemm(1, epi, ptr(a), ptr(b16), ptr(c), ptr(bias), None, r1 - r0, N, K, act,
+                                        1.0 if epi == 3 else 0.0, 0, stream()), "gemm")
+            outs.append(c)
+        torch.cuda.synchronize()
+        return torch.cat(outs)
+
+    for epi, act in ((0, 0), (1, 0), (1, 1), (2, 0), (3, 0)):
+        assert torch.equal(run(epi, M, act), run(epi, CH, act)), f"epilogue {epi} act {act}"
