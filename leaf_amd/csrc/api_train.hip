@@ -90,7 +90,6 @@ extern "C" size_t leaf_text_stash_bytes(leaf_text_t h, int n_seq) {
 extern "C" int leaf_text_forward_train(leaf_text_t h, const float* P, const void* w16_fwd, const int32_t* tokens,
                                        const int32_t* seq_lens, const int32_t* cu_rows, int n_seq, float* out,
                                        void* stash, size_t stash_bytes, void* ws, size_t ws_bytes, leaf_stream_t s_) {
-    (void)ws; (void)ws_bytes;
     if (!h || !P || !w16_fwd || !tokens || !out || !stash || n_seq < 1) { leaf_set_error("null/invalid argument"); return 1; }
     hipStream_t s = (hipStream_t)s_;
     if ((seq_lens == nullptr) != (cu_rows == nullptr)) { leaf_set_error("seq_lens (host) and cu_rows (device) go together"); return 1; }
@@ -115,12 +114,20 @@ extern "C" int leaf_text_forward_train(leaf_text_t h, const float* P, const void
         if (l > 0) LEAF_TRY(leaf_launch_layernorm(xin, P + o.ln1_w, P + o.ln1_b, cf.ln_eps, xn1, rows, d, dt, s));
         if (leaf_gemm(dt, EPI_STORE_T, xn1, d, W + h->w16_qkv(l), d, qkv, 3 * d, P + o.qkv_b, nullptr, rows, 3 * d, d, 0, s)) return 1;
         LEAF_TRY(leaf_launch_attention_fwd(qkv, nullptr, ao, n_seq, map, cf.heads, d, dt, s, nullptr, max_len));
-        LEAF_TRY(hipMemcpyAsync(x1, xin, rd * 4, hipMemcpyDeviceToDevice, s));
-        if (leaf_gemm(dt, EPI_RESID_F32, ao, d, W + h->w16_out(l), d, x1, d, P + o.out_b, nullptr, rows, d, d, 0, s)) return 1;
+        // out-of-place residual adds (aux = residual source): the stash keeps xin, x1 and xout
+        if (leaf_gemm(dt, EPI_RESID_F32, ao, d, W + h->w16_out(l), d, x1, d, P + o.out_b, xin, rows, d, d, 0, s)) return 1;
         LEAF_TRY(leaf_launch_layernorm(x1, P + o.ln2_w, P + o.ln2_b, cf.ln_eps, xn2, rows, d, dt, s));
         if (leaf_gemm(dt, EPI_ACT_T, xn2, d, W + h->w16_fc(l), d, hh, 4 * d, P + o.fc_b, pre, rows, 4 * d, d, cf.activation, s)) return 1;
-        LEAF_TRY(hipMemcpyAsync(xout, x1, rd * 4, hipMemcpyDeviceToDevice, s));
-        if (leaf_gemm(dt, EPI_RESID_F32, hh, 4 * d, W + h->w16_proj(l), 4 * d, xout, d, P + o.proj_b, nullptr, rows, d, 4 * d, 0, s)) return 1;
+        if (leaf_gemm(dt, EPI_RESID_F32, hh, 4 * d, W + h->w16_proj(l), 4 * d, xout, d, P + o.proj_b, x1, rows, d, 4 * d, 0, s)) return 1;
+    }
+    if (leaf_project_rows_ok(d, cf.embed_dim) && ws && ws_bytes >= (size_t)n_seq * d * 4) {
+        // pooled rows -> ws, ln_final -> st.pooled (the stash the backward reads), fp32 matrix-core projection -> out
+        float* xg = (float*)ws;
+        LEAF_TRY(leaf_launch_eot_positions(tokens, st.eot, n_seq, map, s));
+        LEAF_TRY(leaf_launch_gather_rows(st.xin + (size_t)L * rd, st.eot, xg, n_seq, map, d, s));
+        LEAF_TRY(leaf_launch_project_rows(xg, P + h->lnf_w, P + h->lnf_b, cf.ln_eps, P + h->text_proj, st.pooled, out, n_seq, d,
+                                          cf.embed_dim, 0, s));
+        return 0;
     }
     LEAF_TRY(leaf_launch_pool_project(st.xin + (size_t)L * rd, tokens, P + h->lnf_w, P + h->lnf_b, cf.ln_eps,
                                       P + h->text_proj, out, st.pooled, st.eot, n_seq, map, d, cf.embed_dim, 0, s));

@@ -38,11 +38,13 @@ __device__ __forceinline__ void epilogue_block(const GemmArgs& p, const int (&m)
     if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32) {
         float4 r[NI][NJ];
         const bool rd = (EPI == EPI_RESID_F32) || p.beta != 0.f;
+        // residual source: p.aux when given (out-of-place: the training forward keeps both x and x + f(x)), else C itself
+        const float* rsrc = (EPI == EPI_RESID_F32 && p.aux) ? (const float*)p.aux : (const float*)p.C;
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-                r[i][j] = (rd && m[i] < p.M) ? *(const float4*)((const float*)p.C + (size_t)m[i] * p.ldc + nbase + 16 * j)
+                r[i][j] = (rd && m[i] < p.M) ? *(const float4*)(rsrc + (size_t)m[i] * p.ldc + nbase + 16 * j)
                                              : float4{0.f, 0.f, 0.f, 0.f};
         const float beta = (EPI == EPI_RESID_F32) ? 1.f : p.beta;
 #pragma unroll

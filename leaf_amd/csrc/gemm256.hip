@@ -263,6 +263,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_ring_kernel(GemmArgs p) {
     } else {
         // fp32 outputs: four passes of 32 rows x 64 cols: LDS rows of 256 B, 16-B chunks XOR-swizzled by (row & 15)
         const float beta = (EPI == EPI_RESID_F32) ? 1.f : p.beta;
+        const float* rsrc = (EPI == EPI_RESID_F32 && p.aux) ? (const float*)p.aux : (const float*)p.C;   // out-of-place residual
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
             float4 res[8];
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_ring_kernel(GemmArgs p) {
                 for (int it = 0; it < 8; ++it) {
                     const int row = 4 * it + (lane >> 4), pc = lane & 15;
                     const int m = mb + 32 * pass + row;
-                    res[it] = m < p.M ? *(const float4*)((const float*)p.C + (size_t)m * p.ldc + nb + ((pc ^ (row & 15)) << 2))
+                    res[it] = m < p.M ? *(const float4*)(rsrc + (size_t)m * p.ldc + nb + ((pc ^ (row & 15)) << 2))
                                       : float4{0.f, 0.f, 0.f, 0.f};
                 }
             }

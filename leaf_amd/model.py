@@ -381,9 +381,10 @@ class LeafCLIPText:
             with torch.cuda.device(self.device):
                 self._stash = torch.empty(need, dtype=torch.uint8, device=self.device)
         out = torch.empty(n, self.cfg.embed_dim, dtype=torch.float32, device=self.device)
+        ws = self._workspace(2, n)
         _lib.check(self._lib.leaf_text_forward_train(self._h, _ptr(self.flat), _ptr(self.w16), _ptr(t), lens_p, _ptr(cu),
                                                      n, _ptr(out), _ptr(self._stash), self._stash.numel(),
-                                                     C.c_void_p(0), 0, self._stream()), "leaf_text_forward_train")
+                                                     _ptr(ws), ws.numel(), self._stream()), "leaf_text_forward_train")
         self._train_tokens = t
         return out
 
