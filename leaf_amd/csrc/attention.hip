@@ -20,7 +20,8 @@
 namespace {
 
 constexpr int HD = 64;          // head dim (all CLIP text towers)
-constexpr int MAXT = 6;         // 16-row tiles -> ctx <= 96
+constexpr int MAXT_ALL = 6;     // 16-row tiles -> ctx <= 96; kernels are instantiated for 2..6 tiles (register count
+                                // follows the tile count: 140 VGPRs at 6 tiles, 3 waves per SIMD; fewer tiles, more resident waves)
 constexpr int V_LD = 72;        // LDS V row stride (elements): 144 B, 16-B aligned
 // per-wave LDS: the V image of `vrows` rows (a multiple of 16 covering the longest sequence of the launch, <= 96):
 // 13,824 B at 96 rows, 6,912 B at 48 - sizing it by the launch's longest sequence keeps more waves resident per CU
@@ -47,7 +48,7 @@ __device__ __forceinline__ s16x4 load_vt_frag(const char* vlds, int key0, int di
     }
 }
 
-template <class TT, bool USE_TR>
+template <class TT, bool USE_TR, int MAXT>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const u16* __restrict__ qkv, const u16* __restrict__ kv_base,
                                                        u16* __restrict__ out, int n_items, RowMap map, int heads, int d,
                                                        const int32_t* __restrict__ eot_pos, int vrows) {
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const u16* __restrict__ q
 
 hipError_t leaf_launch_attention_fwd(const void* qkv, const void* kv_base, void* out, int n_seq, RowMap map, int heads,
                                      int d, int dtype, hipStream_t s, const int32_t* eot_pos, int max_len) {
-    if (d != heads * HD || map.ctx > 16 * MAXT || map.ctx < 1) return hipErrorInvalidValue;
+    if (d != heads * HD || map.ctx > 16 * MAXT_ALL || map.ctx < 1) return hipErrorInvalidValue;
     if (max_len <= 0 || max_len > map.ctx) max_len = map.ctx;
     const int vrows = (max_len + 15) / 16 * 16;
     static int use_tr = -1;
@@ -174,18 +175,28 @@ hipError_t leaf_launch_attention_fwd(const void* qkv, const void* kv_base, void*
     const dim3 grid((items + 3) / 4), blk(256);
     const size_t lds = 4 * (size_t)wave_lds_bytes(vrows);
     const size_t lds_max = 4 * (size_t)wave_lds_bytes(96);
-#define LEAF_ATTN(TT, TR)                                                                                   \
+#define LEAF_ATTN(TT, TR, MT)                                                                               \
     do {                                                                                                    \
         static bool attr = false;                                                                           \
         if (!attr) {                                                                                        \
-            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<TT, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                (int)lds_max);                                                                \
+            (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<TT, TR, MT>,                             \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);            \
             attr = true;                                                                                    \
         }                                                                                                   \
-        hipLaunchKernelGGL((attn_fwd_kernel<TT, TR>), grid, blk, lds, s, (const u16*)qkv, (const u16*)kv_base, (u16*)out, items, map, heads, d, eot_pos, vrows); \
+        hipLaunchKernelGGL((attn_fwd_kernel<TT, TR, MT>), grid, blk, lds, s, (const u16*)qkv, (const u16*)kv_base,  \
+                           (u16*)out, items, map, heads, d, eot_pos, vrows);                                \
     } while (0)
-    if (dtype == LEAF_F16) { if (use_tr) LEAF_ATTN(F16, true); else LEAF_ATTN(F16, false); }
-    else                   { if (use_tr) LEAF_ATTN(BF16, true); else LEAF_ATTN(BF16, false); }
+#define LEAF_ATTN_T(TT, TR)                                                                                 \
+    switch (vrows / 16) {                                                                                   \
+        case 1: case 2: LEAF_ATTN(TT, TR, 2); break;                                                        \
+        case 3: LEAF_ATTN(TT, TR, 3); break;                                                                \
+        case 4: LEAF_ATTN(TT, TR, 4); break;                                                                \
+        case 5: LEAF_ATTN(TT, TR, 5); break;                                                                \
+        default: LEAF_ATTN(TT, TR, 6); break;                                                               \
+    }
+    if (dtype == LEAF_F16) { if (use_tr) { LEAF_ATTN_T(F16, true); } else { LEAF_ATTN_T(F16, false); } }
+    else                   { if (use_tr) { LEAF_ATTN_T(BF16, true); } else { LEAF_ATTN_T(BF16, false); } }
+#undef LEAF_ATTN_T
 #undef LEAF_ATTN
     return hipGetLastError();
 }
