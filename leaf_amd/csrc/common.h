@@ -89,6 +89,14 @@ __device__ __forceinline__ float act_fwd(float x, int act) {
     if (act == ACT_QUICKGELU) return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.4554669595930157f * x));
     return 0.5f * x * (1.f + fast_erf(x * 0.70710678118654752f));
 }
+// compile-time selected form for the GEMM epilogues (ACT < 0: identity): with the activation id a run-time value inside
+// the per-element loop the compiler emitted one branch per ELEMENT and a serial mul-exp-add-rcp-mul chain per lane
+template <int ACT>
+__device__ __forceinline__ float act_fwd_t(float x) {
+    if constexpr (ACT < 0) return x;
+    else return act_fwd(x, ACT);
+}
+
 __device__ __forceinline__ float act_bwd(float x, int act) {
     if (act == ACT_QUICKGELU) {
         float s = 1.f / (1.f + __expf(-1.702f * x));

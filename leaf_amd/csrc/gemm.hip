@@ -12,6 +12,8 @@
 //
 // Requirements checked on the host: N % 128 == 0, K % 64 == 0, row strides % 8 == 0; M is arbitrary
 // (load rows are clamped, stores masked).
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -81,21 +83,28 @@ __device__ __forceinline__ void epilogue_block(const GemmArgs& p, const int (&m)
                 *(uint2*)((u16*)p.C + (size_t)m[i] * p.ldc + nbase + 16 * j) = pack4<TT>(v[0], v[1], v[2], v[3]);
             }
     } else {
+        // the activation id is fixed at compile time inside the element loops (act_fwd_t, common.h)
+        auto body = [&](auto ACTC) {
+            constexpr int ACT = decltype(ACTC)::value;
 #pragma unroll
-        for (int i = 0; i < NI; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                if (m[i] >= p.M) continue;
-                float v[4] = {acc[i][j][0] + bias[j].x, acc[i][j][1] + bias[j].y, acc[i][j][2] + bias[j].z,
-                              acc[i][j][3] + bias[j].w};
-                const size_t o = (size_t)m[i] * p.ldc + nbase + 16 * j;
-                if constexpr (EPI == EPI_ACT_T) {
-                    if (p.aux) *(uint2*)((u16*)p.aux + o) = pack4<TT>(v[0], v[1], v[2], v[3]);
+                for (int j = 0; j < NJ; ++j) {
+                    if (m[i] >= p.M) continue;
+                    float v[4] = {acc[i][j][0] + bias[j].x, acc[i][j][1] + bias[j].y, acc[i][j][2] + bias[j].z,
+                                  acc[i][j][3] + bias[j].w};
+                    const size_t o = (size_t)m[i] * p.ldc + nbase + 16 * j;
+                    if constexpr (EPI == EPI_ACT_T) {
+                        if (p.aux) *(uint2*)((u16*)p.aux + o) = pack4<TT>(v[0], v[1], v[2], v[3]);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], p.act);
+                        for (int e = 0; e < 4; ++e) v[e] = act_fwd_t<ACT>(v[e]);
+                    }
+                    *(uint2*)((u16*)p.C + o) = pack4<TT>(v[0], v[1], v[2], v[3]);
                 }
-                *(uint2*)((u16*)p.C + o) = pack4<TT>(v[0], v[1], v[2], v[3]);
-            }
+        };
+        if constexpr (EPI != EPI_ACT_T) body(std::integral_constant<int, -1>());
+        else if (p.act == ACT_QUICKGELU) body(std::integral_constant<int, ACT_QUICKGELU>());
+        else body(std::integral_constant<int, ACT_GELU>());
     }
 }
 

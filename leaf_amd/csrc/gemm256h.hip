@@ -5,6 +5,8 @@
 // DMA piece is 8 rows x 128 B = whole 128-B lines (tools/dma_probe*.hip: 45 B/clk/CU L2-hit fill against 25 B/clk/CU
 // for the 16 x 64 B pieces of the 32-deep stages).  Five half-slots = all 160 KiB of LDS: while tile t (A_t, B_t) is
 // multiplied, A_{t+1}, B_{t+1} and A_{t+2} are in flight; ONE barrier per 64 k.
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -181,24 +183,34 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
 
     if constexpr (EPI == EPI_STORE_T || EPI == EPI_ACT_T) {
         // two passes of 64 rows x 64 cols of 16-bit: LDS rows of 128 B, 16-B chunks XOR-swizzled by (row & 7)
-        auto stage16 = [&](int pass, bool activated) {
+        // ACTC: std::integral_constant<int, -1 | ACT_GELU | ACT_QUICKGELU> - the activation is fixed at compile time inside
+        // the element loops (a run-time id there costs one branch per element and serialises the transcendental chains)
+        auto stage16 = [&](int pass, auto ACTC) {
+            constexpr int ACT = decltype(ACTC)::value;
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii) {
                 const int i = 4 * pass + ii;
                 const int row = 16 * ii + frow;
+                float v[4][4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float v[4] = {acc[i][j][0] + bias4[j].x, acc[i][j][1] + bias4[j].y, acc[i][j][2] + bias4[j].z,
-                                  acc[i][j][3] + bias4[j].w};
-                    if (activated) {
+                    v[j][0] = acc[i][j][0] + bias4[j].x; v[j][1] = acc[i][j][1] + bias4[j].y;
+                    v[j][2] = acc[i][j][2] + bias4[j].z; v[j][3] = acc[i][j][3] + bias4[j].w;
+                }
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], p.act);
-                    }
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[j][e] = act_fwd_t<ACT>(v[j][e]);     // 16 independent chains
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
                     const int c = 2 * j + (fq >> 1);
-                    *(uint2*)(sl + row * 128 + ((c ^ (row & 7)) << 4) + (fq & 1) * 8) = pack4<TT>(v[0], v[1], v[2], v[3]);
+                    *(uint2*)(sl + row * 128 + ((c ^ (row & 7)) << 4) + (fq & 1) * 8) = pack4<TT>(v[j][0], v[j][1], v[j][2], v[j][3]);
                 }
             }
         };
+        typedef std::integral_constant<int, -1> NoAct;
+        typedef std::integral_constant<int, ACT_GELU> Gelu;
+        typedef std::integral_constant<int, ACT_QUICKGELU> QuickGelu;
         auto flush16 = [&](int pass, u16* dst) {
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
@@ -211,10 +223,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
             if (EPI == EPI_ACT_T && p.aux) {   // training forward: pre-activation stash first
-                stage16(pass, false);
+                stage16(pass, NoAct());
                 flush16(pass, (u16*)p.aux);
             }
-            stage16(pass, EPI == EPI_ACT_T);
+            if (EPI != EPI_ACT_T) stage16(pass, NoAct());
+            else if (p.act == ACT_QUICKGELU) stage16(pass, QuickGelu());
+            else stage16(pass, Gelu());
             flush16(pass, (u16*)p.C);
         }
     } else {
