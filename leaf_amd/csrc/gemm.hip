@@ -108,14 +108,20 @@ __device__ __forceinline__ void epilogue_block(const GemmArgs& p, const int (&m)
     }
 }
 
-template <class TT, int EPI>
+// MI = 16-row MFMA tiles per wave in M: MI = 4 is the 128 x 128 tile described above (waves 2 x 2 of 64 x 64); MI = 2 is a
+// 64 x 128 tile (waves 2 x 2 of 32 x 64, 48 KiB of LDS, up to 3 workgroups per CU) for launches whose 128-row tiling
+// would leave CUs idle (the B-caption passes: 3,200 rows x 768 columns = 150 tiles of 128^2 on 256 CUs).
+template <class TT, int EPI, int MI>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BMt = 32 * MI;                 // tile rows
+    constexpr int ATILE = BMt * BK * 2;          // A tile bytes; the B tile stays TILE_BYTES
+    constexpr int BUF = ATILE + TILE_BYTES;      // one stage
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
     const int tiles_n = p.N / BN;
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (logical / tiles_n) * BM, n0 = (logical % tiles_n) * BN;
+    const int m0 = (logical / tiles_n) * BMt, n0 = (logical % tiles_n) * BN;
 
     // ---- staging assignment: thread -> (row r0 + 32 i, 16-B chunk c)
     const int c = tid & 7, r0 = tid >> 3;
@@ -126,8 +132,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
     auto arow = [&](int i) { int r = m0 + r0 + 32 * i; return r < p.M ? r : p.M - 1; };
     const u16* a_ptr0 = A + (size_t)arow(0) * p.lda + 8 * c;
     const u16* a_ptr1 = A + (size_t)arow(1) * p.lda + 8 * c;
-    const u16* a_ptr2 = A + (size_t)arow(2) * p.lda + 8 * c;
-    const u16* a_ptr3 = A + (size_t)arow(3) * p.lda + 8 * c;
+    const u16* a_ptr2 = A + (size_t)arow(MI > 2 ? 2 : 0) * p.lda + 8 * c;
+    const u16* a_ptr3 = A + (size_t)arow(MI > 2 ? 3 : 0) * p.lda + 8 * c;
     const u16* b_ptr0 = B + (size_t)(n0 + r0) * p.ldb + 8 * c;
     const u16* b_ptr1 = b_ptr0 + (size_t)32 * p.ldb;
     const u16* b_ptr2 = b_ptr0 + (size_t)64 * p.ldb;
@@ -138,44 +144,48 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
 #define G_LOAD(k0)                                                                                         \
     sa0 = *(const u32x4*)(a_ptr0 + (k0)); sb0 = *(const u32x4*)(b_ptr0 + (k0));                            \
     sa1 = *(const u32x4*)(a_ptr1 + (k0)); sb1 = *(const u32x4*)(b_ptr1 + (k0));                            \
-    sa2 = *(const u32x4*)(a_ptr2 + (k0)); sb2 = *(const u32x4*)(b_ptr2 + (k0));                            \
-    sa3 = *(const u32x4*)(a_ptr3 + (k0)); sb3 = *(const u32x4*)(b_ptr3 + (k0));
+    if constexpr (MI > 2) { sa2 = *(const u32x4*)(a_ptr2 + (k0)); }                                        \
+    sb2 = *(const u32x4*)(b_ptr2 + (k0));                                                                  \
+    if constexpr (MI > 2) { sa3 = *(const u32x4*)(a_ptr3 + (k0)); }                                        \
+    sb3 = *(const u32x4*)(b_ptr3 + (k0));
 #define S_STORE(buf)                                                                                       \
     {                                                                                                      \
-        char* base_ = smem + (buf) * 2 * TILE_BYTES + soff;                                                \
-        *(u32x4*)(base_) = sa0;          *(u32x4*)(base_ + TILE_BYTES) = sb0;                              \
-        *(u32x4*)(base_ + 4096) = sa1;   *(u32x4*)(base_ + TILE_BYTES + 4096) = sb1;                       \
-        *(u32x4*)(base_ + 8192) = sa2;   *(u32x4*)(base_ + TILE_BYTES + 8192) = sb2;                       \
-        *(u32x4*)(base_ + 12288) = sa3;  *(u32x4*)(base_ + TILE_BYTES + 12288) = sb3;                      \
+        char* base_ = smem + (buf) * BUF + soff;                                                           \
+        *(u32x4*)(base_) = sa0;          *(u32x4*)(base_ + ATILE) = sb0;                                   \
+        *(u32x4*)(base_ + 4096) = sa1;   *(u32x4*)(base_ + ATILE + 4096) = sb1;                            \
+        if constexpr (MI > 2) { *(u32x4*)(base_ + 8192) = sa2; }                                           \
+        *(u32x4*)(base_ + ATILE + 8192) = sb2;                                                             \
+        if constexpr (MI > 2) { *(u32x4*)(base_ + 12288) = sa3; }                                          \
+        *(u32x4*)(base_ + ATILE + 12288) = sb3;                                                            \
     }
 
-    f32x4 acc[4][4];
+    f32x4 acc[MI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int frow = lane & 15, fkc = lane >> 4;
     // fragment byte offsets inside a tile (constant over the K loop)
-    int xo[2][4], wo[2][4];
+    int xo[2][MI], wo[2][4];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            xo[ks][i] = lds_off(wm * 64 + i * 16 + frow, ks * 4 + fkc);
-            wo[ks][i] = lds_off(wn * 64 + i * 16 + frow, ks * 4 + fkc);
-        }
+        for (int i = 0; i < MI; ++i) xo[ks][i] = lds_off(wm * (16 * MI) + i * 16 + frow, ks * 4 + fkc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wo[ks][i] = lds_off(wn * 64 + i * 16 + frow, ks * 4 + fkc);
+    }
 #define COMPUTE(buf)                                                                              \
     {                                                                                             \
-        const char* sA_ = smem + (buf) * 2 * TILE_BYTES;                                          \
-        const char* sB_ = sA_ + TILE_BYTES;                                                       \
+        const char* sA_ = smem + (buf) * BUF;                                                     \
+        const char* sB_ = sA_ + ATILE;                                                            \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                        \
-            typename TT::vec8 xa[4], wb[4];                                                       \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                       \
+            typename TT::vec8 xa[MI], wb[4];                                                      \
+            _Pragma("unroll") for (int i = 0; i < MI; ++i)                                        \
                 xa[i] = *(const typename TT::vec8*)(sA_ + xo[ks][i]);                             \
-                wb[i] = *(const typename TT::vec8*)(sB_ + wo[ks][i]);                             \
-            }                                                                                     \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                         \
+                wb[i] = *(const typename TT::vec8*)(sB_ + wo[ks][i]);                             \
+            _Pragma("unroll") for (int i = 0; i < MI; ++i)                                        \
                 _Pragma("unroll") for (int j = 0; j < 4; ++j)                                     \
                     acc[i][j] = TT::mfma(wb[j], xa[i], acc[i][j]);                                \
         }                                                                                         \
@@ -206,10 +216,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
         float4 bias4[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) bias4[j] = p.bias ? *(const float4*)(p.bias + nbase + 16 * j) : float4{0.f, 0.f, 0.f, 0.f};
-        int mrow[4];
+        int mrow[MI];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) mrow[i] = m0 + wm * 64 + i * 16 + frow;
-        epilogue_block<TT, EPI, 4, 4>(p, mrow, nbase, bias4, acc);
+        for (int i = 0; i < MI; ++i) mrow[i] = m0 + wm * (16 * MI) + i * 16 + frow;
+        epilogue_block<TT, EPI, MI, 4>(p, mrow, nbase, bias4, acc);
     }
 }
 
@@ -343,20 +353,30 @@ hipError_t launch_t(const GemmArgs& p, int epi, hipStream_t s) {
     static int use256 = -1;
     if (use256 < 0) { const char* e = getenv("LEAF_GEMM256"); use256 = (e && e[0] == '0') ? 0 : 1; }
     const bool big = use256 && p.N % BN2 == 0 && (long)((p.M + BM2 - 1) / BM2) * (p.N / BN2) >= 128;
-    const int grid = big ? ((p.M + BM2 - 1) / BM2) * (p.N / BN2) : ((p.M + BM - 1) / BM) * (p.N / BN);
-    const size_t lds = big ? 2 * STAGE2 : 4 * TILE_BYTES;
+    // 128-row tiles unless they would leave CUs idle (fewer tiles than the chip has CUs): then 64-row tiles.
+    // LEAF_GEMM_BM64=0 disables the 64-row variant (A/B runs).
+    static int bm64 = -1;
+    if (bm64 < 0) { const char* e = getenv("LEAF_GEMM_BM64"); bm64 = (e && e[0] == '0') ? 0 : 1; }
+    const long t128 = (long)((p.M + BM - 1) / BM) * (p.N / BN);
+    const bool half_m = !big && bm64 && t128 < 256 && p.M > 64;
+    const int grid = big ? ((p.M + BM2 - 1) / BM2) * (p.N / BN2)
+                         : (half_m ? ((p.M + 63) / 64) * (p.N / BN) : (int)t128);
+    const size_t lds = big ? 2 * STAGE2 : (half_m ? 2 * (64 * BK * 2 + TILE_BYTES) : 4 * TILE_BYTES);
 #define LEAF_GEMM_CASE(E)                                                                    \
     case E: {                                                                                \
         static bool attr_done = false;                                                       \
         if (!attr_done) {                                                                    \
-            (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<TT, E>,                    \
+            (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<TT, E, 4>,                 \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES); \
+            (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<TT, E, 2>,                 \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES); \
             (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<TT, E>,                 \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE2);     \
             attr_done = true;                                                                \
         }                                                                                    \
         if (big) hipLaunchKernelGGL((gemm_nt256_kernel<TT, E>), dim3(grid), dim3(512), lds, s, p); \
-        else hipLaunchKernelGGL((gemm_nt_kernel<TT, E>), dim3(grid), dim3(256), lds, s, p);  \
+        else if (half_m) hipLaunchKernelGGL((gemm_nt_kernel<TT, E, 2>), dim3(grid), dim3(256), lds, s, p); \
+        else hipLaunchKernelGGL((gemm_nt_kernel<TT, E, 4>), dim3(grid), dim3(256), lds, s, p); \
         break;                                                                               \
     }
     switch (epi) {
