@@ -121,6 +121,8 @@ def main():
         base[i, 1 + n] = cfg.vocab_size - 1
     base_lens = None if args.dense else (lens.numpy().astype(np.int32) + 2)   # SOT + n ids + EOT rows are kept
     base = base.to(dev)
+    base_ready = torch.cuda.Event()
+    base_ready.record()
 
     def barrier():
         if use_dist:
@@ -129,7 +131,8 @@ def main():
 
     step_id = 0
     for _ in range(args.warmup):
-        train_step_tokens(model, frozen, base, sc, seed=step_id, base_lens=base_lens, prefix_reuse=not args.no_prefix_reuse)
+        train_step_tokens(model, frozen, base, sc, seed=step_id, base_lens=base_lens, prefix_reuse=not args.no_prefix_reuse,
+                          base_ready=base_ready)
         step_id += 1
     lib = _lib.lib()
     barrier()
@@ -138,7 +141,8 @@ def main():
     t0 = time.perf_counter()
     loss = None
     for _ in range(args.steps):
-        loss = train_step_tokens(model, frozen, base, sc, seed=step_id, base_lens=base_lens, prefix_reuse=not args.no_prefix_reuse)
+        loss = train_step_tokens(model, frozen, base, sc, seed=step_id, base_lens=base_lens, prefix_reuse=not args.no_prefix_reuse,
+                          base_ready=base_ready)
         step_id += 1
     barrier()
     dt = time.perf_counter() - t0

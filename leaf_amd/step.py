@@ -122,15 +122,23 @@ def allreduce_grads(model) -> float:
 
 
 def train_step_tokens(model, frozen, base: torch.Tensor, cfg: StepConfig, seed: int, lr: Optional[float] = None,
-                      micro_index: int = 0, base_lens=None, prefix_reuse: bool = True) -> torch.Tensor:
-    """Full outer step on token ids (int32 [B, ctx] on the model's device).  Returns the TextFARE loss (0-d)."""
+                      micro_index: int = 0, base_lens=None, prefix_reuse: bool = True,
+                      base_ready: Optional["torch.cuda.Event"] = None) -> torch.Tensor:
+    """Full outer step on token ids (int32 [B, ctx] on the model's device).  Returns the TextFARE loss (0-d).
+    ``base_ready``: event after which ``base`` is valid.  The anchor forward depends only on ``base`` and the FROZEN
+    weights, so with this event its side stream need not wait for the previous step's backward / all-reduce / AdamW
+    still queued on the current stream and the anchor of step i+1 overlaps the tail of step i; without it the side
+    stream waits for everything queued so far (always safe)."""
     model.eval()
     # The frozen model's anchor forward and the trained model's clean-caption K/V pass are independent B-sequence passes
     # (grids that fill about half the chip each): the anchor runs on a side stream and the search waits for it right
     # before its first scoring call.
     cur = torch.cuda.current_stream()
     side = _side_stream(base.device)
-    side.wait_stream(cur)
+    if base_ready is not None:
+        side.wait_event(base_ready)
+    else:
+        side.wait_stream(cur)
     with torch.cuda.stream(side):
         anchor = frozen.encode_text(base, seq_lens=base_lens)
         ready = torch.cuda.Event()
