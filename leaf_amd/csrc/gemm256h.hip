@@ -59,7 +59,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
     const unsigned b0 = (unsigned)(n0 + wid * 32 + prow) * (unsigned)p.ldb * 2u + schunk * 16;
     const unsigned bstep = 16u * (unsigned)p.ldb;   // 8 rows, bytes
     const int piece = wid * 4096;
+#ifdef LEAF_DIAG_NODMA   // diagnostic only: no operand traffic at all (results are garbage) - isolates the MFMA + LDS-read loop
+#define DMA16(src, dst) asm volatile("" ::"v"(src), "v"(dst))
+#else
 #define DMA16(src, dst) __builtin_amdgcn_global_load_lds((glb_void_t*)(src), (lds_void_t*)(dst), 16, 0, 0)
+#endif
     // piece q (0..3) of half-stage u: u even = A panel of K tile u/2, u odd = B panel
     // (so = byte offset of the ring slot that half-stage lands in, kt = its K tile)
 #define ISSUE_A(so, kt, q) DMA16(A + (size_t)((kt) * (BK * 2)) + ((q) == 0 ? a0 : (q) == 1 ? a1 : (q) == 2 ? a2 : a3), smem + (so) + piece + (q) * 1024)
@@ -77,9 +81,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
     const int fo0 = lds_off_h(frow, fkc), fo1 = lds_off_h(frow, 4 + fkc);   // k-step 0 / 1 inside a 64-deep tile
     const int xbase = wm * 128 * 128, wbase = wn * 64 * 128;
     typedef typename TT::vec8 frag_t;
+#ifdef LEAF_DIAG_NOREAD
+    frag_t dummy_frag;
+    asm volatile("" : "=v"(dummy_frag));
+#endif
     frag_t Fx0, Fx1, Fx2, Fx3, Fx4, Fx5, Fx6, Fx7, Fw0, Fw1, Fw2, Fw3;
     frag_t Gx0, Gx1, Gx2, Gx3, Gx4, Gx5, Gx6, Gx7, Gw0, Gw1, Gw2, Gw3;
+#ifdef LEAF_DIAG_NOREAD   // diagnostic only: no fragment reads (stale registers feed the MFMAs)
+#define LD(ptr) (dummy_frag)
+#else
 #define LD(ptr) (*(const frag_t*)(ptr))
+#endif
     // fragments of one 32-deep k-step: A panel at ring offset sa, B panel at sb
 #define READ_FRAGS(P, sa, sb, fo)                                                                            \
     {                                                                                                        \
@@ -95,13 +107,25 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
 #define MFMA_H1(P) MROW(P, 0, P##x0) MROW(P, 1, P##x1) MROW(P, 2, P##x2) MROW(P, 3, P##x3)
 #define MFMA_H2(P) MROW(P, 4, P##x4) MROW(P, 5, P##x5) MROW(P, 6, P##x6) MROW(P, 7, P##x7)
 #define SB __builtin_amdgcn_sched_barrier(0);
+#ifdef LEAF_DIAG_NOBAR    // diagnostic only: no per-tile workgroup barrier
+#define DIAG_BARRIER
+#else
+#define DIAG_BARRIER __builtin_amdgcn_s_barrier();
+#endif
 #define SYNC_TILE(cnt)                                                                                       \
     SB                                                                                                       \
     asm volatile("s_waitcnt vmcnt(" #cnt ") lgkmcnt(0)" ::: "memory");                                       \
-    __builtin_amdgcn_s_barrier();                                                                            \
+    DIAG_BARRIER                                                                                             \
     asm volatile("" ::: "memory");
-    // one 32-deep k-step: fragments of (T, ks) are read first, the second half of the previous k-step's MFMAs covers
-    // their latency with the four DMA pieces of half-stage u spread in between (IS = issue macro or nothing)
+    // one 32-deep k-step, software-pipelined at instruction granularity: the 12 fragment reads of this k-step (CUR) are
+    // issued ONE AT A TIME in the shadow of individual MFMAs - first under the second half (rows 4-7) of the previous
+    // k-step's MFMAs, the last four (rows 4-7 of CUR, not needed before the next k-step) under CUR's own first half -
+    // instead of twelve back-to-back ds_read_b128 that stall the wave's in-order MFMA issue (diagnostic builds: the
+    // bunched reads cost 10 % of a tile).  The four DMA pieces of a half-stage are spread in between (IS = issue macro).
+#define MF(P, i, j) acc[i][j] = TT::mfma(P##w##j, P##x##i, acc[i][j]);
+#define RDW(P, n) P##w##n = LD(sb_ + (n) * 2048);
+#define RDX(P, n) P##x##n = LD(sa_ + (n) * 2048);
+#ifdef LEAF_GEMM_BUNCHED_READS   // the previous schedule, kept for A/B builds
 #define KSTEP(PREV, CUR, sa, sb, fo, IS0, IS1, IS2, IS3)                                                     \
     READ_FRAGS(CUR, sa, sb, fo)                                                                              \
     SB MROW(PREV, 4, PREV##x4) SB IS0                                                                        \
@@ -109,6 +133,23 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
     SB MROW(PREV, 6, PREV##x6) SB IS2                                                                        \
     SB MROW(PREV, 7, PREV##x7) SB IS3                                                                        \
     SB MFMA_H1(CUR)
+#else
+#define KSTEP(PREV, CUR, sa, sb, fo, IS0, IS1, IS2, IS3)                                                     \
+    {                                                                                                        \
+        const char* sa_ = smem + (sa) + xbase + (fo);                                                        \
+        const char* sb_ = smem + (sb) + wbase + (fo);                                                        \
+        SB MF(PREV, 4, 0) SB RDW(CUR, 0) SB MF(PREV, 4, 1) SB RDW(CUR, 1) SB MF(PREV, 4, 2) SB RDW(CUR, 2)    \
+        SB MF(PREV, 4, 3) SB RDW(CUR, 3) SB IS0                                                              \
+        SB MF(PREV, 5, 0) SB RDX(CUR, 0) SB MF(PREV, 5, 1) MF(PREV, 5, 2) SB RDX(CUR, 1) SB MF(PREV, 5, 3)    \
+        SB IS1                                                                                               \
+        SB MF(PREV, 6, 0) SB RDX(CUR, 2) SB MF(PREV, 6, 1) MF(PREV, 6, 2) SB RDX(CUR, 3) SB MF(PREV, 6, 3)    \
+        SB IS2                                                                                               \
+        SB MROW(PREV, 7, PREV##x7) SB IS3                                                                    \
+        SB MF(CUR, 0, 0) SB RDX(CUR, 4) SB MF(CUR, 0, 1) MF(CUR, 0, 2) SB RDX(CUR, 5) SB MF(CUR, 0, 3)        \
+        SB MF(CUR, 1, 0) SB RDX(CUR, 6) SB MF(CUR, 1, 1) MF(CUR, 1, 2) SB RDX(CUR, 7) SB MF(CUR, 1, 3)        \
+        SB MROW(CUR, 2, CUR##x2) MROW(CUR, 3, CUR##x3) SB                                                    \
+    }
+#endif
 #define NOP_
 
     const int nt = p.K / BK;   // K tiles, >= 4 (host-checked)
@@ -158,6 +199,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
 #undef MFMA_H2
 #undef SYNC_TILE
 #undef KSTEP
+#undef MF
+#undef RDW
+#undef RDX
 #undef NOP_
 #undef SB
 #undef LD
