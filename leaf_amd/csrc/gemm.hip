@@ -398,8 +398,8 @@ hipError_t launch_t(const GemmArgs& p, int epi, hipStream_t s) {
 int leaf_gemm_family(const GemmArgs& p, int epi) {
     static int ver = -1;
     if (ver < 0) { const char* e = getenv("LEAF_GEMM_V"); ver = e ? atoi(e) : 4; }
-    if (ver == 4 && p.M > 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && leaf_gemm256h_eligible(p, epi)) return 4;
-    if (ver >= 2 && p.M > 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && leaf_gemm256_eligible(p, epi)) return ver >= 3 ? 3 : 2;
+    if ((ver == 4 || ver == 5) && p.M > 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && leaf_gemm256h_eligible(p, epi)) return ver;
+    if (ver >= 2 && p.M > 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && leaf_gemm256_eligible(p, epi)) return ver == 3 ? 3 : 2;
     static int use256 = -1;
     if (use256 < 0) { const char* e = getenv("LEAF_GEMM256"); use256 = (e && e[0] == '0') ? 0 : 1; }
     return (use256 && p.N % 256 == 0 && (long)((p.M + 255) / 256) * (p.N / 256) >= 128) ? 1 : 0;
@@ -413,11 +413,13 @@ hipError_t leaf_launch_gemm(const GemmArgs& p_in, int dtype, int epi, hipStream_
     p.stamps = g_stamps;
     // LEAF_GEMM_V: 1 = previous-generation kernels, 2 = 32-deep ring kernel, 3 = persistent ring (gemm256p.hip; measured
     // 3-4 % SLOWER than 2 on the text-tower shapes), 4 = 64-deep half-stage ring with full-line DMA pieces (gemm256h.hip,
-    // default: +8 % over 2 on the layer's four GEMMs); shapes a kernel cannot take fall through to the next one down
+    // default: +8 % over 2 on the layer's four GEMMs), 5 = persistent form of 4 (gemm256hp.hip: next tile's first
+    // half-stages land under the epilogue; measured equal to 4: 844.5 vs 845.2 TF/s over a layer's GEMMs, so not the
+    // default); shapes a kernel cannot take fall through to the next one down
     static int ver = -1;
     if (ver < 0) { const char* e = getenv("LEAF_GEMM_V"); ver = e ? atoi(e) : 4; }
-    if (ver == 4 && p.M > 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && leaf_gemm256h_eligible(p, epi))
-        return leaf_launch_gemm256h(p, dtype, epi, s);
+    if ((ver == 4 || ver == 5) && p.M > 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && leaf_gemm256h_eligible(p, epi))
+        return ver == 5 ? leaf_launch_gemm256hp(p, dtype, epi, s) : leaf_launch_gemm256h(p, dtype, epi, s);
     if (ver >= 2 && p.M > 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && leaf_gemm256_eligible(p, epi))
         return ver == 3 ? leaf_launch_gemm256p(p, dtype, epi, s) : leaf_launch_gemm256(p, dtype, epi, s);
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.N % BN || p.K % BK || p.lda % 8 || p.ldb % 8 || p.ldc % 4)
