@@ -19,10 +19,13 @@ def main():
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     tot_ms, tot_fl = 0.0, 0.0
     pad = int(os.environ.get("PAD", "0"))     # extra elements per row (stride experiments)
+    zero = os.environ.get("ZERO", "0") == "1"  # zero operands: same instruction stream, far less switching energy (clock probe)
     for name, epi, N, K in shapes:
         A = (torch.randn(M, K + pad, device=dev) * 0.5).half()
         B = (torch.randn(N, K + pad, device=dev) * 0.05).half()
         bias = torch.randn(N, device=dev)
+        if zero:
+            A.zero_(); B.zero_(); bias.zero_()
         Cm = torch.zeros(M, N + pad, device=dev, dtype=torch.float32 if epi == 2 else torch.float16)
         args = (1, epi, C.c_void_p(A.data_ptr()), K + pad, C.c_void_p(B.data_ptr()), K + pad, C.c_void_p(Cm.data_ptr()),
                 N + pad, C.c_void_p(bias.data_ptr()), None, M, N, K, 1, 0.0, 0, st)
