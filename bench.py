@@ -25,7 +25,8 @@ sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS_16BIT = 2500.0  # MI355X dense bf16/fp16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
 FAMILY = {0: "gemm_nt_kernel", 1: "gemm_nt256_kernel", 2: "gemm_nt256_ring_kernel", 3: "gemm_nt256_persist_kernel",
-          4: "gemm_nt256_half_kernel", 5: "gemm_nt256_halfp_kernel"}
+          4: "gemm_nt256_half_kernel", 5: "gemm_nt256_halfp_kernel",
+          6: "gemm_nt64_ring_kernel"}
 EPI_NAMES = {0: "store16(qkv)", 1: "act16(c_fc)", 2: "resid32(out_proj+c_proj)", 3: "store32(wgrad/dgrad)", 4: "actgrad16"}
 
 
@@ -152,7 +153,7 @@ def main():
     dt = float(tmax.item())
 
     if rank == 0:
-        nk = 96
+        nk = 128
         ms, fl, by, cnt = (C.c_double * nk)(), (C.c_double * nk)(), (C.c_double * nk)(), (C.c_int64 * nk)()
         _lib.check(lib.leaf_prof_end(ms, fl, by, cnt, nk), "leaf_prof_end")
         kinds = [(ms[i], fl[i], cnt[i], i) for i in range(nk) if cnt[i] > 0]

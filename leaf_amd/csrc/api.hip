@@ -183,7 +183,7 @@ extern "C" int leaf_prof_begin(void) {
     return 0;
 }
 
-// Stops recording, waits for the recorded events and sums per key (= kernel_family*16 + dtype*8 + epilogue id, < 96):
+// Stops recording, waits for the recorded events and sums per key (= kernel_family*16 + dtype*8 + epilogue id, < 128):
 // ms[key], flops[key], bytes[key] (algorithmic operand + output bytes, may be null), count[key].
 extern "C" int leaf_prof_end(double* ms, double* flops, double* bytes, int64_t* count, int n_keys) {
     g_prof_on = false;

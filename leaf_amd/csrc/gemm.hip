@@ -12,10 +12,7 @@
 //
 // Requirements checked on the host: N % 128 == 0, K % 64 == 0, row strides % 8 == 0; M is arbitrary
 // (load rows are clamped, stores masked).
-#include <type_traits>
-
-#include "common.h"
-#include "kernels.h"
+#include "gemm_epilogue.h"
 
 namespace {
 
@@ -23,90 +20,6 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
-
-// Epilogue for one accumulator row-group: NJ fragments (columns n0j + 16 j) of NI rows.  Bias is loaded once per
-// column group; read-modify-write operands (residual / pre-activation) are fetched for the whole batch BEFORE any
-// arithmetic so the loads overlap instead of serialising one L2 round trip per fragment.
-template <class TT, int EPI, int NI, int NJ>
-__device__ __forceinline__ void epilogue_block(const GemmArgs& p, const int (&m)[NI], int nbase, const float4 (&bias)[NJ],
-                                               f32x4 (&acc)[NI][NJ]) {
-    if (p.alpha) {   // gradient un-scaling (weight gradients of the fp16 loss-scaled backward)
-        const float al = *p.alpha;
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[i][j] *= al;
-    }
-    if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32) {
-        float4 r[NI][NJ];
-        const bool rd = (EPI == EPI_RESID_F32) || p.beta != 0.f;
-        // residual source: p.aux when given (out-of-place: the training forward keeps both x and x + f(x)), else C itself
-        const float* rsrc = (EPI == EPI_RESID_F32 && p.aux) ? (const float*)p.aux : (const float*)p.C;
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-                r[i][j] = (rd && m[i] < p.M) ? *(const float4*)(rsrc + (size_t)m[i] * p.ldc + nbase + 16 * j)
-                                             : float4{0.f, 0.f, 0.f, 0.f};
-        const float beta = (EPI == EPI_RESID_F32) ? 1.f : p.beta;
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                if (m[i] >= p.M) continue;
-                // (acc + bias) first, then ONE fused multiply-add with the residual: the same association in every GEMM
-                // kernel, so a row's result does not depend on which kernel the tile-count dispatch picked
-                float4 o;
-                o.x = __builtin_fmaf(r[i][j].x, beta, acc[i][j][0] + bias[j].x);
-                o.y = __builtin_fmaf(r[i][j].y, beta, acc[i][j][1] + bias[j].y);
-                o.z = __builtin_fmaf(r[i][j].z, beta, acc[i][j][2] + bias[j].z);
-                o.w = __builtin_fmaf(r[i][j].w, beta, acc[i][j][3] + bias[j].w);
-                *(float4*)((float*)p.C + (size_t)m[i] * p.ldc + nbase + 16 * j) = o;
-            }
-    } else if constexpr (EPI == EPI_ACTGRAD_T) {
-        uint2 u[NI][NJ];
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-                u[i][j] = m[i] < p.M ? *(const uint2*)((const u16*)p.aux + (size_t)m[i] * p.ldc + nbase + 16 * j) : uint2{0u, 0u};
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                if (m[i] >= p.M) continue;
-                float pre[4];
-                if (p.aux_f16) unpack4<F16>(u[i][j], pre); else unpack4<BF16>(u[i][j], pre);
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * act_bwd(pre[e], p.act);
-                *(uint2*)((u16*)p.C + (size_t)m[i] * p.ldc + nbase + 16 * j) = pack4<TT>(v[0], v[1], v[2], v[3]);
-            }
-    } else {
-        // the activation id is fixed at compile time inside the element loops (act_fwd_t, common.h)
-        auto body = [&](auto ACTC) {
-            constexpr int ACT = decltype(ACTC)::value;
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    if (m[i] >= p.M) continue;
-                    float v[4] = {acc[i][j][0] + bias[j].x, acc[i][j][1] + bias[j].y, acc[i][j][2] + bias[j].z,
-                                  acc[i][j][3] + bias[j].w};
-                    const size_t o = (size_t)m[i] * p.ldc + nbase + 16 * j;
-                    if constexpr (EPI == EPI_ACT_T) {
-                        if (p.aux) *(uint2*)((u16*)p.aux + o) = pack4<TT>(v[0], v[1], v[2], v[3]);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = act_fwd_t<ACT>(v[e]);
-                    }
-                    *(uint2*)((u16*)p.C + o) = pack4<TT>(v[0], v[1], v[2], v[3]);
-                }
-        };
-        if constexpr (EPI != EPI_ACT_T) body(std::integral_constant<int, -1>());
-        else if (p.act == ACT_QUICKGELU) body(std::integral_constant<int, ACT_QUICKGELU>());
-        else body(std::integral_constant<int, ACT_GELU>());
-    }
-}
 
 // MI = 16-row MFMA tiles per wave in M: MI = 4 is the 128 x 128 tile described above (waves 2 x 2 of 64 x 64); MI = 2 is a
 // 64 x 128 tile (waves 2 x 2 of 32 x 64, 48 KiB of LDS, up to 3 workgroups per CU) for launches whose 128-row tiling
@@ -393,8 +306,15 @@ hipError_t launch_t(const GemmArgs& p, int epi, hipStream_t s) {
 
 }  // namespace
 
+// small launches: the 64 x 128 LDS-DMA ring kernel (gemm64.hip) unless LEAF_GEMM64=0
+static bool use_gemm64(const GemmArgs& p) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("LEAF_GEMM64"); on = (e && e[0] == '0') ? 0 : 1; }
+    return on && leaf_gemm64_eligible(p);
+}
+
 // which kernel leaf_launch_gemm will pick: 0 = gemm_nt_kernel (128^2), 1 = gemm_nt256_kernel, 2 = ring, 3 = persistent,
-// 4 = half-stage ring (gemm256h.hip, the default where eligible)
+// 4 = half-stage ring (gemm256h.hip, the default where eligible), 5 = its persistent form, 6 = 64 x 128 ring (gemm64.hip)
 int leaf_gemm_family(const GemmArgs& p, int epi) {
     static int ver = -1;
     if (ver < 0) { const char* e = getenv("LEAF_GEMM_V"); ver = e ? atoi(e) : 4; }
@@ -402,7 +322,8 @@ int leaf_gemm_family(const GemmArgs& p, int epi) {
     if (ver >= 2 && p.M > 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && leaf_gemm256_eligible(p, epi)) return ver == 3 ? 3 : 2;
     static int use256 = -1;
     if (use256 < 0) { const char* e = getenv("LEAF_GEMM256"); use256 = (e && e[0] == '0') ? 0 : 1; }
-    return (use256 && p.N % 256 == 0 && (long)((p.M + 255) / 256) * (p.N / 256) >= 128) ? 1 : 0;
+    if (use256 && p.N % 256 == 0 && (long)((p.M + 255) / 256) * (p.N / 256) >= 128) return 1;
+    return use_gemm64(p) ? 6 : 0;
 }
 
 static void* g_stamps = nullptr;
@@ -424,5 +345,6 @@ hipError_t leaf_launch_gemm(const GemmArgs& p_in, int dtype, int epi, hipStream_
         return ver == 3 ? leaf_launch_gemm256p(p, dtype, epi, s) : leaf_launch_gemm256(p, dtype, epi, s);
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.N % BN || p.K % BK || p.lda % 8 || p.ldb % 8 || p.ldc % 4)
         return hipErrorInvalidValue;
+    if (leaf_gemm_family(p, epi) == 6) return leaf_launch_gemm64(p, dtype, epi, s);
     return dtype == LEAF_F16 ? launch_t<F16>(p, epi, s) : launch_t<BF16>(p, epi, s);
 }

@@ -40,6 +40,9 @@ hipError_t leaf_launch_gemm256p(const GemmArgs& p, int dtype, int epi, hipStream
 // 64-deep half-stage ring with full-line DMA pieces (gemm256h.hip)
 bool leaf_gemm256h_eligible(const GemmArgs& p, int epi);
 hipError_t leaf_launch_gemm256h(const GemmArgs& p, int dtype, int epi, hipStream_t s);
+// 64 x 128 tiles on a 3-slot LDS-DMA ring for small launches (gemm64.hip)
+bool leaf_gemm64_eligible(const GemmArgs& p);
+hipError_t leaf_launch_gemm64(const GemmArgs& p, int dtype, int epi, hipStream_t s);
 // persistent form of the same kernel (gemm256hp.hip): next tile's first half-stages land under the epilogue
 hipError_t leaf_launch_gemm256hp(const GemmArgs& p, int dtype, int epi, hipStream_t s);
 
