@@ -54,24 +54,33 @@ class SyntheticCandidates:
             base_lens = (base.argmax(-1) + 1).cpu().numpy()
         self.inner = np.asarray(base_lens, dtype=np.int64) - 2          # ids between SOT and EOT
 
-    def _apply(self, cur, pos_host):
+    def _draw(self, cur):
+        """Everything of a stage that does not depend on the positions: the rho copies of the caption rows and the
+        replacement ids (drawn on the device).  Stage 2 calls this BEFORE the host waits for the stage-1 winners, so the
+        device has work queued while the host plans the rows."""
         B, rho = self.B, self.rho
-        pos = torch.from_numpy(pos_host).pin_memory().to(cur.device, non_blocking=True)
         ids = torch.randint(1, self.vocab - 2, (B, rho), device=cur.device, generator=self.gen, dtype=torch.int32)
-        cand = cur[:, None, :].repeat(1, rho, 1)
+        return cur[:, None, :].repeat(1, rho, 1), ids
+
+    def _apply(self, drawn, pos_host):
+        cand, ids = drawn
+        pos = torch.from_numpy(pos_host).pin_memory().to(cand.device, non_blocking=True)
         cand.scatter_(2, pos[:, :, None], ids[:, :, None])
         return cand
 
     def stage1(self, cur: torch.Tensor):
         import numpy as np
         pos = 1 + (self.rng.random((self.B, self.rho)) * self.inner[:, None]).astype(np.int64)
-        return self._apply(cur, pos), pos
+        return self._apply(self._draw(cur), pos), pos
 
-    def stage2(self, cur: torch.Tensor, pos, best1_host):
+    def stage2_draw(self, cur: torch.Tensor):
+        return self._draw(cur)
+
+    def stage2(self, drawn, pos, best1_host):
         import numpy as np
         p = pos[np.arange(self.B), best1_host]
         pos2 = np.repeat(p[:, None], self.rho, axis=1)
-        return self._apply(cur, pos2), pos2
+        return self._apply(drawn, pos2), pos2
 
 
 def search_synthetic(model, anchor: torch.Tensor, base: torch.Tensor, cfg: StepConfig, seed: int,
@@ -95,7 +104,8 @@ def search_synthetic(model, anchor: torch.Tensor, base: torch.Tensor, cfg: StepC
             anchor_ready = None
         best1, _ = model.score_candidates(cand.view(B * cfg.rho, -1), anchor, cfg.rho, "l2", want_features=False,
                                           seq_lens=cand_lens, prefix_lens=pos.reshape(-1) if reuse else None, kv=kv)
-        cand, pos2 = gen.stage2(cur, pos, best1.cpu().numpy())          # the search's device->host sync (B indices)
+        drawn = gen.stage2_draw(cur)                                     # queued behind stage 1, before the host waits
+        cand, pos2 = gen.stage2(drawn, pos, best1.cpu().numpy())        # the search's device->host sync (B indices)
         best2, _ = model.score_candidates(cand.view(B * cfg.rho, -1), anchor, cfg.rho, "l2", want_features=False,
                                           seq_lens=cand_lens, prefix_lens=pos2.reshape(-1) if reuse else None, kv=kv)
         cur = cand[ar, best2.to(torch.int64)]
