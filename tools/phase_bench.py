@@ -19,7 +19,8 @@ def main():
     ap.add_argument("--rho", type=int, default=50)
     ap.add_argument("--k-adv", type=int, default=1)
     ap.add_argument("--iters", type=int, default=5)
-    ap.add_argument("--streams", type=int, default=2)
+    ap.add_argument("--streams", type=int, default=1)
+    ap.add_argument("--chunk", type=int, default=0, help="sequences per pass (row budget = chunk * 77); 0 = engine default")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     cfg = get_config(a.model)
@@ -27,6 +28,8 @@ def main():
     frozen = LeafCLIPText(cfg, device=dev, dtype="fp16").copy_from(model)
     frozen.pack(); model.pack()
     model.set_option('streams', a.streams); frozen.set_option('streams', a.streams)
+    if a.chunk:
+        model.set_option('chunk', a.chunk)
     sc = StepConfig(rho=a.rho, k_adv=a.k_adv)
     g = torch.Generator().manual_seed(1234)
     B = a.batch
