@@ -126,21 +126,19 @@ extern "C" size_t leaf_text_w16_bytes(leaf_text_t h) { return h->w16_layer_elems
 extern "C" int leaf_text_pack_weights(leaf_text_t h, const float* params, void* w16_fwd, void* w16_bwd,
                                       leaf_stream_t s_) {
     hipStream_t s = (hipStream_t)s_;
-    const int d = h->cfg.width;
-    for (int l = 0; l < h->cfg.layers; ++l) {
-        const LayerOff& o = h->layer[l];
-        struct { size_t src, dst; int rows, cols; } m[4] = {
-            {o.qkv_w, h->w16_qkv(l), 3 * d, d}, {o.out_w, h->w16_out(l), d, d},
-            {o.fc_w, h->w16_fc(l), 4 * d, d},   {o.proj_w, h->w16_proj(l), d, 4 * d}};
-        for (auto& t : m) {
-            if (w16_fwd)
-                LEAF_TRY(leaf_launch_cast(params + t.src, (uint16_t*)w16_fwd + t.dst, (size_t)t.rows * t.cols,
-                                          h->fwd_dtype, s));
-            if (w16_bwd)  // [rows,cols] fp32 -> [cols,rows] in the gradient path's 16-bit type
-                LEAF_TRY(leaf_launch_transpose16(params + t.src, 2, (uint16_t*)w16_bwd + t.dst, h->grad_dtype, t.rows,
-                                                 t.cols, t.cols, t.rows, s));
+    const int d = h->cfg.width, L = h->cfg.layers;
+    // The fp32 GEMM weights of all layers are one contiguous run (qkv, out, fc, proj per layer = 12 d^2 floats, the
+    // layout of leaf_text_create) and the 16-bit packs use the same offsets: one cast launch for the forward copy, one
+    // grouped transpose launch for the data-gradient copy (was 48 + 48 launches).
+    const float* w32 = params + h->layer[0].qkv_w;
+    for (int l = 0; l < L; ++l)
+        if (h->layer[l].qkv_w != h->layer[0].qkv_w + (size_t)l * h->w16_layer_elems() ||
+            h->layer[l].proj_w != h->layer[l].qkv_w + (size_t)8 * d * d) {
+            leaf_set_error("unexpected parameter layout");
+            return 1;
         }
-    }
+    if (w16_fwd) LEAF_TRY(leaf_launch_cast(w32, w16_fwd, h->w16_layer_elems() * L, h->fwd_dtype, s));
+    if (w16_bwd) LEAF_TRY(leaf_launch_pack_transpose(w32, w16_bwd, h->grad_dtype, d, L, s));
     return 0;
 }
 

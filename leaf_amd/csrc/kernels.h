@@ -119,6 +119,8 @@ struct WgradArgs {
 };
 bool leaf_wgrad_tn_ok(int Nw, int Kw, int ldy, int ldx);
 hipError_t leaf_launch_wgrad_group(WgradArgs a, int x_dtype, int g_dtype, hipStream_t s);
+// transposed 16-bit copies of all layers' GEMM weights in one launch (train.hip)
+hipError_t leaf_launch_pack_transpose(const float* src, void* dst, int dst_kind, int d, int layers, hipStream_t s);
 hipError_t leaf_launch_attention_bwd_mfma(const void* qkv, int qkv_dtype, const void* dout16, void* dqkv16, int gkind,
                                           int n_seq, RowMap map, int heads, int d, hipStream_t s);   // attention_bwd.hip
 hipError_t leaf_launch_attention_bwd(const void* qkv, int qkv_dtype, const void* dout16, void* dqkv16, int gkind,

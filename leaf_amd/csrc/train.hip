@@ -47,6 +47,31 @@ __global__ __launch_bounds__(256) void transpose16_kernel(const void* __restrict
     }
 }
 
+// All 4 GEMM weights of all layers in ONE launch: w16_bwd[l][m] = transpose(params[l][m]) in the gradient path's 16-bit
+// type.  The fp32 weights of a layer are contiguous in the order qkv [3d,d], out [d,d], fc [4d,d], proj [d,4d] (12 d^2
+// floats) and the 16-bit pack uses the same offsets; grid = (32 x 32 tiles of one layer = 12 d^2 / 1024, layers).
+__global__ __launch_bounds__(256) void pack_transpose_kernel(const float* __restrict__ src, void* __restrict__ dst,
+                                                             int dkind, int d) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int dt = d >> 5;                         // tiles along a d-wide side
+    int b = blockIdx.x;
+    int rows, cols;
+    size_t moff;
+    if (b < 3 * dt * dt) { rows = 3 * d; cols = d; moff = 0; }
+    else if (b < 4 * dt * dt) { b -= 3 * dt * dt; rows = d; cols = d; moff = (size_t)3 * d * d; }
+    else if (b < 8 * dt * dt) { b -= 4 * dt * dt; rows = 4 * d; cols = d; moff = (size_t)4 * d * d; }
+    else { b -= 8 * dt * dt; rows = d; cols = 4 * d; moff = (size_t)8 * d * d; }
+    const int tc = cols >> 5;
+    const int c0 = (b % tc) * 32, r0 = (b / tc) * 32;
+    const size_t base = (size_t)blockIdx.y * 12 * d * d + moff;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tile[ty + 8 * i][tx] = src[base + (size_t)(r0 + ty + 8 * i) * cols + c0 + tx];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) store16(dst, dkind, base + (size_t)(c0 + ty + 8 * i) * rows + r0 + tx, tile[tx][ty + 8 * i]);
+}
+
 __global__ __launch_bounds__(256) void cast16_kernel(const void* __restrict__ src, int kind, void* __restrict__ dst,
                                                      int dkind, size_t n) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -432,6 +457,12 @@ hipError_t leaf_launch_transpose16(const void* src, int src_kind, void* dst, int
                                    int rpad, hipStream_t s) {
     dim3 grid((cols + 31) / 32, (rpad + 31) / 32);
     hipLaunchKernelGGL(transpose16_kernel, grid, dim3(256), 0, s, src, src_kind, dst, dst_kind, rows, cols, ld_src, rpad);
+    return hipGetLastError();
+}
+
+hipError_t leaf_launch_pack_transpose(const float* src, void* dst, int dst_kind, int d, int layers, hipStream_t s) {
+    if (d % 32 || layers < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pack_transpose_kernel, dim3(12 * (d / 32) * (d / 32), layers), dim3(256), 0, s, src, dst, dst_kind, d);
     return hipGetLastError();
 }
 
