@@ -68,7 +68,7 @@ BwdBuf carve_bwd(const leaf_text* h, Carver& c, int n_seq, size_t rows) {
     b.tA = (uint16_t*)c.take(4 * d * rpad * 2);
     b.tB = (uint16_t*)c.take(4 * d * rpad * 2);
     b.dout = (float*)c.take((size_t)n_seq * h->cfg.embed_dim * 4);
-    b.gscale = (float*)c.take(256);
+    b.gscale = (float*)c.take(256 + (size_t)n_seq * 8);   // {S, 1/S} + per-caption loss partials
     return b;
 }
 

@@ -79,18 +79,18 @@ __global__ __launch_bounds__(256) void cast16_kernel(const void* __restrict__ sr
     for (; i < n; i += stride) store16(dst, dkind, i, load_as_f32(src, kind, i));
 }
 
-// single block: loss = mean_b sum_j (a-f)^2 ; dout = 2 (f-a)/B * scale ; gscale = {S, 1/S}
-__global__ __launch_bounds__(256) void fare_loss_kernel(const float* __restrict__ feat, const float* __restrict__ anchor,
-                                                        int B, int D, float scale, float* __restrict__ loss,
-                                                        float* __restrict__ dout, float* __restrict__ gscale,
-                                                        int use_scaling) {
+// loss = mean_b sum_j (a-f)^2 ; dout = 2 (f-a)/B * scale ; gscale = {S, 1/S}.  Two launches: one block per caption writes
+// its dout row and {row sum, row max|dout|} partials, one block reduces the partials in a fixed order.
+__global__ __launch_bounds__(256) void fare_rows_kernel(const float* __restrict__ feat, const float* __restrict__ anchor,
+                                                        int B, int D, float scale, float* __restrict__ dout,
+                                                        float* __restrict__ partial) {
     __shared__ float red[8];
-    const int tid = threadIdx.x;
-    const size_t n = (size_t)B * D;
-    float s = 0.f, amax = 0.f;
+    const int tid = threadIdx.x, b = blockIdx.x;
     const float k = 2.0f / (float)B * scale;
-    for (size_t i = tid; i < n; i += 256) {
-        float df = feat[i] - anchor[i];
+    float s = 0.f, amax = 0.f;
+    for (int j = tid; j < D; j += 256) {
+        const size_t i = (size_t)b * D + j;
+        const float df = feat[i] - anchor[i];
         s = fmaf(df, df, s);
         const float g = k * df;
         amax = fmaxf(amax, fabsf(g));
@@ -101,7 +101,23 @@ __global__ __launch_bounds__(256) void fare_loss_kernel(const float* __restrict_
     if ((tid & 63) == 0) { red[tid >> 6] = s; red[4 + (tid >> 6)] = amax; }
     __syncthreads();
     if (tid == 0) {
-        if (loss) *loss = (red[0] + red[1] + red[2] + red[3]) / (float)B;
+        partial[2 * b] = (red[0] + red[1]) + (red[2] + red[3]);
+        partial[2 * b + 1] = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+    }
+}
+
+__global__ __launch_bounds__(256) void fare_reduce_kernel(const float* __restrict__ partial, int B, float* __restrict__ loss,
+                                                          float* __restrict__ gscale, int use_scaling) {
+    __shared__ float red[8];
+    const int tid = threadIdx.x;
+    float s = 0.f, amax = 0.f;
+    for (int b = tid; b < B; b += 256) { s += partial[2 * b]; amax = fmaxf(amax, partial[2 * b + 1]); }
+    s = wave_sum(s);
+    amax = wave_max(amax);
+    if ((tid & 63) == 0) { red[tid >> 6] = s; red[4 + (tid >> 6)] = amax; }
+    __syncthreads();
+    if (tid == 0) {
+        if (loss) *loss = ((red[0] + red[1]) + (red[2] + red[3])) / (float)B;
         float S = 1.f;
         const float a = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
         if (use_scaling && a > 0.f && a < 3.0e38f) {
@@ -410,7 +426,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const u16* __restrict__ q
 __global__ __launch_bounds__(256) void pos_bwd_kernel(const float* __restrict__ dx, const float* __restrict__ gscale,
                                                       float* __restrict__ dpos, int n_seq, RowMap map, int d) {
     const int p = blockIdx.x;
-    for (int c = threadIdx.x; c < d; c += 256) {
+    const int c = blockIdx.y * 256 + threadIdx.x;     // grid (ctx, ceil(d / 256)): one column per thread
+    if (c < d) {
         float s = 0.f;
         for (int n = 0; n < n_seq; ++n)
             if (p < seq_len(map, map.s0 + n)) s += dx[((size_t)seq_row(map, map.s0 + n) + p) * d + c];
@@ -476,8 +493,9 @@ hipError_t leaf_launch_cast16(const void* src, int src_kind, void* dst, int dst_
 
 hipError_t leaf_launch_fare_loss(const float* feat, const float* anchor, int B, int D, float scale, float* loss,
                                  float* dout, float* gscale, int use_scaling, hipStream_t s) {
-    hipLaunchKernelGGL(fare_loss_kernel, dim3(1), dim3(256), 0, s, feat, anchor, B, D, scale, loss, dout, gscale,
-                       use_scaling);
+    float* partial = gscale + 64;   // [B][2] right behind the {S, 1/S} slot (carve_bwd reserves it)
+    hipLaunchKernelGGL(fare_rows_kernel, dim3(B), dim3(256), 0, s, feat, anchor, B, D, scale, dout, partial);
+    hipLaunchKernelGGL(fare_reduce_kernel, dim3(1), dim3(256), 0, s, partial, B, loss, gscale, use_scaling);
     return hipGetLastError();
 }
 
@@ -544,7 +562,7 @@ hipError_t leaf_launch_attention_bwd(const void* qkv, int qkv_dtype, const void*
 
 hipError_t leaf_launch_embed_bwd(const float* dx, const float* gscale, const int32_t* tokens, float* dtok, float* dpos,
                                  int rows, int n_seq, RowMap map, int d, int vocab, hipStream_t s) {
-    hipLaunchKernelGGL(pos_bwd_kernel, dim3(map.ctx), dim3(256), 0, s, dx, gscale, dpos, n_seq, map, d);
+    hipLaunchKernelGGL(pos_bwd_kernel, dim3(map.ctx, (d + 255) / 256), dim3(256), 0, s, dx, gscale, dpos, n_seq, map, d);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(tok_bwd_kernel, dim3(rows), dim3(256), 0, s, dx, gscale, tokens, dtok, rows, n_seq, map, d, vocab);
