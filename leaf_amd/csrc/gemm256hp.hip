@@ -16,7 +16,6 @@ namespace {
 constexpr int BM = 256, BN = 256, BK = 64, NSLOT = 5;
 constexpr int HALF = BM * BK * 2;       // 32 KiB: one operand panel of one K tile
 constexpr int RING = NSLOT * HALF;      // 160 KiB
-constexpr int SLICE = 16384;            // epilogue staging per wave (inside the idle ring)
 
 // In-kernel stamps (diagnostic builds only: -DLEAF_GEMM_STAMPS): s_memtime at phase boundaries, one 8-slot record per
 // workgroup in a caller-supplied buffer that nothing else reads.
