@@ -201,13 +201,18 @@ def _mha(cfg, xn, wqkv, bqkv, wo, bo, rnd: Round, stash=None):
 
 
 def encode_text(w: Dict[str, np.ndarray], cfg: TextCfg, tokens: np.ndarray, normalize: bool = False,
-                rnd: Round = None, stash: Optional[list] = None) -> np.ndarray:
-    """[N,ctx] int ids -> [N,embed_dim] fp32 (src/open_clip/model.py:269-284)."""
+                rnd: Round = None, stash: Optional[list] = None, delta: Optional[np.ndarray] = None) -> np.ndarray:
+    """[N,ctx] int ids -> [N,embed_dim] fp32 (src/open_clip/model.py:269-284).  ``delta`` [N,ctx,width]: additive
+    perturbation of the token embeddings (the embedding-input forward of src/pez/open_clip_pez/model.py:210-228),
+    SURVEY.md 8a row a12."""
     tokens = np.asarray(tokens)
     N, L = tokens.shape
     d = cfg.width
     act = _act(cfg)
-    x = (w["token_embedding.weight"][tokens] + w["positional_embedding"][:L]).astype(F32)
+    x = w["token_embedding.weight"][tokens]
+    if delta is not None:
+        x = x + np.asarray(delta, dtype=F32)
+    x = (x + w["positional_embedding"][:L]).astype(F32)
     for i in range(cfg.layers):
         p = f"transformer.resblocks.{i}."
         st = {} if stash is not None else None
@@ -285,15 +290,17 @@ def _ln_bwd(dy, x, mu, rstd, g):
     return dx.astype(F32), dg.astype(F32), db.astype(F32)
 
 
-def encode_text_backward(w, cfg: TextCfg, tokens: np.ndarray, anchor: np.ndarray, accum_scale: float = 1.0):
+def encode_text_backward(w, cfg: TextCfg, tokens: np.ndarray, anchor: np.ndarray, accum_scale: float = 1.0,
+                         delta: Optional[np.ndarray] = None):
     """Forward + TextFARE loss + full backward in fp32.  Returns (loss, feat, grads) where
     grads has the same keys/shapes as ``w`` (utils_AT.py:317-337; loss / accum_freq is
-    what gets back-propagated, ``accum_scale`` = 1/accum_freq)."""
+    what gets back-propagated, ``accum_scale`` = 1/accum_freq) plus ``grads["d_embed"]`` [N,ctx,width], the gradient
+    with respect to the (perturbed) token embeddings = the gradient of ``delta``."""
     tokens = np.asarray(tokens)
     N, L = tokens.shape
     d, H, hd = cfg.width, cfg.heads, cfg.head_dim
     stash: list = []
-    feat = encode_text(w, cfg, tokens, stash=stash)
+    feat = encode_text(w, cfg, tokens, stash=stash, delta=delta)
     loss = textfare_loss(anchor, feat)
     g = {k: np.zeros_like(v) for k, v in w.items()}
     top = stash[-1]
@@ -337,7 +344,36 @@ def encode_text_backward(w, cfg: TextCfg, tokens: np.ndarray, anchor: np.ndarray
         dx = (dx1 + dl).astype(F32)
     g["positional_embedding"][:L] = dx.sum(0)
     np.add.at(g["token_embedding.weight"], tokens.reshape(-1), dx.reshape(N * L, d))
+    g["d_embed"] = dx.astype(F32)
     return loss, feat, g
+
+
+# --------------------------------------------------------------------------- optional embedding-space PGD (a12)
+def pgd_normalize_grad(grad: np.ndarray, norm: str) -> np.ndarray:
+    """src/robust_vlm/train/utils.py:107-114: 'linf' -> sign; 'l2' -> per-sample F.normalize of the flattened gradient
+    (eps 1e-12)."""
+    if norm == "linf":
+        return np.sign(grad).astype(F32)
+    flat = grad.reshape(grad.shape[0], -1)
+    n = np.maximum(np.sqrt((flat.astype(np.float64) ** 2).sum(1)), 1e-12)
+    return (flat / n[:, None]).reshape(grad.shape).astype(F32)
+
+
+def pgd_project(delta: np.ndarray, eps: float, norm: str) -> np.ndarray:
+    """src/robust_vlm/train/utils.py:96-104: 'linf' -> clamp(-eps, eps); 'l2' -> torch.renorm(p=2, dim=0, maxnorm=eps):
+    a sample whose L2 norm exceeds eps is scaled by eps / (norm + 1e-7)."""
+    if norm == "linf":
+        return np.clip(delta, -eps, eps).astype(F32)
+    flat = delta.reshape(delta.shape[0], -1)
+    n = np.sqrt((flat.astype(np.float64) ** 2).sum(1))
+    f = np.where(n > eps, eps / (n + 1e-7), 1.0)
+    return (flat * f[:, None]).reshape(delta.shape).astype(F32)
+
+
+def pgd_step(delta: np.ndarray, grad: np.ndarray, alpha: float, eps: float, norm: str) -> np.ndarray:
+    """delta <- project(delta + alpha * normalize_grad(grad)): the update of the continuous attack loop
+    (utils_attacks.py:680-697 in its 'linf' form) generalised by the two functions above."""
+    return pgd_project((delta + F32(alpha) * pgd_normalize_grad(grad, norm)).astype(F32), eps, norm)
 
 
 def exclude_from_decay(name: str, p: np.ndarray) -> bool:

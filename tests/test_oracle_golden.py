@@ -100,3 +100,27 @@ def test_cosine_lr(golden_dir):
     c = _manifest(golden_dir)["cosine_lr"]
     for s, v in c["values"].items():
         assert abs(O.cosine_lr(c["base_lr"], c["warmup"], c["steps"], int(s)) - v) < 1e-12
+
+
+def test_embedding_pgd_matches_reference_pieces(golden_dir):
+    """Optional embedding-space PGD mode: the oracle's forward with an additive embedding perturbation,
+    the gradient with respect to it and the linf / l2 update against tests/golden/tiny_pgd.npz, which was produced by the
+    reference's own encode_text (delta injected at token_embedding), torch.autograd and the reference's
+    normalize_grad / project_perturbation (tests/golden/make_golden_pgd.py)."""
+    z = np.load(os.path.join(golden_dir, "tiny_pgd.npz"))
+    cfg = O.TextCfg(128, 2, 2, 64, quick_gelu=True)
+    w = O.init_weights(cfg, seed=12)
+    toks, anchor = z["tokens"], z["anchor"]
+    assert rel_l2(O.encode_text(w, cfg, toks), z["clean"]) < 5e-6
+    for norm in ("linf", "l2"):
+        eps, alpha = float(z[f"{norm}_eps"]), float(z[f"{norm}_alpha"])
+        for k in range(3):
+            delta = z[f"{norm}_delta{k}"]
+            loss, feat, g = O.encode_text_backward(w, cfg, toks, anchor, delta=delta)
+            assert rel_l2(feat, z[f"{norm}_feat{k}"]) < 5e-6
+            # the fixture's loss is the SUM over the batch (utils_attacks.py:686), TextFARE's the mean: factor N
+            assert abs(loss * toks.shape[0] - float(z[f"{norm}_loss{k}"])) < 1e-4 * float(z[f"{norm}_loss{k}"])
+            assert rel_l2(g["d_embed"] * toks.shape[0], z[f"{norm}_grad{k}"]) < 1e-4
+            # the update itself, from the fixture's own gradient (sign() of a near-zero component may differ otherwise)
+            nxt = O.pgd_step(delta, z[f"{norm}_grad{k}"], alpha, eps, norm)
+            assert np.abs(nxt - z[f"{norm}_delta{k + 1}"]).max() < 1e-6
