@@ -107,6 +107,27 @@ int leaf_text_forward_train(leaf_text_t h, const float* params, const void* w16_
                             const int32_t* seq_lens, const int32_t* cu_rows, int n_seq, float* out, void* stash,
                             size_t stash_bytes, void* ws, size_t ws_bytes, leaf_stream_t s);
 
+/* OPTIONAL embedding-space PGD mode (no reference path runs it on text, the pieces are the
+ * reference's): forward of tokens whose embeddings carry an additive perturbation delta (fp32 [rows, width], packed like
+ * the activations, resident in HBM across the inner iterations; NULL = none) - the embedding-input forward of
+ * src/pez/open_clip_pez/model.py:210-228 fused into the embedding gather + first LayerNorm. */
+int leaf_text_forward_train_delta(leaf_text_t h, const float* params, const void* w16_fwd, const int32_t* tokens,
+                                  const int32_t* seq_lens, const int32_t* cu_rows, int n_seq, const float* delta,
+                                  float* out, void* stash, size_t stash_bytes, void* ws, size_t ws_bytes, leaf_stream_t s);
+/* TextFARE loss of (anchor, feat) and ONLY its gradient with respect to the token embeddings / delta (fp32
+ * [rows, width], un-scaled): the backward of the continuous attack loop (utils_attacks.py:683-692) without any
+ * parameter gradient.  loss_out: one device float (mean over captions of the squared distance). */
+int leaf_textfare_input_grad(leaf_text_t h, const float* params, const void* w16_bwd, const int32_t* tokens,
+                             const int32_t* seq_lens, const int32_t* cu_rows, int n_seq, const float* feat,
+                             const float* anchor, const void* stash, float* d_embed, float* loss_out, void* ws,
+                             size_t ws_bytes, leaf_stream_t s);
+/* fused grad-sign / normalise - step - project on the resident perturbation, per sequence over its kept rows:
+ * norm 0 (linf): delta <- clamp(delta + alpha sign(grad), -eps, eps)       (utils_attacks.py:693-694)
+ * norm 2 (l2)  : delta <- renorm_2(delta + alpha grad / ||grad||_2, eps)   (src/robust_vlm/train/utils.py:96-114)
+ * cu_rows: device prefix sums of the kept rows ([n_seq + 1]) or NULL for dense ctx rows per sequence. */
+int leaf_pgd_step(float* delta, const float* grad, const int32_t* cu_rows, int n_seq, int ctx, int width, float alpha,
+                  float eps, int norm, leaf_stream_t s);
+
 /* TextFARE loss + backward (utils_AT.py:321-337): loss = mean_b sum_j (anchor - feat)^2; back-propagates
  * loss * accum_scale (= 1/accum_freq) and ACCUMULATES (+=) into grads (flat fp32, parameter layout).
  * loss_out: one device float (unscaled loss). */

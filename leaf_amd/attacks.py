@@ -222,3 +222,39 @@ def attack_text_leaf(model, tokenizer, sentences, anchor_features, device=None, 
 def attack_text(model, tokenizer, sentences, image_features, device=None, objective="l2", n=10, k=1, V=DEFAULT_V,
                 constrain=False, debug=False):
     return attack_text_leaf(model, tokenizer, sentences, image_features, device, objective, n, k, V, constrain, debug)
+
+
+# ----------------------------------------------------------------------------- optional embedding-space PGD (a12)
+def attack_embedding_pgd(model, tokens, anchor_features, eps: float, alpha: float, k: int = 1, norm: str = "linf",
+                         delta0=None, seq_lens=None, seed: Optional[int] = None):
+    """Continuous attack on the token EMBEDDINGS: k steps of  delta <- project(delta + alpha * normalize_grad(grad))
+    maximising sum((anchor - f(tokens; delta))**2).  NOT part of the reference's text trainer (SURVEY.md 8a row a12);
+    the loop is the reference's continuous attack (utils_attacks.py:680-697) with the embedding-input forward of
+    src/pez/open_clip_pez/model.py:210-228 and the normalise / project pair of src/robust_vlm/train/utils.py:96-114.
+    ``delta0``: packed fp32 [rows, width] start (default eps * U(-1, 1), utils_attacks.py:680, projected for 'l2').
+    Returns (features of the perturbed captions [B, D], delta) - delta stays resident on the device throughout."""
+    import torch
+    if seq_lens is None:
+        arr = tokens if isinstance(tokens, np.ndarray) else tokens.cpu().numpy()
+        seq_lens = arr.reshape(-1, arr.shape[-1]).argmax(-1) + 1
+    lens = np.asarray(seq_lens).reshape(-1)
+    rows = int(lens.sum()) if getattr(model, "trim_rows", False) else lens.size * model.cfg.context_length
+    if delta0 is None:
+        gen = torch.Generator(device=model.device)
+        gen.manual_seed(0 if seed is None else seed)
+        delta = eps * (2 * torch.rand(rows, model.cfg.width, device=model.device, generator=gen) - 1)
+    else:
+        delta = delta0.to(device=model.device, dtype=torch.float32).contiguous().clone()
+    was_training = getattr(model, "training", False)
+    model.eval()
+    feat = model.forward_train(tokens, seq_lens=seq_lens, delta=delta)
+    if delta0 is None and norm == "l2":      # bring the random start into the ball: a zero-gradient step projects only
+        model.pgd_step(delta, torch.zeros_like(delta), 0.0, eps, "l2")
+        feat = model.forward_train(tokens, seq_lens=seq_lens, delta=delta)
+    for _ in range(k):
+        _, grad = model.input_grad(feat, anchor_features)
+        model.pgd_step(delta, grad, alpha, eps, norm)
+        feat = model.forward_train(tokens, seq_lens=seq_lens, delta=delta)
+    if was_training:
+        model.train()
+    return feat, delta

@@ -87,9 +87,10 @@ extern "C" size_t leaf_text_stash_bytes(leaf_text_t h, int n_seq) {
     return align_up(c.off, 256) + 256;
 }
 
-extern "C" int leaf_text_forward_train(leaf_text_t h, const float* P, const void* w16_fwd, const int32_t* tokens,
-                                       const int32_t* seq_lens, const int32_t* cu_rows, int n_seq, float* out,
-                                       void* stash, size_t stash_bytes, void* ws, size_t ws_bytes, leaf_stream_t s_) {
+extern "C" int leaf_text_forward_train_delta(leaf_text_t h, const float* P, const void* w16_fwd, const int32_t* tokens,
+                                             const int32_t* seq_lens, const int32_t* cu_rows, int n_seq,
+                                             const float* delta, float* out, void* stash, size_t stash_bytes, void* ws,
+                                             size_t ws_bytes, leaf_stream_t s_) {
     if (!h || !P || !w16_fwd || !tokens || !out || !stash || n_seq < 1) { leaf_set_error("null/invalid argument"); return 1; }
     hipStream_t s = (hipStream_t)s_;
     if ((seq_lens == nullptr) != (cu_rows == nullptr)) { leaf_set_error("seq_lens (host) and cu_rows (device) go together"); return 1; }
@@ -105,7 +106,7 @@ extern "C" int leaf_text_forward_train(leaf_text_t h, const float* P, const void
     const size_t rd = (size_t)rows * d;
     const uint16_t* W = (const uint16_t*)w16_fwd;
     LEAF_TRY(leaf_launch_embed_ln(tokens, P + h->tok_emb, P + h->pos_emb, P + h->layer[0].ln1_w, P + h->layer[0].ln1_b,
-                                  cf.ln_eps, st.xin, st.xn1, rows, n_seq, map, d, cf.vocab_size, dt, s));
+                                  cf.ln_eps, st.xin, st.xn1, rows, n_seq, map, d, cf.vocab_size, dt, s, delta));
     for (int l = 0; l < L; ++l) {
         const LayerOff& o = h->layer[l];
         float* xin = st.xin + l * rd; float* x1 = st.x1 + l * rd; float* xout = st.xin + (l + 1) * rd;
@@ -134,12 +135,20 @@ extern "C" int leaf_text_forward_train(leaf_text_t h, const float* P, const void
     return 0;
 }
 
-extern "C" int leaf_textfare_backward(leaf_text_t h, const float* P, const void* w16_bwd, const int32_t* tokens,
-                                      const int32_t* seq_lens, const int32_t* cu_rows, int n_seq, const float* feat,
-                                      const float* anchor, float accum_scale,
-                                      const void* stash, float* G, float* loss_out, void* ws, size_t ws_bytes,
-                                      leaf_stream_t s_) {
-    if (!h || !P || !w16_bwd || !tokens || !feat || !anchor || !stash || !G || !ws || n_seq < 1) {
+extern "C" int leaf_text_forward_train(leaf_text_t h, const float* P, const void* w16_fwd, const int32_t* tokens,
+                                       const int32_t* seq_lens, const int32_t* cu_rows, int n_seq, float* out,
+                                       void* stash, size_t stash_bytes, void* ws, size_t ws_bytes, leaf_stream_t s_) {
+    return leaf_text_forward_train_delta(h, P, w16_fwd, tokens, seq_lens, cu_rows, n_seq, nullptr, out, stash, stash_bytes,
+                                         ws, ws_bytes, s_);
+}
+
+// Shared body of the parameter-gradient backward (G != null) and of the input-gradient-only backward of the optional
+// embedding-space PGD mode (G == null, d_embed != null: no weight / bias / LayerNorm / embedding-table gradients).
+static int backward_impl(leaf_text_t h, const float* P, const void* w16_bwd, const int32_t* tokens,
+                         const int32_t* seq_lens, const int32_t* cu_rows, int n_seq, const float* feat,
+                         const float* anchor, float accum_scale, const void* stash, float* G, float* d_embed,
+                         float* loss_out, void* ws, size_t ws_bytes, leaf_stream_t s_) {
+    if (!h || !P || !w16_bwd || !tokens || !feat || !anchor || !stash || (!G && !d_embed) || !ws || n_seq < 1) {
         leaf_set_error("null/invalid argument");
         return 1;
     }
@@ -172,8 +181,9 @@ extern "C" int leaf_textfare_backward(leaf_text_t h, const float* P, const void*
     LEAF_TRY(leaf_launch_fare_loss(feat, anchor, n_seq, D, accum_scale, loss_out, b.dout, b.gscale, gk == 1, s));
     LEAF_TRY(hipMemsetAsync(b.dx, 0, rd * 4, s));
     LEAF_TRY(leaf_launch_pool_project_bwd(b.dout, st.pooled, st.xin + (size_t)L * rd, st.eot, P + h->lnf_w, P + h->lnf_b,
-                                          cf.ln_eps, P + h->text_proj, b.dx, G + h->text_proj, G + h->lnf_w,
-                                          G + h->lnf_b, b.gscale, n_seq, map, d, D, b.dxn /* free until the first dgrad */, s));
+                                          cf.ln_eps, P + h->text_proj, b.dx, G ? G + h->text_proj : nullptr,
+                                          G ? G + h->lnf_w : nullptr, G ? G + h->lnf_b : nullptr, b.gscale, n_seq, map, d, D,
+                                          b.dxn /* free until the first dgrad */, s));
     LEAF_TRY(leaf_launch_cast16(b.dx, 2, b.dx16, gk, rd, s));
 
     // LEAF_WGRAD=0: first implementation (two transposes + NT GEMM per weight, atomics column sums), kept for A/B
@@ -186,28 +196,30 @@ extern "C" int leaf_textfare_backward(leaf_text_t h, const float* P, const void*
         const uint16_t* xn1 = st.xn1 + l * rd; const uint16_t* qkv = st.qkv + 3 * l * rd; const uint16_t* ao = st.ao + l * rd;
         const uint16_t* xn2 = st.xn2 + l * rd; const uint16_t* pre = st.pre + 4 * l * rd; const uint16_t* hh = st.hh + 4 * l * rd;
         // ---- MLP
-        if (!grouped) {
+        if (G && !grouped) {
             if (wgrad(b.dx16, d, hh, fk, 4 * d, G + o.proj_w)) return 1;
             LEAF_TRY(leaf_launch_colsum(b.dx16, gk, b.gscale, d, rows, d, G + o.proj_b, s));
         }
         if (leaf_gemm(gk, EPI_ACTGRAD_T, b.dx16, d, WT + h->w16_proj(l), d, b.big16, 4 * d, nullptr, (void*)pre, rows,
                  4 * d, d, cf.activation, s, 0.f, fk)) return 1;
-        if (!grouped) {
+        if (G && !grouped) {
             if (wgrad(b.big16, 4 * d, xn2, fk, d, G + o.fc_w)) return 1;
             LEAF_TRY(leaf_launch_colsum(b.big16, gk, b.gscale, 4 * d, rows, 4 * d, G + o.fc_b, s));
         }
         if (leaf_gemm(gk, EPI_STORE_F32, b.big16, 4 * d, WT + h->w16_fc(l), 4 * d, b.dxn, d, nullptr, nullptr, rows, d,
                  4 * d, 0, s)) return 1;
-        LEAF_TRY(leaf_launch_layernorm_bwd(b.dxn, x1, P + o.ln2_w, cf.ln_eps, b.dx, b.dx16b, gk, b.gscale, G + o.ln2_w,
-                                           G + o.ln2_b, rows, d, s));
+        LEAF_TRY(leaf_launch_layernorm_bwd(b.dxn, x1, P + o.ln2_w, cf.ln_eps, b.dx, b.dx16b, gk, b.gscale,
+                                           G ? G + o.ln2_w : nullptr, G ? G + o.ln2_b : nullptr, rows, d, s));
         // ---- attention
-        if (!grouped) {
+        if (G && !grouped) {
             if (wgrad(b.dx16b, d, ao, fk, d, G + o.out_w)) return 1;
             LEAF_TRY(leaf_launch_colsum(b.dx16b, gk, b.gscale, d, rows, d, G + o.out_b, s));
         }
         if (leaf_gemm(gk, EPI_STORE_T, b.dx16b, d, WT + h->w16_out(l), d, b.do16, d, nullptr, nullptr, rows, d, d, 0, s)) return 1;
         LEAF_TRY(leaf_launch_attention_bwd(qkv, h->fwd_dtype, b.do16, b.dqkv, gk, n_seq, map, cf.heads, d, s));
-        if (!grouped) {
+        if (!G) {
+            // input-gradient-only: nothing to accumulate
+        } else if (!grouped) {
             if (wgrad(b.dqkv, 3 * d, xn1, fk, d, G + o.qkv_w)) return 1;
             LEAF_TRY(leaf_launch_colsum(b.dqkv, gk, b.gscale, 3 * d, rows, 3 * d, G + o.qkv_b, s));
         } else {
@@ -223,11 +235,41 @@ extern "C" int leaf_textfare_backward(leaf_text_t h, const float* P, const void*
         }
         if (leaf_gemm(gk, EPI_STORE_F32, b.dqkv, 3 * d, WT + h->w16_qkv(l), 3 * d, b.dxn, d, nullptr, nullptr, rows, d,
                  3 * d, 0, s)) return 1;
-        LEAF_TRY(leaf_launch_layernorm_bwd(b.dxn, xin, P + o.ln1_w, cf.ln_eps, b.dx, b.dx16, gk, b.gscale, G + o.ln1_w,
-                                           G + o.ln1_b, rows, d, s));
+        LEAF_TRY(leaf_launch_layernorm_bwd(b.dxn, xin, P + o.ln1_w, cf.ln_eps, b.dx, b.dx16, gk, b.gscale,
+                                           G ? G + o.ln1_w : nullptr, G ? G + o.ln1_b : nullptr, rows, d, s));
     }
-    LEAF_TRY(leaf_launch_embed_bwd(b.dx, b.gscale, tokens, G + h->tok_emb, G + h->pos_emb, rows, n_seq, map, d, cf.vocab_size, s));
+    if (G) LEAF_TRY(leaf_launch_embed_bwd(b.dx, b.gscale, tokens, G + h->tok_emb, G + h->pos_emb, rows, n_seq, map, d, cf.vocab_size, s));
+    if (d_embed) LEAF_TRY(leaf_launch_scale_copy(b.dx, inv_s, d_embed, rd, s));   // d loss / d (token embedding), un-scaled
     return 0;
+}
+
+extern "C" int leaf_textfare_backward(leaf_text_t h, const float* P, const void* w16_bwd, const int32_t* tokens,
+                                      const int32_t* seq_lens, const int32_t* cu_rows, int n_seq, const float* feat,
+                                      const float* anchor, float accum_scale,
+                                      const void* stash, float* G, float* loss_out, void* ws, size_t ws_bytes,
+                                      leaf_stream_t s_) {
+    if (!G) { leaf_set_error("null/invalid argument"); return 1; }
+    return backward_impl(h, P, w16_bwd, tokens, seq_lens, cu_rows, n_seq, feat, anchor, accum_scale, stash, G, nullptr,
+                         loss_out, ws, ws_bytes, s_);
+}
+
+extern "C" int leaf_textfare_input_grad(leaf_text_t h, const float* P, const void* w16_bwd, const int32_t* tokens,
+                                        const int32_t* seq_lens, const int32_t* cu_rows, int n_seq, const float* feat,
+                                        const float* anchor, const void* stash, float* d_embed, float* loss_out, void* ws,
+                                        size_t ws_bytes, leaf_stream_t s_) {
+    if (!d_embed) { leaf_set_error("null/invalid argument"); return 1; }
+    return backward_impl(h, P, w16_bwd, tokens, seq_lens, cu_rows, n_seq, feat, anchor, 1.0f, stash, nullptr, d_embed,
+                         loss_out, ws, ws_bytes, s_);
+}
+
+extern "C" int leaf_pgd_step(float* delta, const float* grad, const int32_t* cu_rows, int n_seq, int ctx, int width,
+                             float alpha, float eps, int norm, leaf_stream_t s_) {
+    if (!delta || !grad || n_seq < 1 || ctx < 1 || (norm != 0 && norm != 2) || alpha < 0.f || eps < 0.f) {
+        leaf_set_error("null/invalid argument (norm: 0 = linf, 2 = l2)");
+        return 1;
+    }
+    const RowMap map{cu_rows, 0, 0, ctx, nullptr, nullptr, 1};
+    return leaf_check(leaf_launch_pgd_step(delta, grad, n_seq, map, width, alpha, eps, norm == 2, (hipStream_t)s_), "pgd_step");
 }
 
 extern "C" int leaf_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n,

@@ -68,6 +68,10 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x_in,
             int c = lane + 64 * i;
             if (c < nq) {
                 float4 a = *(const float4*)(te + 4 * c), p = *(const float4*)(pe + 4 * c);
+                if (x_in) {   // EMBED mode: x_in = optional additive embedding perturbation delta [rows, d] (row a12)
+                    const float4 dl = *(const float4*)(x_in + (size_t)row * d + 4 * c);
+                    a = float4{a.x + dl.x, a.y + dl.y, a.z + dl.z, a.w + dl.w};
+                }
                 v[i] = float4{a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w};
                 *(float4*)(xo + 4 * c) = v[i];
             }
@@ -296,14 +300,14 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src
 
 hipError_t leaf_launch_embed_ln(const int32_t* tokens, const float* tok_emb, const float* pos_emb, const float* g,
                                 const float* b, float eps, float* x, void* xn, int rows, int n_seq, RowMap map, int d,
-                                int vocab, int dtype, hipStream_t s) {
+                                int vocab, int dtype, hipStream_t s, const float* delta) {
     if (d % 4 || d > 256 * MAXCH) return hipErrorInvalidValue;
     dim3 grid((rows + 3) / 4), blk(256);
     if (dtype == LEAF_F16)
-        hipLaunchKernelGGL((ln_kernel<F16, true>), grid, blk, 0, s, nullptr, tokens, tok_emb, pos_emb, g, b, eps, x,
+        hipLaunchKernelGGL((ln_kernel<F16, true>), grid, blk, 0, s, delta, tokens, tok_emb, pos_emb, g, b, eps, x,
                            (u16*)xn, rows, n_seq, map, d, vocab);
     else
-        hipLaunchKernelGGL((ln_kernel<BF16, true>), grid, blk, 0, s, nullptr, tokens, tok_emb, pos_emb, g, b, eps, x,
+        hipLaunchKernelGGL((ln_kernel<BF16, true>), grid, blk, 0, s, delta, tokens, tok_emb, pos_emb, g, b, eps, x,
                            (u16*)xn, rows, n_seq, map, d, vocab);
     return hipGetLastError();
 }

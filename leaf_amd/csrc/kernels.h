@@ -50,7 +50,7 @@ hipError_t leaf_launch_gemm256hp(const GemmArgs& p, int dtype, int epi, hipStrea
 // x[r,:] = tok_emb[tokens[r],:] + pos_emb[r % ctx,:]   and   xn = LN(x) (16-bit)
 hipError_t leaf_launch_embed_ln(const int32_t* tokens, const float* tok_emb, const float* pos_emb, const float* g,
                                 const float* b, float eps, float* x, void* xn, int rows, int n_seq, RowMap map, int d,
-                                int vocab, int dtype, hipStream_t s);
+                                int vocab, int dtype, hipStream_t s, const float* delta = nullptr /* [rows,d] additive embedding perturbation */);
 hipError_t leaf_launch_layernorm(const float* x, const float* g, const float* b, float eps, void* xn, int rows, int d,
                                  int dtype, hipStream_t s);
 // out[n,:] = LN_final(x[n*ctx + eot(n),:]) @ P  (fp32 math), optional L2 normalisation; pooled (optional) keeps
@@ -121,6 +121,10 @@ bool leaf_wgrad_tn_ok(int Nw, int Kw, int ldy, int ldx);
 hipError_t leaf_launch_wgrad_group(WgradArgs a, int x_dtype, int g_dtype, hipStream_t s);
 // transposed 16-bit copies of all layers' GEMM weights in one launch (train.hip)
 hipError_t leaf_launch_pack_transpose(const float* src, void* dst, int dst_kind, int d, int layers, hipStream_t s);
+// optional embedding-space PGD mode, train.hip
+hipError_t leaf_launch_scale_copy(const float* src, const float* scale_dev, float* dst, size_t n, hipStream_t s);
+hipError_t leaf_launch_pgd_step(float* delta, const float* grad, int n_seq, RowMap map, int d, float alpha, float eps,
+                                int norm_l2, hipStream_t s);
 hipError_t leaf_launch_attention_bwd_mfma(const void* qkv, int qkv_dtype, const void* dout16, void* dqkv16, int gkind,
                                           int n_seq, RowMap map, int heads, int d, hipStream_t s);   // attention_bwd.hip
 hipError_t leaf_launch_attention_bwd(const void* qkv, int qkv_dtype, const void* dout16, void* dqkv16, int gkind,

@@ -305,6 +305,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             }
         }
     }
+    if (!dg) return;   // input-gradient-only backward (embedding-space PGD): no parameter gradients wanted
     // block-level reduction of the per-wave column partials through LDS, then one atomic per column per block
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* red = (float4*)smem;   // [4 waves][2][nq]
@@ -470,6 +471,86 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 
 }  // namespace
 
+namespace {
+// ---------------------------------------------------------------- optional embedding-space PGD mode
+// dst = src * scale[0]  (un-scaling of the loss-scaled gradient stream: d loss / d delta)
+__global__ __launch_bounds__(256) void scale_copy_kernel(const float* __restrict__ src, const float* __restrict__ scale,
+                                                         float* __restrict__ dst, size_t n4) {
+    const float sc = scale[0];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 v = ((const float4*)src)[i];
+        ((float4*)dst)[i] = float4{v.x * sc, v.y * sc, v.z * sc, v.w * sc};
+    }
+}
+
+// The fused grad-sign-project-clip step on the perturbation that stays resident in HBM across the k inner iterations:
+//   linf: delta <- clamp(delta + alpha * sign(g), -eps, eps)                (utils_attacks.py:693-694)
+//   l2  : delta <- renorm_2(delta + alpha * g / max(||g||_2, 1e-12), eps)   (src/robust_vlm/train/utils.py:96-114),
+// norms taken per SEQUENCE over its kept rows x width (positions after EOT carry delta = 0 and a zero gradient).
+// One block per sequence; the l2 form makes two passes over the sequence's rows with block reductions in between.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__device__ __forceinline__ float linf_update(float x, float g, float alpha, float eps) {
+    const float sgn = g > 0.f ? 1.f : (g < 0.f ? -1.f : 0.f);
+    return fminf(fmaxf(x + alpha * sgn, -eps), eps);
+}
+
+__global__ __launch_bounds__(256) void pgd_step_kernel(float* __restrict__ delta, const float* __restrict__ grad, RowMap map,
+                                                       int d, float alpha, float eps, int norm_l2) {
+    __shared__ float red[4];
+    const int sq = map.s0 + blockIdx.x;
+    const size_t base = (size_t)seq_row(map, sq) * d;
+    const size_t n4 = (size_t)seq_len(map, sq) * d / 4;
+    float4* dl = (float4*)(delta + base);
+    const float4* g = (const float4*)(grad + base);
+    if (!norm_l2) {
+        for (size_t i = threadIdx.x; i < n4; i += 256) {
+            const float4 a = dl[i], b = g[i];
+            dl[i] = float4{linf_update(a.x, b.x, alpha, eps), linf_update(a.y, b.y, alpha, eps),
+                           linf_update(a.z, b.z, alpha, eps), linf_update(a.w, b.w, alpha, eps)};
+        }
+        return;
+    }
+    float s = 0.f;
+    for (size_t i = threadIdx.x; i < n4; i += 256) { const float4 b = g[i]; s += (b.x * b.x + b.y * b.y) + (b.z * b.z + b.w * b.w); }
+    const float gn = fmaxf(sqrtf(block_sum(s, red)), 1e-12f);
+    const float step = alpha / gn;
+    float q = 0.f;
+    for (size_t i = threadIdx.x; i < n4; i += 256) {
+        float4 a = dl[i];
+        const float4 b = g[i];
+        a = float4{fmaf(step, b.x, a.x), fmaf(step, b.y, a.y), fmaf(step, b.z, a.z), fmaf(step, b.w, a.w)};
+        dl[i] = a;
+        q += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
+    }
+    const float dn = sqrtf(block_sum(q, red));
+    if (dn > eps) {
+        const float f = eps / (dn + 1e-7f);
+        for (size_t i = threadIdx.x; i < n4; i += 256) { float4 a = dl[i]; dl[i] = float4{a.x * f, a.y * f, a.z * f, a.w * f}; }
+    }
+}
+}  // namespace
+
+hipError_t leaf_launch_scale_copy(const float* src, const float* scale_dev, float* dst, size_t n, hipStream_t s) {
+    if (n % 4) return hipErrorInvalidValue;
+    const size_t n4 = n / 4, nb = (n4 + 255) / 256;
+    hipLaunchKernelGGL(scale_copy_kernel, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, s, src, scale_dev, dst, n4);
+    return hipGetLastError();
+}
+
+hipError_t leaf_launch_pgd_step(float* delta, const float* grad, int n_seq, RowMap map, int d, float alpha, float eps,
+                                int norm_l2, hipStream_t s) {
+    if (d % 4 || n_seq < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pgd_step_kernel, dim3(n_seq), dim3(256), 0, s, delta, grad, map, d, alpha, eps, norm_l2);
+    return hipGetLastError();
+}
+
 hipError_t leaf_launch_transpose16(const void* src, int src_kind, void* dst, int dst_kind, int rows, int cols, int ld_src,
                                    int rpad, hipStream_t s) {
     dim3 grid((cols + 31) / 32, (rpad + 31) / 32);
@@ -507,12 +588,12 @@ hipError_t leaf_launch_pool_project_bwd(const float* dout, const float* pooled, 
     if (d % 32 || d > 256 * MAXCH) return hipErrorInvalidValue;
     float* dpooled = scratch;
     float* stats = scratch + (size_t)n_seq * d;
-    hipLaunchKernelGGL(proj_wgrad_kernel, dim3(d), dim3(256), 0, s, pooled, dout, dproj, n_seq, d, D);
+    if (dproj) hipLaunchKernelGGL(proj_wgrad_kernel, dim3(d), dim3(256), 0, s, pooled, dout, dproj, n_seq, d, D);
     hipLaunchKernelGGL(dpooled_kernel, dim3(n_seq, d / 32), dim3(256), 0, s, dout, proj, dpooled, d, D);
     hipLaunchKernelGGL(pool_ln_bwd_kernel, dim3((n_seq + 3) / 4), dim3(256), 0, s, dpooled, x, eot_idx, g, eps, dx, stats,
                        gscale, n_seq, map, d);
-    hipLaunchKernelGGL(pool_ln_wgrad_kernel, dim3((d + 255) / 256), dim3(256), 0, s, dpooled, x, eot_idx, stats, dg, db,
-                       n_seq, map, d);
+    if (dg) hipLaunchKernelGGL(pool_ln_wgrad_kernel, dim3((d + 255) / 256), dim3(256), 0, s, dpooled, x, eot_idx, stats, dg, db,
+                               n_seq, map, d);
     return hipGetLastError();
 }
 

@@ -367,7 +367,10 @@ class LeafCLIPText:
     def zero_grad(self):
         self.grads.zero_()
 
-    def forward_train(self, text, seq_lens=None) -> torch.Tensor:
+    def forward_train(self, text, seq_lens=None, delta: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Training-mode forward that keeps the activation stash.  ``delta`` (optional embedding-space PGD mode, SURVEY 8a
+        row a12): fp32 CUDA tensor [rows, width] in the PACKED row layout of this call (``rows_of(seq_lens)`` rows; dense
+        [N * ctx, width] when rows are not trimmed), added to the token embeddings."""
         self.enable_training()
         if not self._packed:
             self.pack()
@@ -382,11 +385,44 @@ class LeafCLIPText:
                 self._stash = torch.empty(need, dtype=torch.uint8, device=self.device)
         out = torch.empty(n, self.cfg.embed_dim, dtype=torch.float32, device=self.device)
         ws = self._workspace(2, n)
-        _lib.check(self._lib.leaf_text_forward_train(self._h, _ptr(self.flat), _ptr(self.w16), _ptr(t), lens_p, _ptr(cu),
-                                                     n, _ptr(out), _ptr(self._stash), self._stash.numel(),
-                                                     _ptr(ws), ws.numel(), self._stream()), "leaf_text_forward_train")
+        if delta is not None:
+            rows = int(keep.sum()) if keep is not None else n * self.cfg.context_length
+            if delta.dtype != torch.float32 or not delta.is_contiguous() or delta.numel() != rows * self.cfg.width:
+                raise ValueError(f"delta must be contiguous fp32 with {rows} x {self.cfg.width} elements")
+        _lib.check(self._lib.leaf_text_forward_train_delta(self._h, _ptr(self.flat), _ptr(self.w16), _ptr(t), lens_p,
+                                                           _ptr(cu), n, _ptr(delta), _ptr(out), _ptr(self._stash),
+                                                           self._stash.numel(), _ptr(ws), ws.numel(), self._stream()),
+                   "leaf_text_forward_train_delta")
         self._train_tokens = t
         return out
+
+    def input_grad(self, feat: torch.Tensor, anchor: torch.Tensor):
+        """TextFARE loss of (anchor, feat) and its gradient with respect to the token embeddings (= the gradient of
+        ``delta``) through the stash of the last ``forward_train``: (loss 0-d, d_embed fp32 [rows, width] packed).
+        No parameter gradient is touched (the inner step of the optional embedding-space PGD mode)."""
+        t = self._train_tokens
+        n = t.shape[0]
+        lens_p, cu, keep = self._train_plan
+        rows = int(keep.sum()) if keep is not None else n * self.cfg.context_length
+        loss = torch.empty((), dtype=torch.float32, device=self.device)
+        g = torch.empty(rows, self.cfg.width, dtype=torch.float32, device=self.device)
+        anchor = anchor.to(device=self.device, dtype=torch.float32).contiguous()
+        ws = self._workspace(2, n)
+        _lib.check(self._lib.leaf_textfare_input_grad(self._h, _ptr(self.flat), _ptr(self.w16_bwd), _ptr(t), lens_p,
+                                                      _ptr(cu), n, _ptr(feat.contiguous()), _ptr(anchor),
+                                                      _ptr(self._stash), _ptr(g), _ptr(loss), _ptr(ws), ws.numel(),
+                                                      self._stream()), "leaf_textfare_input_grad")
+        return loss, g
+
+    def pgd_step(self, delta: torch.Tensor, grad: torch.Tensor, alpha: float, eps: float, norm: str = "linf"):
+        """In-place fused update of the resident perturbation for the rows of the last ``forward_train``:
+        'linf': clamp(delta + alpha sign(grad), -eps, eps); 'l2': per-sequence normalised step + L2-ball projection."""
+        lens_p, cu, keep = self._train_plan
+        n = self._train_tokens.shape[0]
+        _lib.check(self._lib.leaf_pgd_step(_ptr(delta), _ptr(grad), _ptr(cu), n, self.cfg.context_length, self.cfg.width,
+                                           float(alpha), float(eps), {"linf": 0, "l2": 2}[norm], self._stream()),
+                   "leaf_pgd_step")
+        return delta
 
     def backward(self, feat: torch.Tensor, anchor: torch.Tensor, accum_scale: float = 1.0) -> torch.Tensor:
         """TextFARE loss of (anchor, feat) + backward through the stash of the last ``forward_train``.
