@@ -82,6 +82,12 @@ def main():
     ap.add_argument("--dense", action="store_true", help="compute all 77 rows per sequence (no EOT trimming)")
     ap.add_argument("--no-prefix-reuse", action="store_true", help="recompute every kept row of every candidate")
     ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--attack", default="leaf", choices=["leaf", "pgd"],
+                    help="leaf = the reference's character search (the BASELINE.json metric); pgd = the OPTIONAL embedding-space "
+                         "PGD mode of SURVEY.md 8a row a12 (k-adv inner steps), which the reference's text trainer does not run")
+    ap.add_argument("--pgd-eps", type=float, default=0.05)
+    ap.add_argument("--pgd-alpha", type=float, default=0.02)
+    ap.add_argument("--pgd-norm", default="linf", choices=["linf", "l2"])
     args = ap.parse_args()
 
     import numpy as np
@@ -109,7 +115,8 @@ def main():
     frozen = LeafCLIPText(cfg, device=dev, dtype=args.dtype).copy_from(model)
     frozen.pack()
     model.pack()
-    sc = StepConfig(rho=args.rho, k_adv=args.k_adv, lr=1e-5, wd=1e-4)
+    sc = StepConfig(rho=args.rho, k_adv=args.k_adv, lr=1e-5, wd=1e-4, attack=args.attack, pgd_eps=args.pgd_eps,
+                    pgd_alpha=args.pgd_alpha, pgd_norm=args.pgd_norm)
     # synthetic captions: SOT, U{8..40} ids, EOT, zero pad; a different shard per rank (seed + rank)
     g = torch.Generator().manual_seed(1234 + rank)
     B = args.batch
@@ -165,7 +172,9 @@ def main():
         gemm_total_ms = sum(k[0] for k in kinds)
         gemm_total_fl = sum(k[1] for k in kinds)
         F = fwd_flops_per_seq(cfg)
-        flops_per_sample = (2 * args.rho * args.k_adv + 4) * F
+        # algorithmic cost per sample: LEAF search (2 rho k candidate forwards + anchor + train fwd + 2x bwd), or for the
+        # optional embedding-space PGD mode k x (fwd + input-gradient bwd ~ 1 + 1) on top of anchor + start fwd + train bwd
+        flops_per_sample = (2 * args.rho * args.k_adv + 4) * F if args.attack == "leaf" else (2 * args.k_adv + 4) * F
         value = B * world * args.steps / dt
         traffic = None     # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/)
         try:
@@ -181,8 +190,12 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype + " MFMA operands, f32 accumulate", "data": "synthetic",
-            "config": {"workload": f"CLIP {args.model} text encoder, LEAF step k={args.k_adv} rho={args.rho}, "
-                                   f"B={B} per GPU, seq=77 (BASELINE.json configs[1])",
+            "config": {"workload": (f"CLIP {args.model} text encoder, LEAF step k={args.k_adv} rho={args.rho}, "
+                                    f"B={B} per GPU, seq=77 (BASELINE.json configs[1])") if args.attack == "leaf" else
+                                   (f"CLIP {args.model} text encoder, OPTIONAL embedding-space PGD mode (SURVEY 8a row a12, NOT "
+                                    f"the reference's text attack): k={args.k_adv} steps, {args.pgd_norm} eps={args.pgd_eps} "
+                                    f"alpha={args.pgd_alpha}, B={B} per GPU, seq=77"),
+                       "attack": args.attack,
                        "global_batch": B * world, "seq_len": cfg.context_length, "rho": args.rho, "k": args.k_adv,
                        "parallelism": f"dp{world}", "candidate_forwards_per_step_per_gpu": 2 * args.rho * args.k_adv * B},
             "roofline": {
@@ -206,7 +219,7 @@ def main():
             "executed_gemm_tflop_per_step": gemm_total_fl / args.steps / 1e12,
             "loss": float(loss),
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.attack == "leaf":
             oracle_name = args.model if args.model in ("ViT-L-14", "ViT-L-14-quickgelu", "ViT-H-14", "ViT-g-14", "ViT-bigG-14") else "ViT-L-14"
             out["cpu_baseline"] = cpu_baseline(oracle_name, args.rho, args.k_adv, args.cpu_batch, seed=1234)
         print(json.dumps(out), flush=True)

@@ -22,6 +22,7 @@ import os
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
+import numpy as np
 import torch
 
 
@@ -35,6 +36,13 @@ class StepConfig:
     beta2: float = 0.999
     eps: float = 1e-8
     accum_freq: int = 1
+    # attack = "leaf": the reference's character search (default, the BASELINE.json metric).  attack = "pgd": the OPTIONAL
+    # embedding-space PGD mode (not what the reference's text trainer runs): k_adv steps of
+    # delta <- project(delta + pgd_alpha * normalize_grad(grad)) within the pgd_norm ball of radius pgd_eps.
+    attack: str = "leaf"
+    pgd_eps: float = 0.05
+    pgd_alpha: float = 0.02
+    pgd_norm: str = "linf"
 
 
 class SyntheticCandidates:
@@ -154,10 +162,19 @@ def train_step_tokens(model, frozen, base: torch.Tensor, cfg: StepConfig, seed: 
         ready = torch.cuda.Event()
         ready.record(side)
     anchor.record_stream(cur)
-    adv = search_synthetic(model, anchor, base, cfg, seed, base_lens=base_lens, prefix_reuse=prefix_reuse,
-                           anchor_ready=ready)
-    model.train()
-    feat = model.forward_train(adv, seq_lens=base_lens)
+    if cfg.attack == "pgd":
+        from .attacks import attack_embedding_pgd
+        cur.wait_event(ready)
+        # the attack's last forward is the training forward of the perturbed captions: its stash feeds the backward
+        feat, _ = attack_embedding_pgd(model, base, anchor, cfg.pgd_eps, cfg.pgd_alpha, k=cfg.k_adv, norm=cfg.pgd_norm,
+                                       seq_lens=base_lens if base_lens is not None else np.full(base.shape[0], base.shape[1]),
+                                       seed=seed)
+        model.train()
+    else:
+        adv = search_synthetic(model, anchor, base, cfg, seed, base_lens=base_lens, prefix_reuse=prefix_reuse,
+                               anchor_ready=ready)
+        model.train()
+        feat = model.forward_train(adv, seq_lens=base_lens)
     if micro_index % cfg.accum_freq == 0:
         model.zero_grad()
     loss = model.backward(feat, anchor, accum_scale=1.0 / cfg.accum_freq)
