@@ -294,8 +294,8 @@ def encode_text_backward(w, cfg: TextCfg, tokens: np.ndarray, anchor: np.ndarray
                          delta: Optional[np.ndarray] = None):
     """Forward + TextFARE loss + full backward in fp32.  Returns (loss, feat, grads) where
     grads has the same keys/shapes as ``w`` (utils_AT.py:317-337; loss / accum_freq is
-    what gets back-propagated, ``accum_scale`` = 1/accum_freq) plus ``grads["d_embed"]`` [N,ctx,width], the gradient
-    with respect to the (perturbed) token embeddings = the gradient of ``delta``."""
+    what gets back-propagated, ``accum_scale`` = 1/accum_freq); when ``delta`` is given also ``grads["d_embed"]``
+    [N,ctx,width], the gradient with respect to the perturbed token embeddings = the gradient of ``delta``."""
     tokens = np.asarray(tokens)
     N, L = tokens.shape
     d, H, hd = cfg.width, cfg.heads, cfg.head_dim
@@ -344,7 +344,8 @@ def encode_text_backward(w, cfg: TextCfg, tokens: np.ndarray, anchor: np.ndarray
         dx = (dx1 + dl).astype(F32)
     g["positional_embedding"][:L] = dx.sum(0)
     np.add.at(g["token_embedding.weight"], tokens.reshape(-1), dx.reshape(N * L, d))
-    g["d_embed"] = dx.astype(F32)
+    if delta is not None:      # only in the embedding-space mode, so that g keeps exactly the keys of w otherwise
+        g["d_embed"] = dx.astype(F32)
     return loss, feat, g
 
 
