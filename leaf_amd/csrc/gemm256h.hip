@@ -261,7 +261,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
                 const int row = 8 * it + (lane >> 3), pc = lane & 7;
                 const uint4 v = *(const uint4*)(sl + row * 128 + (pc << 4));
                 const int m = mb + 64 * pass + row;
-                if (m < p.M) *(uint4*)(dst + (size_t)m * p.ldc + nb + ((pc ^ (row & 7)) << 3)) = v;
+                if (m < p.M) {
+                    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, v), (u32x4_t*)(dst + (size_t)m * p.ldc + nb + ((pc ^ (row & 7)) << 3)));
+                }
             }
         };
 #pragma unroll
@@ -312,7 +315,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
                     v.x = __builtin_fmaf(res[it].x, beta, v.x); v.y = __builtin_fmaf(res[it].y, beta, v.y);
                     v.z = __builtin_fmaf(res[it].z, beta, v.z); v.w = __builtin_fmaf(res[it].w, beta, v.w);
                 }
-                if (m < p.M) *(float4*)((float*)p.C + (size_t)m * p.ldc + nb + ((pc ^ (row & 15)) << 2)) = v;
+                if (m < p.M) {
+                    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store(f32x4_t{v.x, v.y, v.z, v.w}, (f32x4_t*)((float*)p.C + (size_t)m * p.ldc + nb + ((pc ^ (row & 15)) << 2)));
+                }
             }
         }
     }
