@@ -43,7 +43,21 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
     const int wm = wid >> 2, wn = wid & 3;
     const int tiles_n = p.N / BN;
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (logical / tiles_n) * BM, n0 = (logical % tiles_n) * BN;
+    // Tile order: N tiles in groups of p.ngroup; inside a group M-major / N-minor.  An XCD (a contiguous range of logical
+    // ids) then sweeps many M panels against ONE group's B panels, which stay in its 4-MiB L2 instead of being re-fetched
+    // for every round of 32 tiles (the host picks the group size, launch256h).
+    int m0, n0;
+    {
+        const int G = (p.ngroup > 0 && p.ngroup < tiles_n) ? p.ngroup : tiles_n;
+        const int tiles_m = (p.M + BM - 1) / BM;
+        int g = logical / (tiles_m * G);
+        const int ng = (tiles_n + G - 1) / G;
+        if (g > ng - 1) g = ng - 1;
+        const int rem = logical - g * tiles_m * G;
+        const int gsz = g == ng - 1 ? tiles_n - g * G : G;
+        m0 = (rem / gsz) * BM;
+        n0 = (g * G + rem % gsz) * BN;
+    }
 
     // ---- DMA sources: wave w moves pieces 4w..4w+3 (8 rows x 128 B) of whichever panel a half-stage carries
     const int prow = lane >> 3;
@@ -325,8 +339,33 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
     STAMP(4)
 }
 
+// N tiles per group: minimise the bytes that miss L2.  A group's B panels (G x 256 rows x K) stay resident in an XCD's L2
+// when they are small (<= ~2 MiB); the A operand is then streamed once per group.  With everything in one group (the
+// M-major order) B is re-fetched for every round of 32 concurrent tiles per XCD once it no longer fits beside A.
+// LEAF_GEMM_NGROUP = n forces a size (0 = never group).
+static int pick_ngroup(const GemmArgs& p) {
+    static int forced = -2;
+    if (forced == -2) { const char* e = getenv("LEAF_GEMM_NGROUP"); forced = e ? atoi(e) : -1; }
+    const int tiles_n = p.N / BN, tiles_m = (p.M + BM - 1) / BM;
+    if (forced >= 0) return forced < tiles_n ? forced : 0;
+    const double a_bytes = (double)p.M * p.K * 2, b_tile = (double)BN * p.K * 2;
+    const double rounds = (double)tiles_m * tiles_n / 256.0;    // rounds of 32 tiles per XCD
+    int best = 0;
+    double best_cost = -1;
+    for (int G = 1; G <= tiles_n; ++G) {
+        const int ng = (tiles_n + G - 1) / G;
+        const bool resident = G * b_tile <= 2.0 * 1024 * 1024;
+        const double b_cost = resident ? b_tile * tiles_n * 8 : b_tile * tiles_n * 8 * (rounds > 1 ? rounds : 1);
+        const double cost = a_bytes * ng + b_cost;
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = G; }
+    }
+    return best >= tiles_n ? 0 : best;
+}
+
 template <class TT>
-hipError_t launch256h(const GemmArgs& p, int epi, hipStream_t s) {
+hipError_t launch256h(const GemmArgs& p_in, int epi, hipStream_t s) {
+    GemmArgs p = p_in;
+    p.ngroup = pick_ngroup(p);
     const int grid = ((p.M + BM - 1) / BM) * (p.N / BN);
 #define LEAF_CASE(E)                                                                                         \
     case E: {                                                                                                \

@@ -27,6 +27,7 @@ struct GemmArgs {
     float beta;
     void* stamps; // diagnostic builds only (-DLEAF_GEMM_STAMPS)
     const float* alpha;  // optional DEVICE scalar multiplying the accumulator (gradient un-scaling), or null
+    int ngroup;   // tile order of the 256^2 kernels: N tiles per group (0 = all: M-major / N-minor over the whole matrix)
 };
 
 hipError_t leaf_launch_gemm(const GemmArgs& p, int dtype, int epi, hipStream_t s);
