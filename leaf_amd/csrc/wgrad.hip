@@ -52,12 +52,15 @@ template <class XT, class GT>
 __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    // XCD-aware order: blocks that share an XCD (blockIdx % 8) take a contiguous range of tiles, so the tiles that re-read one
+    // dY column panel / X column panel hit that XCD's L2 instead of every XCD fetching its own copy
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < 4; ++i)
-        if (i < a.nprob && (int)blockIdx.x >= a.p[i].tile0) pi = i;
+        if (i < a.nprob && bid >= a.p[i].tile0) pi = i;
     const WgradProb& P = a.p[pi];
-    const int local = blockIdx.x - P.tile0;
+    const int local = bid - P.tile0;
     const int tn = local / P.tiles_k, tk = local % P.tiles_k;
     const int n0 = tn * TM, k0 = tk * TN;
     const int rows = a.rows;
