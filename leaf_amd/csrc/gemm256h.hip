@@ -393,7 +393,9 @@ hipError_t launch256h(const GemmArgs& p_in, int epi, hipStream_t s) {
 
 bool leaf_gemm256h_eligible(const GemmArgs& p, int epi) {
     const long tiles = (long)((p.M + BM - 1) / BM) * (p.N / BN);
-    return p.N % BN == 0 && tiles >= 128 && p.K % BK == 0 && p.K >= 4 * BK && p.ldc % 8 == 0 && epi != EPI_ACTGRAD_T;
+    // the DMA sources are 32-bit byte offsets from the operand bases (saddr + voffset): both operands must span < 4 GiB
+    const bool fits32 = (unsigned long long)p.M * p.lda * 2ull < (1ull << 32) && (unsigned long long)p.N * p.ldb * 2ull < (1ull << 32);
+    return p.N % BN == 0 && tiles >= 128 && p.K % BK == 0 && p.K >= 4 * BK && p.ldc % 8 == 0 && epi != EPI_ACTGRAD_T && fits32;
 }
 
 hipError_t leaf_launch_gemm256h(const GemmArgs& p, int dtype, int epi, hipStream_t s) {

@@ -201,7 +201,9 @@ int pick_mi(const GemmArgs& p) {
 }  // namespace
 
 bool leaf_gemm64_eligible(const GemmArgs& p) {
-    return p.M > 0 && p.N % BN == 0 && p.K % BK == 0 && p.K >= 3 * BK && p.lda % 8 == 0 && p.ldb % 8 == 0 && p.ldc % 4 == 0;
+    // 32-bit byte offsets from the operand bases: both operands must span < 4 GiB
+    const bool fits32 = (unsigned long long)p.M * p.lda * 2ull < (1ull << 32) && (unsigned long long)p.N * p.ldb * 2ull < (1ull << 32);
+    return p.M > 0 && p.N % BN == 0 && p.K % BK == 0 && p.K >= 3 * BK && p.lda % 8 == 0 && p.ldb % 8 == 0 && p.ldc % 4 == 0 && fits32;
 }
 
 hipError_t leaf_launch_gemm64(const GemmArgs& p, int dtype, int epi, hipStream_t s) {
