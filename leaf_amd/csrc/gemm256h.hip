@@ -391,6 +391,8 @@ hipError_t launch256h(const GemmArgs& p_in, int epi, hipStream_t s) {
 
 }  // namespace
 
+int leaf_gemm256h_pick_ngroup(const GemmArgs& p) { return pick_ngroup(p); }
+
 bool leaf_gemm256h_eligible(const GemmArgs& p, int epi) {
     const long tiles = (long)((p.M + BM - 1) / BM) * (p.N / BN);
     // the DMA sources are 32-bit byte offsets from the operand bases (saddr + voffset): both operands must span < 4 GiB

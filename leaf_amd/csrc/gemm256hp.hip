@@ -66,7 +66,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_halfp_kernel(GemmArgs p, in
     const unsigned bstep = 16u * (unsigned)p.ldb;   // 8 rows, bytes
 #define SET_TILE(t)                                                                                          \
     {                                                                                                        \
-        m0 = ((t) / tiles_n) * BM; n0 = ((t) % tiles_n) * BN;                                                \
+        {                                                                                                    \
+            const int G_ = (p.ngroup > 0 && p.ngroup < tiles_n) ? p.ngroup : tiles_n;                        \
+            const int tm_ = (p.M + BM - 1) / BM, ng_ = (tiles_n + G_ - 1) / G_;                              \
+            int g_ = (t) / (tm_ * G_);                                                                       \
+            if (g_ > ng_ - 1) g_ = ng_ - 1;                                                                  \
+            const int rem_ = (t) - g_ * tm_ * G_;                                                            \
+            const int gsz_ = g_ == ng_ - 1 ? tiles_n - g_ * G_ : G_;                                         \
+            m0 = (rem_ / gsz_) * BM; n0 = (g_ * G_ + rem_ % gsz_) * BN;                                      \
+        }                                                                                                    \
         const int r_ = m0 + wid * 32 + prow;                                                                 \
         const int c0_ = r_ < p.M ? r_ : p.M - 1, c1_ = r_ + 8 < p.M ? r_ + 8 : p.M - 1;                      \
         const int c2_ = r_ + 16 < p.M ? r_ + 16 : p.M - 1, c3_ = r_ + 24 < p.M ? r_ + 24 : p.M - 1;          \
@@ -263,7 +271,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_halfp_kernel(GemmArgs p, in
                 const int row = 8 * it + (lane >> 3), pc = lane & 7;
                 const uint4 v = *(const uint4*)(sl + row * 128 + (pc << 4));
                 const int m = mb + 64 * pass + row;
-                if (m < p.M) *(uint4*)(dst + (size_t)m * p.ldc + nb + ((pc ^ (row & 7)) << 3)) = v;
+                if (m < p.M) {
+                    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, v), (u32x4_t*)(dst + (size_t)m * p.ldc + nb + ((pc ^ (row & 7)) << 3)));
+                }
             }
         };
 #pragma unroll
@@ -314,7 +325,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_halfp_kernel(GemmArgs p, in
                     v.x = __builtin_fmaf(res[it].x, beta, v.x); v.y = __builtin_fmaf(res[it].y, beta, v.y);
                     v.z = __builtin_fmaf(res[it].z, beta, v.z); v.w = __builtin_fmaf(res[it].w, beta, v.w);
                 }
-                if (m < p.M) *(float4*)((float*)p.C + (size_t)m * p.ldc + nb + ((pc ^ (row & 15)) << 2)) = v;
+                if (m < p.M) {
+                    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store(f32x4_t{v.x, v.y, v.z, v.w}, (f32x4_t*)((float*)p.C + (size_t)m * p.ldc + nb + ((pc ^ (row & 15)) << 2)));
+                }
             }
         }
     }
@@ -343,7 +357,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_halfp_kernel(GemmArgs p, in
 }
 
 template <class TT>
-hipError_t launch256hp(const GemmArgs& p, int epi, hipStream_t s) {
+hipError_t launch256hp(const GemmArgs& p_in, int epi, hipStream_t s) {
+    GemmArgs p = p_in;
+    p.ngroup = leaf_gemm256h_pick_ngroup(p);
     const int ntiles = ((p.M + BM - 1) / BM) * (p.N / BN);
     static int ncu = 0;
     if (!ncu) {

@@ -40,6 +40,7 @@ hipError_t leaf_launch_gemm256(const GemmArgs& p, int dtype, int epi, hipStream_
 hipError_t leaf_launch_gemm256p(const GemmArgs& p, int dtype, int epi, hipStream_t s);
 // 64-deep half-stage ring with full-line DMA pieces (gemm256h.hip)
 bool leaf_gemm256h_eligible(const GemmArgs& p, int epi);
+int leaf_gemm256h_pick_ngroup(const GemmArgs& p);   // N tiles per L2-sized group (0 = one group)
 hipError_t leaf_launch_gemm256h(const GemmArgs& p, int dtype, int epi, hipStream_t s);
 // 64 x 128 tiles on a 3-slot LDS-DMA ring for small launches (gemm64.hip)
 bool leaf_gemm64_eligible(const GemmArgs& p);
