@@ -103,6 +103,7 @@ extern "C" int leaf_text_set_option(leaf_text_t h, const char* name, int value) 
     if (!strcmp(name, "chunk")) return leaf_text_set_chunk(h, value);
     if (!strcmp(name, "last_layer_trim")) { h->last_trim = value ? 1 : 0; return 0; }
     if (!strcmp(name, "streams")) { h->streams = value >= 2 ? 2 : 1; return 0; }
+    if (!strcmp(name, "normalize_fare")) { h->normalize_fare = value ? 1 : 0; return 0; }
     leaf_set_error("unknown option '%s'", name);
     return 1;
 }

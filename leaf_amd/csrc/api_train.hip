@@ -15,6 +15,7 @@ struct Stash {
     uint16_t* hh;    // [L][rows,4d]
     float* pooled;   // [n,d]
     int32_t* eot;    // [n]
+    float* norms;    // [n]  ||features|| of the last training forward (--normalize_fare)
 };
 
 size_t total_rows(const leaf_text* h, const int32_t* lens, int n_seq) {
@@ -37,6 +38,7 @@ Stash carve_stash(const leaf_text* h, Carver& c, int n_seq, size_t rows) {
     s.hh = (uint16_t*)c.take(L * rows * 4 * d * 2);
     s.pooled = (float*)c.take((size_t)n_seq * d * 4);
     s.eot = (int32_t*)c.take((size_t)n_seq * 4);
+    s.norms = (float*)c.take((size_t)n_seq * 4);
     return s;
 }
 
@@ -128,10 +130,11 @@ extern "C" int leaf_text_forward_train_delta(leaf_text_t h, const float* P, cons
         LEAF_TRY(leaf_launch_gather_rows(st.xin + (size_t)L * rd, st.eot, xg, n_seq, map, d, s));
         LEAF_TRY(leaf_launch_project_rows(xg, P + h->lnf_w, P + h->lnf_b, cf.ln_eps, P + h->text_proj, st.pooled, out, n_seq, d,
                                           cf.embed_dim, 0, s));
-        return 0;
+    } else {
+        LEAF_TRY(leaf_launch_pool_project(st.xin + (size_t)L * rd, tokens, P + h->lnf_w, P + h->lnf_b, cf.ln_eps,
+                                          P + h->text_proj, out, st.pooled, st.eot, n_seq, map, d, cf.embed_dim, 0, s));
     }
-    LEAF_TRY(leaf_launch_pool_project(st.xin + (size_t)L * rd, tokens, P + h->lnf_w, P + h->lnf_b, cf.ln_eps,
-                                      P + h->text_proj, out, st.pooled, st.eot, n_seq, map, d, cf.embed_dim, 0, s));
+    if (h->normalize_fare) LEAF_TRY(leaf_launch_normalize_rows(out, st.norms, n_seq, cf.embed_dim, s));   // utils_AT.py:319
     return 0;
 }
 
@@ -178,7 +181,8 @@ static int backward_impl(leaf_text_t h, const float* P, const void* w16_bwd, con
                          inv_s);
     };
 
-    LEAF_TRY(leaf_launch_fare_loss(feat, anchor, n_seq, D, accum_scale, loss_out, b.dout, b.gscale, gk == 1, s));
+    LEAF_TRY(leaf_launch_fare_loss(feat, anchor, n_seq, D, accum_scale, loss_out, b.dout, b.gscale, gk == 1, s,
+                                   h->normalize_fare ? st.norms : nullptr));
     LEAF_TRY(hipMemsetAsync(b.dx, 0, rd * 4, s));
     LEAF_TRY(leaf_launch_pool_project_bwd(b.dout, st.pooled, st.xin + (size_t)L * rd, st.eot, P + h->lnf_w, P + h->lnf_b,
                                           cf.ln_eps, P + h->text_proj, b.dx, G ? G + h->text_proj : nullptr,

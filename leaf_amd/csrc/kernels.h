@@ -90,7 +90,9 @@ hipError_t leaf_launch_cast16(const void* src, int src_kind, void* dst, int dst_
 // loss = mean_b sum_j (anchor-feat)^2 ; dout = 2 (feat-anchor) / B * scale.  gscale[0] = S, gscale[1] = 1/S: the
 // power-of-two loss scale of the fp16 gradient path (S = 1 when use_scaling == 0), chosen so that max|dout| * S ~ 16.
 hipError_t leaf_launch_fare_loss(const float* feat, const float* anchor, int B, int D, float scale, float* loss,
-                                 float* dout, float* gscale, int use_scaling, hipStream_t s);
+                                 float* dout, float* gscale, int use_scaling, hipStream_t s,
+                                 const float* norms = nullptr /* --normalize_fare: ||f|| per caption, feat is f / ||f|| */);
+hipError_t leaf_launch_normalize_rows(float* x, float* norms, int M, int D, hipStream_t s);
 // projection + pooling + final-LN backward: writes dx (fp32 [rows,d], zero except EOT rows), accumulates
 // dproj [d,D], dg/db of ln_final.
 hipError_t leaf_launch_pool_project_bwd(const float* dout, const float* pooled, const float* x, const int32_t* eot_idx,

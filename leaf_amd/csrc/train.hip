@@ -83,27 +83,63 @@ __global__ __launch_bounds__(256) void cast16_kernel(const void* __restrict__ sr
 // its dout row and {row sum, row max|dout|} partials, one block reduces the partials in a fixed order.
 __global__ __launch_bounds__(256) void fare_rows_kernel(const float* __restrict__ feat, const float* __restrict__ anchor,
                                                         int B, int D, float scale, float* __restrict__ dout,
-                                                        float* __restrict__ partial) {
-    __shared__ float red[8];
+                                                        float* __restrict__ partial, const float* __restrict__ norms) {
+    __shared__ float red[12];
     const int tid = threadIdx.x, b = blockIdx.x;
     const float k = 2.0f / (float)B * scale;
-    float s = 0.f, amax = 0.f;
-    for (int j = tid; j < D; j += 256) {
-        const size_t i = (size_t)b * D + j;
-        const float df = feat[i] - anchor[i];
-        s = fmaf(df, df, s);
-        const float g = k * df;
-        amax = fmaxf(amax, fabsf(g));
-        if (dout) dout[i] = g;
+    constexpr int PER = 8;                      // D <= 2048
+    float g[PER], f[PER];
+    float s = 0.f, dot = 0.f;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int j = tid + 256 * u;
+        g[u] = 0.f; f[u] = 0.f;
+        if (j < D) {
+            const size_t i = (size_t)b * D + j;
+            f[u] = feat[i];
+            const float df = f[u] - anchor[i];
+            s = fmaf(df, df, s);
+            g[u] = k * df;
+            dot = fmaf(f[u], g[u], dot);
+        }
     }
     s = wave_sum(s);
+    dot = wave_sum(dot);
+    if ((tid & 63) == 0) { red[tid >> 6] = s; red[8 + (tid >> 6)] = dot; }
+    __syncthreads();
+    // --normalize_fare (utils_AT.py:319): feat = f / ||f||; d f = (d feat - feat (feat . d feat)) / ||f||
+    const float dotb = (red[8] + red[9]) + (red[10] + red[11]);
+    const float inv_n = norms ? 1.0f / fmaxf(norms[b], 1e-12f) : 1.0f;
+    float amax = 0.f;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int j = tid + 256 * u;
+        if (j < D) {
+            const float go = norms ? (g[u] - f[u] * dotb) * inv_n : g[u];
+            amax = fmaxf(amax, fabsf(go));
+            if (dout) dout[(size_t)b * D + j] = go;
+        }
+    }
     amax = wave_max(amax);
-    if ((tid & 63) == 0) { red[tid >> 6] = s; red[4 + (tid >> 6)] = amax; }
+    if ((tid & 63) == 0) red[4 + (tid >> 6)] = amax;
     __syncthreads();
     if (tid == 0) {
         partial[2 * b] = (red[0] + red[1]) + (red[2] + red[3]);
         partial[2 * b + 1] = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
     }
+}
+
+// in place: x[b] /= max(||x[b]||, 1e-12) and norms[b] = ||x[b]||   (F.normalize of the training features, one wave per row)
+__global__ __launch_bounds__(256) void normalize_rows_kernel(float* __restrict__ x, float* __restrict__ norms, int M, int D) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float* xr = x + (size_t)row * D;
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) s = fmaf(xr[c], xr[c], s);
+    const float n = sqrtf(wave_sum(s));
+    const float inv = 1.0f / fmaxf(n, 1e-12f);
+    for (int c = lane; c < D; c += 64) xr[c] *= inv;
+    if (lane == 0) norms[row] = n;
 }
 
 __global__ __launch_bounds__(256) void fare_reduce_kernel(const float* __restrict__ partial, int B, float* __restrict__ loss,
@@ -572,10 +608,16 @@ hipError_t leaf_launch_cast16(const void* src, int src_kind, void* dst, int dst_
     return hipGetLastError();
 }
 
+hipError_t leaf_launch_normalize_rows(float* x, float* norms, int M, int D, hipStream_t s) {
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, norms, M, D);
+    return hipGetLastError();
+}
+
 hipError_t leaf_launch_fare_loss(const float* feat, const float* anchor, int B, int D, float scale, float* loss,
-                                 float* dout, float* gscale, int use_scaling, hipStream_t s) {
+                                 float* dout, float* gscale, int use_scaling, hipStream_t s, const float* norms) {
+    if (D > 2048) return hipErrorInvalidValue;
     float* partial = gscale + 64;   // [B][2] right behind the {S, 1/S} slot (carve_bwd reserves it)
-    hipLaunchKernelGGL(fare_rows_kernel, dim3(B), dim3(256), 0, s, feat, anchor, B, D, scale, dout, partial);
+    hipLaunchKernelGGL(fare_rows_kernel, dim3(B), dim3(256), 0, s, feat, anchor, B, D, scale, dout, partial, norms);
     hipLaunchKernelGGL(fare_reduce_kernel, dim3(1), dim3(256), 0, s, partial, B, loss, gscale, use_scaling);
     return hipGetLastError();
 }

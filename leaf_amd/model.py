@@ -127,7 +127,7 @@ class LeafCLIPText:
 
     def set_option(self, name: str, value: int):
         """Engine switches (leaf_text_set_option): 'chunk', 'last_layer_trim', 'streams' (1 | 2: two-stream
-        chunk pipeline of the forward-only passes)."""
+        chunk pipeline of the forward-only passes), 'normalize_fare' (training forward / backward on normalised features)."""
         _lib.check(self._lib.leaf_text_set_option(self._h, name.encode(), int(value)), "leaf_text_set_option")
         return self
 
@@ -367,11 +367,15 @@ class LeafCLIPText:
     def zero_grad(self):
         self.grads.zero_()
 
-    def forward_train(self, text, seq_lens=None, delta: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def forward_train(self, text, seq_lens=None, delta: Optional[torch.Tensor] = None, normalize: bool = False) -> torch.Tensor:
         """Training-mode forward that keeps the activation stash.  ``delta`` (optional embedding-space PGD mode, SURVEY 8a
         row a12): fp32 CUDA tensor [rows, width] in the PACKED row layout of this call (``rows_of(seq_lens)`` rows; dense
-        [N * ctx, width] when rows are not trimmed), added to the token embeddings."""
+        [N * ctx, width] when rows are not trimmed), added to the token embeddings.  ``normalize`` = --normalize_fare
+        (utils_AT.py:319): returns F.normalize(features); the following ``backward`` differentiates through it."""
         self.enable_training()
+        if bool(normalize) != getattr(self, "_normalize_fare", False):
+            self.set_option("normalize_fare", int(bool(normalize)))
+            self._normalize_fare = bool(normalize)
         if not self._packed:
             self.pack()
         self._train_plan = self._row_plan(text, seq_lens)

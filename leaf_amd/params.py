@@ -4,7 +4,7 @@ Every flag the reference's LEAF launch scripts pass (scripts/train_leaf_vit*.sh)
 and default.  Flags that only concern parts of the reference outside the text hot path (image tower, evaluation
 sets, wandb, remote sync ...) are parsed and ignored, so an existing command line keeps working; the ones that
 would change the text path's behaviour in a way this engine does not implement are rejected loudly
-(``--use_charmer``, ``--horovod``, ``--normalize_fare``).
+(``--use_charmer``, ``--horovod``); ``--normalize_fare`` is implemented in the training kernels.
 
 Model-dependent Adam defaults follow ``get_default_params`` (params_AT.py:17-23): "vit" in the lower-cased model
 name -> beta2 0.98 / eps 1e-6, else 0.999 / 1e-8 (so ``hf-hub:chs20/fare2-clip`` gets the latter, as in the

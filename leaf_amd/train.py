@@ -232,8 +232,7 @@ def train_one_epoch_text_only(model, model_frozen, tokenizer, V, data, loss, epo
         raise NotImplementedError("--use_charmer (per-sentence Charmer attack) is outside the accelerated path")
     if getattr(args, "horovod", False):
         raise NotImplementedError("horovod is not supported; launch with torch.distributed.run (RCCL)")
-    if getattr(args, "normalize_fare", False):
-        raise NotImplementedError("--normalize_fare is not implemented in the training kernels")
+    normalize_fare = bool(getattr(args, "normalize_fare", False))   # utils_AT.py:296,319
     device = torch.device(args.device)
     model.train()
     data['train'].set_epoch(epoch)
@@ -251,14 +250,14 @@ def train_one_epoch_text_only(model, model_frozen, tokenizer, V, data, loss, epo
             scheduler(step)
         _, texts = batch
         model.eval()
-        anchor = model_frozen.encode_text(tokenizer.encode_batch(texts))
+        anchor = model_frozen.encode_text(tokenizer.encode_batch(texts), normalize=normalize_fare)
         t0 = time.time()
         _, adv_texts = attack_text(model, tokenizer, texts, anchor, device, objective='l2', n=args.rho, k=args.k_adv,
                                    V=V, constrain=args.constrain, debug=False)
         times.append(time.time() - t0)
         adv_tokens = tokenizer.encode_batch(adv_texts)
         model.train()
-        feat = model.forward_train(adv_tokens)
+        feat = model.forward_train(adv_tokens, normalize=normalize_fare)
         data_time_m.update(time.time() - end)
         loss_fare = model.backward(feat, anchor, accum_scale=1.0 / args.accum_freq)   # device scalar, no sync
         for key in ("loss", "loss_FARE_text"):

@@ -291,20 +291,30 @@ def _ln_bwd(dy, x, mu, rstd, g):
 
 
 def encode_text_backward(w, cfg: TextCfg, tokens: np.ndarray, anchor: np.ndarray, accum_scale: float = 1.0,
-                         delta: Optional[np.ndarray] = None):
+                         delta: Optional[np.ndarray] = None, normalize: bool = False):
     """Forward + TextFARE loss + full backward in fp32.  Returns (loss, feat, grads) where
     grads has the same keys/shapes as ``w`` (utils_AT.py:317-337; loss / accum_freq is
     what gets back-propagated, ``accum_scale`` = 1/accum_freq); when ``delta`` is given also ``grads["d_embed"]``
-    [N,ctx,width], the gradient with respect to the perturbed token embeddings = the gradient of ``delta``."""
+    [N,ctx,width], the gradient with respect to the perturbed token embeddings = the gradient of ``delta``.
+    ``normalize`` = --normalize_fare (utils_AT.py:296,319): the loss is taken on F.normalize(feat) (the anchor is expected
+    normalised by the caller); the returned ``feat`` is then the normalised one."""
     tokens = np.asarray(tokens)
     N, L = tokens.shape
     d, H, hd = cfg.width, cfg.heads, cfg.head_dim
     stash: list = []
     feat = encode_text(w, cfg, tokens, stash=stash, delta=delta)
-    loss = textfare_loss(anchor, feat)
+    if normalize:       # F.normalize(dim=-1, eps=1e-12) and its backward: d f = (d n - n (n . d n)) / ||f||
+        nrm = np.maximum(np.linalg.norm(feat.astype(np.float64), axis=-1, keepdims=True), 1e-12)
+        feat_n = (feat / nrm).astype(F32)
+        loss = textfare_loss(anchor, feat_n)
+        dn = 2.0 * (feat_n - anchor) / N * accum_scale
+        dout = ((dn - feat_n * (feat_n * dn).sum(-1, keepdims=True)) / nrm).astype(F32)
+        feat = feat_n
+    else:
+        loss = textfare_loss(anchor, feat)
+        dout = (2.0 * (feat - anchor) / N * accum_scale).astype(F32)          # [N,D]
     g = {k: np.zeros_like(v) for k, v in w.items()}
     top = stash[-1]
-    dout = (2.0 * (feat - anchor) / N * accum_scale).astype(F32)          # [N,D]
     g["text_projection"] = (top["pooled"].T @ dout).astype(F32)
     dpooled = dout @ w["text_projection"].T                                # [N,d]
     dxf = np.zeros((N, L, d), dtype=F32)

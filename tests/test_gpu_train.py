@@ -116,3 +116,32 @@ def test_packed_training_matches_dense(torch_mod):
         res.append((loss, feat.cpu().numpy(), m.grads.cpu().numpy()))
     assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1])
     assert rel_l2(res[0][2], res[1][2]) < 1e-5
+
+
+def test_normalize_fare_vs_reference_fixture(torch_mod, golden_dir):
+    """--normalize_fare (utils_AT.py:296,319): normalised training features, the loss on them and every gradient against
+    tests/golden/tiny_normfare.npz (the reference's encode_text(normalize=True) + torch.autograd)."""
+    from leaf_amd.model import create_model
+    z = np.load(os.path.join(golden_dir, "tiny_normfare.npz"))
+    m = create_model("tiny-test-quickgelu", seed=12, trainable=True)
+    feat = m.forward_train(z["tokens"], normalize=True)
+    assert rel_l2(feat.cpu().numpy(), z["feat"]) < 2e-3
+    assert np.array_equal(feat.cpu().numpy(), m.encode_text(z["tokens"], normalize=True).cpu().numpy())
+    m.zero_grad()
+    loss = m.backward(feat, torch_mod.from_numpy(z["anchor"]).cuda())
+    torch_mod.cuda.synchronize()
+    assert abs(float(loss) - float(z["loss"])) < 3e-3 * float(z["loss"])
+    worst = 0.0
+    for k, (off, shape) in m.layout.items():
+        g = m.grads[off: off + int(np.prod(shape))].view(shape).cpu().numpy()
+        if k == "token_embedding.weight":
+            r = rel_l2(g[z["tok_rows"]], z["g_tok_rows"])
+        elif "g:" + k in z.files:
+            r = rel_l2(g, z["g:" + k])
+        else:
+            continue
+        worst = max(worst, r)
+        assert r < 1.0e-2, (k, r)
+    print(f"normalize_fare: worst gradient rel-L2 {worst:.2e}")
+    feat2 = m.forward_train(z["tokens"])                  # switching back gives the un-normalised features again
+    assert rel_l2(feat2.cpu().numpy() / np.linalg.norm(feat2.cpu().numpy(), axis=-1, keepdims=True), z["feat"]) < 2e-3

@@ -124,3 +124,18 @@ def test_embedding_pgd_matches_reference_pieces(golden_dir):
             # the update itself, from the fixture's own gradient (sign() of a near-zero component may differ otherwise)
             nxt = O.pgd_step(delta, z[f"{norm}_grad{k}"], alpha, eps, norm)
             assert np.abs(nxt - z[f"{norm}_delta{k + 1}"]).max() < 1e-6
+
+
+def test_normalize_fare_matches_reference(golden_dir):
+    """--normalize_fare (utils_AT.py:296,319): loss on L2-normalised features and every gradient against the fixture the
+    reference's encode_text(normalize=True) + torch.autograd produced (tests/golden/make_golden_normfare.py)."""
+    z = np.load(os.path.join(golden_dir, "tiny_normfare.npz"))
+    cfg = O.TextCfg(128, 2, 2, 64, quick_gelu=True)
+    w = O.init_weights(cfg, seed=12)
+    loss, feat, g = O.encode_text_backward(w, cfg, z["tokens"], z["anchor"], normalize=True)
+    assert rel_l2(feat, z["feat"]) < 5e-6
+    assert abs(loss - float(z["loss"])) < 1e-5 * float(z["loss"])
+    for k in z.files:
+        if k.startswith("g:"):
+            assert rel_l2(g[k[2:]], z[k]) < 2e-4, k
+    assert rel_l2(g["token_embedding.weight"][z["tok_rows"]], z["g_tok_rows"]) < 2e-4
