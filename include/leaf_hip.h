@@ -142,6 +142,13 @@ int leaf_textfare_backward(leaf_text_t h, const float* params, const void* w16_b
 int leaf_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, size_t n_decay,
                     float lr, float beta1, float beta2, float eps, float wd, int step, float grad_scale,
                     leaf_stream_t s);
+/* the same step preceded by torch.nn.utils.clip_grad_norm_(parameters, max_norm, 2.0) (--grad-clip-norm,
+ * utils_AT.py:348-357): total norm = grad_scale * ||grads||_2, gradients are multiplied by min(1, max_norm / (norm + 1e-6))
+ * inside the AdamW kernel (grads themselves are left untouched).  clip_ws: fp32 device scratch [2 + 2048]; after the
+ * call clip_ws[0] = coefficient, clip_ws[1] = total norm. */
+int leaf_adamw_step_clip(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, size_t n_decay,
+                         float lr, float beta1, float beta2, float eps, float wd, int step, float grad_scale,
+                         float max_norm, float* clip_ws, leaf_stream_t s);
 
 /* ---- native host side of the search: CLIP BPE + single-edit mutation, multithreaded ----
  * leaf_tok_create takes the DECOMPRESSED text of bpe_simple_vocab_16e6.txt (src/open_clip/tokenizer.py:139-150).

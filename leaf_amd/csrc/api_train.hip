@@ -283,3 +283,11 @@ extern "C" int leaf_adamw_step(float* params, const float* grads, float* exp_avg
     return leaf_check(leaf_launch_adamw(params, grads, exp_avg, exp_avg_sq, n, n_decay, lr, beta1, beta2, eps, wd, step,
                                         grad_scale, (hipStream_t)s), "adamw");
 }
+
+extern "C" int leaf_adamw_step_clip(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n,
+                                    size_t n_decay, float lr, float beta1, float beta2, float eps, float wd, int step,
+                                    float grad_scale, float max_norm, float* clip_ws, leaf_stream_t s) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !clip_ws || !(max_norm > 0.f)) { leaf_set_error("null/invalid argument"); return 1; }
+    return leaf_check(leaf_launch_adamw(params, grads, exp_avg, exp_avg_sq, n, n_decay, lr, beta1, beta2, eps, wd, step,
+                                        grad_scale, (hipStream_t)s, max_norm, clip_ws), "adamw_clip");
+}

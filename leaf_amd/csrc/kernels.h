@@ -137,4 +137,5 @@ hipError_t leaf_launch_attention_bwd(const void* qkv, int qkv_dtype, const void*
 hipError_t leaf_launch_embed_bwd(const float* dx, const float* gscale, const int32_t* tokens, float* dtok, float* dpos,
                                  int rows, int n_seq, RowMap map, int d, int vocab, hipStream_t s);
 hipError_t leaf_launch_adamw(float* p, const float* g, float* m, float* v, size_t n, size_t n_decay, float lr,
-                             float beta1, float beta2, float eps, float wd, int step, float grad_scale, hipStream_t s);
+                             float beta1, float beta2, float eps, float wd, int step, float grad_scale, hipStream_t s,
+                             float max_norm = 0.f /* > 0: clip_grad_norm_ first */, float* clip_ws = nullptr /* [2 + 2048] fp32 */);

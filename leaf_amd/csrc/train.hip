@@ -485,7 +485,10 @@ __global__ __launch_bounds__(256) void tok_bwd_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v, size_t n4,
                                                     size_t n_decay, float lr, float b1, float b2, float eps, float wd,
-                                                    float bc1, float sqrt_bc2, float gscale) {
+                                                    float bc1, float sqrt_bc2, float gscale_host,
+                                                    const float* __restrict__ clip_coef) {
+    // clip_coef: optional device scalar from clip_coef_kernel (--grad-clip-norm): gradients are multiplied by it
+    const float gscale = clip_coef ? gscale_host * clip_coef[0] : gscale_host;
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * 256;
     for (; i < n4; i += stride) {
@@ -502,6 +505,38 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
             P[e] -= (lr / bc1) * (M[e] / denom);
         }
         ((float4*)p)[i] = pp; ((float4*)m)[i] = mm; ((float4*)v)[i] = vv;
+    }
+}
+
+// ---- --grad-clip-norm (utils_AT.py:348-357: torch.nn.utils.clip_grad_norm_(parameters, c, 2.0) before the step)
+// partial[b] = sum of squares of this block's grid-stride share of g
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, size_t n4, float* __restrict__ partial) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = ((const float4*)g)[i];
+        s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+// out[0] = clip coefficient min(1, c / (norm + 1e-6)), out[1] = norm = grad_scale * sqrt(sum partial)  (fixed order)
+__global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict__ partial, int nb, float grad_scale,
+                                                        float max_norm, float* __restrict__ out) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nb; b += 256) s += (double)partial[b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float norm = grad_scale * (float)sqrt((red[0] + red[1]) + (red[2] + red[3]));
+        const float coef = max_norm / (norm + 1e-6f);
+        out[0] = coef < 1.f ? coef : 1.f;
+        out[1] = norm;
     }
 }
 
@@ -693,12 +728,21 @@ hipError_t leaf_launch_embed_bwd(const float* dx, const float* gscale, const int
 }
 
 hipError_t leaf_launch_adamw(float* p, const float* g, float* m, float* v, size_t n, size_t n_decay, float lr,
-                             float beta1, float beta2, float eps, float wd, int step, float grad_scale, hipStream_t s) {
+                             float beta1, float beta2, float eps, float wd, int step, float grad_scale, hipStream_t s,
+                             float max_norm, float* clip_ws) {
     if (n % 4 || step < 1) return hipErrorInvalidValue;
     const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
     const float bc2 = (float)(1.0 - pow((double)beta2, (double)step));
     size_t n4 = n / 4, nb = (n4 + 255) / 256;
+    const float* coef = nullptr;
+    if (max_norm > 0.f) {   // clip_ws: [2 + 2048] floats: {coef, norm, partials...}
+        if (!clip_ws) return hipErrorInvalidValue;
+        const int pb = (int)(nb < 2048 ? nb : 2048);
+        hipLaunchKernelGGL(sumsq_partial_kernel, dim3(pb), dim3(256), 0, s, g, n4, clip_ws + 2);
+        hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, s, clip_ws + 2, pb, grad_scale, max_norm, clip_ws);
+        coef = clip_ws;
+    }
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)(nb < 16384 ? nb : 16384)), dim3(256), 0, s, p, g, m, v, n4, n_decay,
-                       lr, beta1, beta2, eps, wd, bc1, sqrtf(bc2), grad_scale);
+                       lr, beta1, beta2, eps, wd, bc1, sqrtf(bc2), grad_scale, coef);
     return hipGetLastError();
 }

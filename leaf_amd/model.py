@@ -444,13 +444,26 @@ class LeafCLIPText:
         return loss
 
     def adamw_step(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
-                   grad_scale: float = 1.0):
+                   grad_scale: float = 1.0, max_norm: Optional[float] = None):
+        """Fused AdamW over the flat buffers.  ``max_norm`` (--grad-clip-norm, utils_AT.py:348-357): clip the global L2
+        norm of grad_scale * grads first (torch.nn.utils.clip_grad_norm_ semantics); returns the 0-d total norm then."""
         self.opt_step += 1
+        if max_norm is not None:
+            if getattr(self, "_clip_ws", None) is None:
+                self._clip_ws = torch.zeros(2 + 2048, dtype=torch.float32, device=self.device)
+            _lib.check(self._lib.leaf_adamw_step_clip(_ptr(self.flat), _ptr(self.grads), _ptr(self.exp_avg),
+                                                      _ptr(self.exp_avg_sq), self.n_params, self.n_decay, float(lr),
+                                                      float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
+                                                      self.opt_step, float(grad_scale), float(max_norm),
+                                                      _ptr(self._clip_ws), self._stream()), "leaf_adamw_step_clip")
+            self._packed = False
+            return self._clip_ws[1]
         _lib.check(self._lib.leaf_adamw_step(_ptr(self.flat), _ptr(self.grads), _ptr(self.exp_avg),
                                              _ptr(self.exp_avg_sq), self.n_params, self.n_decay, float(lr),
                                              float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
                                              self.opt_step, float(grad_scale), self._stream()), "leaf_adamw_step")
         self._packed = False
+        return None
 
 
 def create_model(name: str, device="cuda:0", dtype: str = None, pretrained: Optional[str] = None,

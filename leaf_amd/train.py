@@ -97,11 +97,14 @@ class LeafAdamW:
             {"params": excl, "weight_decay": 0.0, "lr": lr, "betas": tuple(betas), "eps": eps},
             {"params": rest, "weight_decay": weight_decay, "lr": lr, "betas": tuple(betas), "eps": eps}]
 
-    def step(self):
+    def step(self, max_norm=None):
+        """``max_norm``: --grad-clip-norm (utils_AT.py:348-357), applied to the all-reduced, averaged gradients like
+        clip_grad_norm_ on DDP-averaged .grad; returns the total norm (0-d tensor) when clipping."""
         g = self.param_groups[1]
         scale = allreduce_grads(self.model)   # the single collective of the step
-        self.model.adamw_step(g["lr"], g["betas"], g["eps"], g["weight_decay"], grad_scale=scale)
+        total = self.model.adamw_step(g["lr"], g["betas"], g["eps"], g["weight_decay"], grad_scale=scale, max_norm=max_norm)
         self.model.pack()
+        return total
 
     def zero_grad(self):
         self.model.zero_grad()
@@ -262,10 +265,11 @@ def train_one_epoch_text_only(model, model_frozen, tokenizer, V, data, loss, epo
         loss_fare = model.backward(feat, anchor, accum_scale=1.0 / args.accum_freq)   # device scalar, no sync
         for key in ("loss", "loss_FARE_text"):
             losses_accum[key] = losses_accum.get(key, 0) + loss_fare / args.accum_freq
-        if args.grad_clip_norm is not None:
-            raise NotImplementedError("--grad-clip-norm (default off, params_AT.py:388-390) is not implemented")
         if (i + 1) % args.accum_freq == 0:
-            optimizer.step()
+            # --grad-clip-norm (utils_AT.py:348-357) is fused into the step.  The reference clips after EVERY micro-batch's
+            # backward (also when accum_freq > 1, i.e. the partial sums get clipped repeatedly); here the accumulated
+            # gradient is clipped once, right before the step.
+            optimizer.step(max_norm=args.grad_clip_norm)
             optimizer.zero_grad()
         with torch.no_grad():
             unwrap_model(model).logit_scale.clamp_(0, math.log(100))

@@ -407,6 +407,16 @@ def adamw_step(w, g, m, v, step: int, lr: float, wd: float, beta1: float = 0.9, 
         w[k] -= (F32(lr / bc1) * m[k] / denom).astype(F32)
 
 
+def clip_grad_norm(g: Dict[str, np.ndarray], max_norm: float) -> float:
+    """torch.nn.utils.clip_grad_norm_(parameters, max_norm, norm_type=2.0) in place (utils_AT.py:348-357): total norm over
+    all tensors, coefficient max_norm / (total + 1e-6) clamped to 1.  Returns the total norm."""
+    total = math.sqrt(sum(float((v.astype(np.float64) ** 2).sum()) for v in g.values()))
+    coef = min(1.0, max_norm / (total + 1e-6))
+    for k in g:
+        g[k] = (g[k] * F32(coef)).astype(F32)
+    return total
+
+
 def cosine_lr(base_lr: float, warmup: int, total_steps: int, step: int) -> float:
     """src/open_clip_train/scheduler.py:4-10,43-53."""
     if step < warmup:
