@@ -56,3 +56,20 @@ def test_eval_textfare_script(tmp_path, monkeypatch):
     assert all(r["textfare_adv"] >= 0.0 for r in rows) and any(r["textfare_adv"] > 0.0 for r in rows)
     out = list((tmp_path / "results_textfare").glob("*_leaf_k2_rho_12.csv"))
     assert len(out) == 1 and out[0].read_text().splitlines()[0] == "sentence,adv_sentence,textfare_clean,textfare_adv"
+
+
+def test_train_cli_normalize_fare_and_grad_clip(tmp_path, monkeypatch):
+    """The two optional flags of the reference trainer that change the training arithmetic (--normalize_fare,
+    utils_AT.py:296,319; --grad-clip-norm, utils_AT.py:348-357) run end to end and bound the loss / keep it finite."""
+    import train_AT_text_only as cli
+    monkeypatch.chdir(tmp_path)
+    args = ["--model", "tiny-test-quickgelu", "--dataset-type", "synthetic", "--train-num-samples", "16", "--batch-size", "8",
+            "--lr", "1e-4", "--wd", "1e-4", "--warmup", "2", "--rho", "6", "--k_adv", "1", "--seed", "2", "--epochs", "1",
+            "--custom_out_folder", "n_", "--logs", str(tmp_path / "logs"), "--name", "runn",
+            "--normalize_fare", "--grad-clip-norm", "1.0"]
+    assert cli.main(args) == 0
+    out = tmp_path / "results" / "n_text_only_k1_rho6_seed2"
+    rows = open(out / "results.csv").read().strip().splitlines()
+    hdr, vals = rows[0].split(","), rows[1].split(",")
+    loss = float(vals[hdr.index("loss")])
+    assert np.isfinite(loss) and 0.0 <= loss <= 4.0        # squared distance of two unit vectors
