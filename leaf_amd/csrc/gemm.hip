@@ -1,4 +1,6 @@
 // NT GEMM on MFMA for the text tower:  C[M,N] (+)= A[M,K] * B[N,K]^T, 16-bit operands, fp32 accumulate.
+// This file: the first (register-staged) kernel, the two-stage 256^2 kernel and the DISPATCH over all GEMM kernels
+// (leaf_launch_gemm at the end: gemm256h.hip for >= 128 tiles of 256^2, gemm64.hip for small launches, these otherwise).
 //
 // Both operands are K-contiguous (nn.Linear weight layout [N,K]; activations [rows,K]), which is the
 // natural fragment shape of v_mfma_f32_16x16x32_{f16,bf16}: lane l holds 8 consecutive k of row l&15.

@@ -1,4 +1,5 @@
-// NT GEMM, 256x256 output tile, 4-stage LDS-DMA ring -- the kernel the text tower's big GEMMs run on.
+// NT GEMM, 256x256 output tile, 4-stage LDS-DMA ring -- the second-generation kernel (LEAF_GEMM_V=2); the default for
+// the text tower's big GEMMs is now the half-stage ring of gemm256h.hip, which grew out of this one.
 //
 //   C[M,N] (+)= A[M,K] * B[N,K]^T      16-bit operands (fp16 / bf16), fp32 accumulate, fused epilogues
 //
