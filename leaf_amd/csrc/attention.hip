@@ -113,9 +113,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const u16* __restrict__ q
                 a = TT::mfma(kf[kt][1], qf1, a);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int kidx = kt * 16 + 4 * g + e;
                     float s = a[e] * 0.125f;
-                    s = kidx > qv ? -INFINITY : s;
+                    // causal mask: key tiles below the diagonal tile hold only keys < every query of this tile (a clamped
+                    // query row qv >= ctx - 1 >= those keys as well), so only the diagonal tile needs the compare
+                    if (kt == qt) s = (kt * 16 + 4 * g + e) > qv ? -INFINITY : s;
                     a[e] = s;
                     m = __builtin_fmaxf(m, s);
                 }
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const u16* __restrict__ q
             for (int kt = 0; kt < MAXT; ++kt) {
                 if (kt <= qt) {
                     const s16x4 pf = __builtin_bit_cast(
-                        s16x4, pack4<TT>(sc[kt][0] * inv, sc[kt][1] * inv, sc[kt][2] * inv, sc[kt][3] * inv));
+                        s16x4, pack4_bounded<TT>(sc[kt][0] * inv, sc[kt][1] * inv, sc[kt][2] * inv, sc[kt][3] * inv));
 #pragma unroll
                     for (int dt = 0; dt < 4; ++dt)
                         o[dt] = TT::mfma16(load_vt_frag<USE_TR>(vlds, kt * 16, dt * 16, lane), pf, o[dt]);
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const u16* __restrict__ q
                 u16* op = out + (eot >= 0 ? (size_t)n : (size_t)row_s + qidx - pfx) * d + h * HD + 4 * g;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt)
-                    *(uint2*)(op + dt * 16) = pack4<TT>(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
+                    *(uint2*)(op + dt * 16) = pack4_bounded<TT>(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
             }
         }
     }

@@ -51,6 +51,14 @@ __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
     v[0] = TT::from_f32(a); v[1] = TT::from_f32(b); v[2] = TT::from_f32(c); v[3] = TT::from_f32(d);
     return __builtin_bit_cast(uint2, v);
 }
+// pack4 without the fp16 saturation clamp, for values whose magnitude is bounded by construction (softmax
+// probabilities; attention outputs = convex combinations of 16-bit V values): one v_med3 less per element
+template <class TT>
+__device__ __forceinline__ uint2 pack4_bounded(float a, float b, float c, float d) {
+    typename TT::vec4 v;
+    v[0] = (typename TT::elem)a; v[1] = (typename TT::elem)b; v[2] = (typename TT::elem)c; v[3] = (typename TT::elem)d;
+    return __builtin_bit_cast(uint2, v);
+}
 template <class TT>
 __device__ __forceinline__ void unpack4(uint2 u, float (&o)[4]) {
     typename TT::vec4 v = __builtin_bit_cast(typename TT::vec4, u);
