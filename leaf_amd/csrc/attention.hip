@@ -76,7 +76,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const u16* __restrict__ q
     const int qt1 = eot >= 0 ? eot >> 4 : nt - 1;
 
     // ---- V rows -> LDS (row-major), rows ctx..vrows-1 zero
-    for (int idx = lane; idx < vrows * 8; idx += 64) {
+    // rows beyond the sequence's own last 16-row tile are never read (key tiles kt <= qt < nt)
+    for (int idx = lane; idx < nt * 16 * 8; idx += 64) {
         const int key = idx >> 3, ch = idx & 7;
         uint4 v = uint4{0u, 0u, 0u, 0u};
         if (key < ctx) v = *(const uint4*)(rowptr(key) + 2 * d + ch * 8);
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const u16* __restrict__ q
                 a = TT::mfma(kf[kt][1], qf1, a);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float s = a[e] * 0.125f;
+                    float s = a[e] * 0.18033688011112042f;   // 1/sqrt(64) * log2(e): the softmax below runs in base 2
                     // causal mask: key tiles below the diagonal tile hold only keys < every query of this tile (a clamped
                     // query row qv >= ctx - 1 >= those keys as well), so only the diagonal tile needs the compare
                     if (kt == qt) s = (kt * 16 + 4 * g + e) > qv ? -INFINITY : s;
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const u16* __restrict__ q
             for (int kt = 0; kt <= qt; ++kt)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float p = __expf(sc[kt][e] - m);
+                    float p = __builtin_amdgcn_exp2f(sc[kt][e] - m);
                     sc[kt][e] = p;
                     sum += p;
                 }
