@@ -292,8 +292,9 @@ int forward_chunk(const leaf_text* h, const float* P, const uint16_t* W, const i
     if (out && leaf_project_rows_ok(d, c.embed_dim)) {
         // same op sequence as the trimmed path (bit-identical features): gather the pooled rows, LN, fp32 projection.
         // qkv / fc scratch is dead here.
-        float* xg = (float*)b.qkv;
-        float* xn = (float*)((char*)b.qkv + align_up((size_t)cs * d * 4, 256));
+        // scratch in the chunk's OWN qkv / fc buffers (b_in): with kv.kv_write, b.qkv points into the caller's K/V cache
+        float* xg = (float*)b_in.qkv;
+        float* xn = (float*)((char*)b_in.qkv + align_up((size_t)cs * d * 4, 256));
         LEAF_TRY(leaf_launch_eot_positions(tokens, b.eot, cs, map, s));
         LEAF_TRY(leaf_launch_gather_rows(b.x, b.eot, xg, cs, map, d, s));
         LEAF_TRY(leaf_launch_project_rows(xg, P + h->lnf_w, P + h->lnf_b, c.ln_eps, P + h->text_proj, xn, out, cs, d,

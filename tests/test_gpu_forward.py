@@ -276,3 +276,8 @@ def test_prefix_reuse_is_bit_exact_across_kernels(torch_mod):
     kv = m.encode_text_kv(base)
     i1, f1, l1 = m.score_candidates(flat, anchor, rho, "l2", want_loss=True, seq_lens=lens, prefix_lens=pl.reshape(-1), kv=kv)
     assert torch_mod.equal(l0, l1) and torch_mod.equal(i0, i1) and torch_mod.equal(f0, f1)
+    # the cache pass can also return the captions' features; its final projection must not touch the cache
+    kv2, feats = m.encode_text_kv(base, want_features=True)
+    assert torch_mod.equal(feats, m.encode_text(base))
+    i2, f2, l2 = m.score_candidates(flat, anchor, rho, "l2", want_loss=True, seq_lens=lens, prefix_lens=pl.reshape(-1), kv=kv2)
+    assert torch_mod.equal(l0, l2) and torch_mod.equal(i0, i2) and torch_mod.equal(f0, f2)
