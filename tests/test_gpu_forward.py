@@ -281,3 +281,37 @@ def test_prefix_reuse_is_bit_exact_across_kernels(torch_mod):
     assert torch_mod.equal(feats, m.encode_text(base))
     i2, f2, l2 = m.score_candidates(flat, anchor, rho, "l2", want_loss=True, seq_lens=lens, prefix_lens=pl.reshape(-1), kv=kv2)
     assert torch_mod.equal(l0, l2) and torch_mod.equal(i0, i2) and torch_mod.equal(f0, f2)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_random_shapes_dense_packed_prefix_agree(torch_mod, seed):
+    """Randomised edge cases on the tiny config: captions of every length up to the full 77 tokens (EOT in the last
+    position), one-token captions, odd B and rho, edits at the first and last token: the dense, the EOT-trimmed and the
+    prefix-reuse computation must give bit-identical losses, winners and features."""
+    rng = np.random.default_rng(100 + seed)
+    m = _model("tiny-test-quickgelu", 12)
+    B, rho = int(rng.integers(3, 8)), int(rng.integers(5, 12))
+    base = np.concatenate([O.synthetic_tokens(B - 2, seed=200 + seed, min_len=0, max_len=75),
+                           O.synthetic_tokens(1, seed=300 + seed, min_len=75, max_len=75),      # EOT at position 76
+                           O.synthetic_tokens(1, seed=400 + seed, min_len=0, max_len=0)], 0)    # SOT, EOT only
+    lens = base.argmax(-1) + 1
+    cand = np.repeat(base[:, None, :], rho, axis=1)
+    for b in range(B):
+        for r in range(rho):
+            if lens[b] > 2 and r % 4 != 3:                       # every 4th candidate stays a no-op
+                p = 1 if r == 0 else (lens[b] - 2 if r == 1 else int(rng.integers(1, lens[b] - 1)))
+                cand[b, r, p] = int(rng.integers(1, 49405))
+    flat = cand.reshape(-1, 77)
+    neq = cand != base[:, None, :]
+    pl = neq.argmax(-1)
+    pl[~neq.any(-1)] = 77
+    anchor = m.encode_text(base) + 0.3
+    cl = np.repeat(lens, rho)
+    m.trim_rows = False
+    i0, f0, l0 = m.score_candidates(flat, anchor, rho, "l2", want_loss=True)
+    m.trim_rows = True
+    i1, f1, l1 = m.score_candidates(flat, anchor, rho, "l2", want_loss=True, seq_lens=cl)
+    kv = m.encode_text_kv(base)
+    i2, f2, l2 = m.score_candidates(flat, anchor, rho, "l2", want_loss=True, seq_lens=cl, prefix_lens=pl.reshape(-1), kv=kv)
+    assert torch_mod.equal(l0, l1) and torch_mod.equal(i0, i1) and torch_mod.equal(f0, f1)
+    assert torch_mod.equal(l0, l2) and torch_mod.equal(i0, i2) and torch_mod.equal(f0, f2)
