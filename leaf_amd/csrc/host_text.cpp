@@ -66,6 +66,9 @@ const std::string END = "</w>";
 
 const std::vector<int32_t>& bpe_word(Tok& tk, std::unordered_map<std::string, std::vector<int32_t>>& cache,
                                      const std::string& word) {
+    // The search feeds millions of one-off mutated words through here (12,800 candidates per step); the reference's
+    // Python cache grows without bound, this one is dropped when it gets large (callers hold no reference across calls).
+    if (cache.size() > (size_t)1 << 19) cache.clear();
     auto it = cache.find(word);
     if (it != cache.end()) return it->second;
     std::vector<std::string> parts;
