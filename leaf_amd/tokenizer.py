@@ -100,6 +100,8 @@ class SimpleTokenizer:
                     i += 1
             parts = merged
         ids = tuple(self.encoder[p] for p in parts)
+        if len(self._word_cache) > (1 << 20):      # the search produces millions of one-off mutated words: keep it bounded
+            self._word_cache = {"<start_of_text>": (self.sot_token_id,), "<end_of_text>": (self.eot_token_id,)}
         self._word_cache[word] = ids
         return ids
 
