@@ -106,6 +106,10 @@ def main():
     dev = torch.device("cuda", local)
     use_dist = world > 1 or os.environ.get("LEAF_BENCH_FORCE_DIST") == "1"   # the latter rehearses the RCCL path on 1 GPU
     if use_dist:
+        # the image exports NCCL_DEBUG=VERSION, which makes RCCL print a version banner on STDOUT in front of the one JSON
+        # line this script owes its caller; keep stdout clean (any other NCCL_DEBUG setting is respected)
+        if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+            del os.environ["NCCL_DEBUG"]
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
