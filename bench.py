@@ -5,18 +5,28 @@ One "step" = anchor forward [B,77] + 2k x score_candidates([B*rho,77]) + train f
 loss on [B,77] + (flat RCCL all-reduce) + AdamW + weight re-pack, on synthetic token ids resident in HBM.
 value = B * world / step_time  (adversarial text samples/s; the reference's own formula, utils_AT.py:390).
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py                               # 1 GPU, default steps / warmup
+    python bench.py --gpus 2 --steps 50           # starts 2 ranks itself (torch.distributed.run, RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W    # the driver's form: runs as launched
 
-Prints ONE JSON line on rank 0 (fields: see the task contract; plus `roofline` for the dominant GEMM kernel timed
-live with HIP events around every launch on its stream, `cpu_baseline` = the numpy oracle timed on the host cores
-for a bounded sample of the same workload, and `step_mfma_frac` = whole-step algorithmic FLOP/s / dense peak).
+Prints ONE JSON line on rank 0: the task contract's fields, plus
+  roofline      the dominant GEMM kernel, timed live with HIP events around every launch on its own stream
+                (leaf_prof_*), and `shapes`: the same figures per GEMM shape (N, K) of every kernel family;
+  cpu_baseline  a plain PyTorch-CPU fp32 harness of the same step (oracle/torch_cpu_harness.py) on BASELINE.json
+                configs[0] (B = 8), bounded in time, all usable host cores (rank 0, N = 1 only);
+  dense         samples/s of the same step with every exact work-skipping switched off (a few steps, after the timed region);
+  step_exec_frac    executed GEMM FLOP/s of the whole step / dense 16-bit MFMA peak  (the honest step-level fraction);
+  dense_equiv_frac  samples/s x dense algorithmic FLOPs per sample / peak (SURVEY.md 8d's prescription; exceeds the
+                    executed fraction by the factor exact work skipping removes).
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,10 +34,21 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS_16BIT = 2500.0  # MI355X dense bf16/fp16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
-FAMILY = {0: "gemm_nt_kernel", 1: "gemm_nt256_kernel", 2: "gemm_nt256_ring_kernel", 3: "gemm_nt256_persist_kernel",
-          4: "gemm_nt256_half_kernel", 5: "gemm_nt256_halfp_kernel",
-          6: "gemm_nt64_ring_kernel"}
-EPI_NAMES = {0: "store16(qkv)", 1: "act16(c_fc)", 2: "resid32(out_proj+c_proj)", 3: "store32(wgrad/dgrad)", 4: "actgrad16"}
+PEAK_HBM_GBS = 8000.0       # HBM3E spec peak (same table; ~6.3 TB/s achievable)
+FAMILY = {0: "gemm_nt_kernel", 4: "gemm_nt256_half_kernel", 6: "gemm_nt64_ring_kernel"}
+EPI_NAMES = {0: "store16", 1: "act16", 2: "resid32", 3: "store32", 4: "actgrad16", 5: "lnfold16", 6: "lnfold_act16", 7: "resid32+x16+stats"}
+
+
+def kernel_sources_hash():
+    """sha256 over the GEMM kernel sources: a traffic summary under profiles/ is only attached to a line produced by the
+    same kernels."""
+    h = hashlib.sha256()
+    for f in ("gemm256h.hip", "gemm64.hip", "gemm.hip", "gemm_epilogue.h", "common.h"):
+        p = os.path.join(ROOT, "leaf_amd", "csrc", f)
+        if os.path.exists(p):
+            with open(p, "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def fwd_flops_per_seq(cfg, L=77):
@@ -35,53 +56,83 @@ def fwd_flops_per_seq(cfg, L=77):
     return cfg.layers * (24 * cfg.width ** 2 * L + 4 * L * L * cfg.width)
 
 
-def cpu_baseline(model_name, rho, k, b_cpu, seed):
-    """The numpy oracle (kind "port") running the same step on b_cpu captions; all host cores via OpenBLAS."""
-    import numpy as np
+def cpu_baseline(model_name, rho, k, b_cpu, seed, budget_s):
+    """Plain PyTorch-CPU fp32 harness (own code, oracle/torch_cpu_harness.py) of the same step, dense, all usable cores."""
     from oracle import text_oracle as O
+    from oracle import torch_cpu_harness as H
     cfg = O.CONFIGS[model_name]
     w = O.init_weights(cfg, seed=1)
     base = O.synthetic_tokens(b_cpu, seed=seed)
-    t0 = time.time()
-    anchor = O.encode_text(w, cfg, base)
-    cur = base
-    for _ in range(k):
-        cand = O.synthetic_candidates(cur, rho, seed=seed + 1)
-        idx, _, _ = O.score_candidates(w, cfg, cand, anchor, chunk=50)
-        pos = np.array([int(np.nonzero(cand[b, idx[b]] != cur[b])[0][0]) if np.any(cand[b, idx[b]] != cur[b]) else 1
-                        for b in range(b_cpu)])
-        cand = O.synthetic_candidates(cur, rho, seed=seed + 2, fixed_pos=pos)
-        idx, _, _ = O.score_candidates(w, cfg, cand, anchor, chunk=50)
-        cur = cand[np.arange(b_cpu), idx]
-    loss, _, g = O.encode_text_backward(w, cfg, cur, anchor)
-    m = {kk: np.zeros_like(v) for kk, v in w.items()}
-    v = {kk: np.zeros_like(vv) for kk, vv in w.items()}
-    O.adamw_step(w, g, m, v, 1, 1e-5, 1e-4)
-    dt = time.time() - t0
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        cores = os.cpu_count() or 1
-    return {"value": b_cpu / dt, "unit": "samples/s", "cores": int(cores), "kind": "port",
-            "sample": f"numpy fp32 oracle, one full step on B={b_cpu} captions (rho={rho}, k={k}: "
-                      f"{2 * rho * k * b_cpu} candidate forwards + anchor + train fwd/bwd + AdamW), {dt:.1f} s"}
+    r = H.time_step(w, cfg, base, lambda cur, rho_, s, pos: O.synthetic_candidates(cur, rho_, s, fixed_pos=pos), rho, k,
+                    budget_s=budget_s)
+    return {"value": r["samples_per_s"], "unit": "samples/s", "cores": r["cores"], "kind": "port",
+            "impl": "own harness: plain PyTorch CPU fp32 (torch.nn.functional ops), dense 77-row sequences",
+            "sample": (f"BASELINE.json configs[0] shape: one step on B={b_cpu} captions, rho={rho}, k={k}: anchor + "
+                       f"{r['total_candidate_forwards']} candidate forwards ({r['measured_candidate_forwards']} measured at "
+                       f"{r['seq_per_s']:.1f} seq/s{', rest extrapolated' if r['extrapolated'] else ''}) + train fwd/bwd + AdamW "
+                       f"({r['t_train_s']:.1f} s); {r['wall_s']:.1f} s of CPU time spent")}
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """--gpus N > 1 from a bare shell: start N fresh ranks with torch.distributed.run.  This parent has not touched the
+    GPU (no torch.cuda call, nothing imported that initialises HIP); it only waits and forwards the children's output."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args):
+    """Launcher / rendezvous rehearsal without a GPU (tests/test_bench_launch.py): gloo process group, one all-reduce,
+    the same one-JSON-line contract with n_ranks_seen."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if world > 1:
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)])
+    seen = 1
+    if world > 1:
+        dist.all_reduce(t)
+        seen = dist.get_world_size()
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "adversarial text samples/sec", "value": 0.0, "unit": "samples/s", "n_gpus": args.gpus,
+                          "n_ranks_seen": seen, "dry": True, "backend": args.backend, "allreduce_sum": float(t.item()),
+                          "steps": args.steps, "warmup": args.warmup}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--model", default=os.environ.get("LEAF_BENCH_MODEL", "ViT-L-14-quickgelu"))
     ap.add_argument("--batch", type=int, default=int(os.environ.get("LEAF_BENCH_BATCH", "128")))
     ap.add_argument("--rho", type=int, default=50)
     ap.add_argument("--k-adv", type=int, default=int(os.environ.get("LEAF_BENCH_K", "1")))
+    ap.add_argument("--accum-freq", type=int, default=1, help="micro-batches per optimizer step (configs[3]: --batch 32 --accum-freq 4)")
     ap.add_argument("--dtype", default=os.environ.get("LEAF_DTYPE", "fp16"), choices=["fp16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dense-leg", action="store_true")
     ap.add_argument("--dense", action="store_true", help="compute all 77 rows per sequence (no EOT trimming)")
     ap.add_argument("--no-prefix-reuse", action="store_true", help="recompute every kept row of every candidate")
-    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--dry", action="store_true", help="rendezvous rehearsal only (no GPU work); with --backend gloo runs on CPU")
     ap.add_argument("--attack", default="leaf", choices=["leaf", "pgd"],
                     help="leaf = the reference's character search (the BASELINE.json metric); pgd = the OPTIONAL embedding-space "
                          "PGD mode of SURVEY.md 8a row a12 (k-adv inner steps), which the reference's text trainer does not run")
@@ -90,6 +141,14 @@ def main():
     ap.add_argument("--pgd-norm", default="linf", choices=["linf", "l2"])
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args, sys.argv[1:]))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry:
+        return dry_run(args)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -97,11 +156,8 @@ def main():
     from leaf_amd.model import LeafCLIPText, create_model, get_config
     from leaf_amd.step import StepConfig, train_step_tokens
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or os.environ.get("LEAF_BENCH_FORCE_DIST") == "1"   # the latter rehearses the RCCL path on 1 GPU
@@ -113,6 +169,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    n_ranks_seen = dist.get_world_size() if use_dist else 1
 
     cfg = get_config(args.model)
     model = create_model(args.model, device=dev, dtype=args.dtype, seed=1, trainable=True)
@@ -120,7 +177,7 @@ def main():
     frozen.pack()
     model.pack()
     sc = StepConfig(rho=args.rho, k_adv=args.k_adv, lr=1e-5, wd=1e-4, attack=args.attack, pgd_eps=args.pgd_eps,
-                    pgd_alpha=args.pgd_alpha, pgd_norm=args.pgd_norm)
+                    pgd_alpha=args.pgd_alpha, pgd_norm=args.pgd_norm, accum_freq=args.accum_freq)
     # synthetic captions: SOT, U{8..40} ids, EOT, zero pad; a different shard per rank (seed + rank)
     g = torch.Generator().manual_seed(1234 + rank)
     B = args.batch
@@ -131,7 +188,8 @@ def main():
         base[i, 0] = cfg.vocab_size - 2
         base[i, 1:1 + n] = torch.randint(1, cfg.vocab_size - 2, (n,), generator=g, dtype=torch.int32)
         base[i, 1 + n] = cfg.vocab_size - 1
-    base_lens = None if args.dense else (lens.numpy().astype(np.int32) + 2)   # SOT + n ids + EOT rows are kept
+    lens_np = lens.numpy().astype(np.int32) + 2                       # SOT + n ids + EOT rows are kept
+    base_lens = None if args.dense else lens_np
     base = base.to(dev)
     base_ready = torch.cuda.Event()
     base_ready.record()
@@ -141,21 +199,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    step_id = 0
-    for _ in range(args.warmup):
-        train_step_tokens(model, frozen, base, sc, seed=step_id, base_lens=base_lens, prefix_reuse=not args.no_prefix_reuse,
-                          base_ready=base_ready)
-        step_id += 1
+    step_id = [0]
+
+    def run_steps(n, lens_arg, prefix):
+        loss = None
+        for _ in range(n):
+            loss = train_step_tokens(model, frozen, base, sc, seed=step_id[0], base_lens=lens_arg, prefix_reuse=prefix,
+                                     base_ready=base_ready, micro_index=step_id[0] % args.accum_freq)
+            step_id[0] += 1
+        return loss
+
+    run_steps(args.warmup, base_lens, not args.no_prefix_reuse)
     lib = _lib.lib()
     barrier()
     if rank == 0:
         lib.leaf_prof_begin()
     t0 = time.perf_counter()
-    loss = None
-    for _ in range(args.steps):
-        loss = train_step_tokens(model, frozen, base, sc, seed=step_id, base_lens=base_lens, prefix_reuse=not args.no_prefix_reuse,
-                          base_ready=base_ready)
-        step_id += 1
+    loss = run_steps(args.steps, base_lens, not args.no_prefix_reuse)
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -164,68 +224,107 @@ def main():
     dt = float(tmax.item())
 
     if rank == 0:
-        nk = 128
-        ms, fl, by, cnt = (C.c_double * nk)(), (C.c_double * nk)(), (C.c_double * nk)(), (C.c_int64 * nk)()
-        _lib.check(lib.leaf_prof_end(ms, fl, by, cnt, nk), "leaf_prof_end")
-        kinds = [(ms[i], fl[i], cnt[i], i) for i in range(nk) if cnt[i] > 0]
-        kinds.sort(reverse=True)
-        dom_ms, dom_fl, dom_cnt, dom_key = kinds[0]
-        dom_bytes = by[dom_key]
-        dt_code = 1 if args.dtype == "fp16" else 0
+        ng = 256
+        ms, fl, by = (C.c_double * ng)(), (C.c_double * ng)(), (C.c_double * ng)()
+        rows, info, n_out = (C.c_int64 * ng)(), (C.c_int32 * (4 * ng))(), C.c_int(0)
+        _lib.check(lib.leaf_prof_end_shapes(ms, fl, by, rows, info, ng, C.byref(n_out)), "leaf_prof_end_shapes")
+        shapes, per_key = [], {}
+        for i in range(n_out.value):
+            key, N, K, cnt = info[4 * i], info[4 * i + 1], info[4 * i + 2], info[4 * i + 3]
+            if ms[i] <= 0:
+                continue
+            kname = f"{FAMILY.get(key // 16, 'gemm?')}<{'F16' if (key // 8) % 2 == 1 else 'BF16'},{key % 8}>"
+            tf = fl[i] / (ms[i] * 1e-3) / 1e12
+            gbs = by[i] / (ms[i] * 1e-3) / 1e9
+            # which roofline bounds this shape: algorithmic FLOP per algorithmic byte against the machine balance
+            intensity = fl[i] / by[i]
+            bound = "hbm" if intensity < PEAK_TFLOPS_16BIT * 1e12 / (PEAK_HBM_GBS * 1e9) * 0.5 else "mfma"
+            shapes.append({"kernel": kname, "epilogue": EPI_NAMES.get(key % 8), "N": N, "K": K, "launches": cnt,
+                           "rows_per_launch": rows[i] / cnt, "ms_per_step": ms[i] / args.steps, "tflops": tf,
+                           "mfma_frac": tf / PEAK_TFLOPS_16BIT, "algorithmic_gbs": gbs, "hbm_frac": gbs / PEAK_HBM_GBS,
+                           "flop_per_byte": intensity, "bound": bound})
+            a = per_key.setdefault(key, [0.0, 0.0, 0.0, 0])
+            a[0] += ms[i]; a[1] += fl[i]; a[2] += by[i]; a[3] += cnt
+        shapes.sort(key=lambda s: -s["ms_per_step"])
+        dom_key = max(per_key, key=lambda k: per_key[k][0])
+        dom_ms, dom_fl, dom_bytes, dom_cnt = per_key[dom_key]
+        dom_name = f"{FAMILY.get(dom_key // 16, 'gemm?')}<{'F16' if (dom_key // 8) % 2 == 1 else 'BF16'},{dom_key % 8}>"
         achieved = dom_fl / (dom_ms * 1e-3) / 1e12
-        gemm_total_ms = sum(k[0] for k in kinds)
-        gemm_total_fl = sum(k[1] for k in kinds)
+        gemm_total_ms = sum(v[0] for v in per_key.values())
+        gemm_total_fl = sum(v[1] for v in per_key.values())
         F = fwd_flops_per_seq(cfg)
         # algorithmic cost per sample: LEAF search (2 rho k candidate forwards + anchor + train fwd + 2x bwd), or for the
         # optional embedding-space PGD mode k x (fwd + input-gradient bwd ~ 1 + 1) on top of anchor + start fwd + train bwd
         flops_per_sample = (2 * args.rho * args.k_adv + 4) * F if args.attack == "leaf" else (2 * args.k_adv + 4) * F
         value = B * world * args.steps / dt
-        traffic = None     # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/)
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+        traffic, traffic_note = None, "no PMC summary under profiles/ for this kernel build"
+        try:    # HBM bytes per launch of the dominant kernel from the committed PMC passes; only for the build they were taken on
+            with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as f:
                 tj = json.load(f)
-            if tj["kernel"] == f"{FAMILY[dom_key // 16]}<{'F16' if (dom_key // 8) % 2 == 1 else 'BF16'},{dom_key % 8}>" and not args.dense \
-                    and not args.no_prefix_reuse and args.model == "ViT-L-14-quickgelu" and B == 128:
+            default_cfg = not args.dense and not args.no_prefix_reuse and args.model == "ViT-L-14-quickgelu" and B == 128 \
+                and args.k_adv == 1 and args.attack == "leaf"
+            if tj.get("kernel") == dom_name and tj.get("kernel_sources_sha16") == kernel_sources_hash() and default_cfg:
                 traffic = tj["traffic_bytes_per_launch"]
-        except Exception:
+                traffic_note = ("HBM bytes per launch, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) * 1024, separate passes, "
+                                "profiles/r02_traffic.json (same kernel sources, sha16 " + tj["kernel_sources_sha16"] + ")")
+            elif tj.get("kernel_sources_sha16") != kernel_sources_hash():
+                traffic_note = "profiles/r02_traffic.json was taken on different kernel sources: not attached"
+        except (OSError, ValueError, KeyError):
             pass
         out = {
             "metric": "adversarial text samples/sec", "value": value, "unit": "samples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype + " MFMA operands, f32 accumulate", "data": "synthetic",
             "config": {"workload": (f"CLIP {args.model} text encoder, LEAF step k={args.k_adv} rho={args.rho}, "
-                                    f"B={B} per GPU, seq=77 (BASELINE.json configs[1])") if args.attack == "leaf" else
+                                    f"B={B} per GPU" + (f" x accum {args.accum_freq}" if args.accum_freq > 1 else "") +
+                                    f", seq=77 (BASELINE.json configs[1]; {args.dtype} operands run the MFMA at the bf16 rate -- "
+                                    "fp16's 11-bit significand is what meets the 1e-3 embedding tolerance)") if args.attack == "leaf" else
                                    (f"CLIP {args.model} text encoder, OPTIONAL embedding-space PGD mode (SURVEY 8a row a12, NOT "
                                     f"the reference's text attack): k={args.k_adv} steps, {args.pgd_norm} eps={args.pgd_eps} "
                                     f"alpha={args.pgd_alpha}, B={B} per GPU, seq=77"),
-                       "attack": args.attack,
+                       "attack": args.attack, "accum_freq": args.accum_freq,
                        "global_batch": B * world, "seq_len": cfg.context_length, "rho": args.rho, "k": args.k_adv,
                        "parallelism": f"dp{world}", "candidate_forwards_per_step_per_gpu": 2 * args.rho * args.k_adv * B},
             "roofline": {
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS_16BIT, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_TFLOPS_16BIT, "traffic": traffic,
-                "traffic_note": "HBM bytes per launch, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) * 1024, profiles/r01_traffic.json",
-                "kernel": f"{FAMILY[dom_key // 16]}<{'F16' if (dom_key // 8) % 2 == 1 else 'BF16'},{dom_key % 8}> {EPI_NAMES.get(dom_key % 8)}",
+                "frac": achieved / PEAK_TFLOPS_16BIT, "traffic": traffic, "traffic_note": traffic_note,
+                "kernel": f"{dom_name} {EPI_NAMES.get(dom_key % 8)}",
                 "algorithmic_bytes_per_launch": dom_bytes / dom_cnt if dom_bytes else None,
                 "launches": int(dom_cnt), "avg_launch_ms": dom_ms / dom_cnt,
                 "algorithmic_gflop_per_launch": dom_fl / dom_cnt / 1e9,
                 "all_gemm_tflops": gemm_total_fl / (gemm_total_ms * 1e-3) / 1e12,
                 "gemm_share_of_step": gemm_total_ms * 1e-3 / dt,
+                "shapes": shapes[:12],
             },
-            "step_mfma_frac": value * flops_per_sample / (world * PEAK_TFLOPS_16BIT * 1e12),
+            "step_exec_frac": gemm_total_fl / dt / (PEAK_TFLOPS_16BIT * 1e12),
+            "dense_equiv_frac": value * flops_per_sample / (world * PEAK_TFLOPS_16BIT * 1e12),
             "algorithmic_tflop_per_sample": flops_per_sample / 1e12,
             "exact_work_skipping": "none (dense, 77 rows per sequence)" if args.dense else
                                    "EOT trimming: rows after EOT are not computed (bit-identical outputs); "
-                                   f"mean kept rows {float(base_lens.mean()):.1f} of 77" +
+                                   f"mean kept rows {float(lens_np.mean()):.1f} of 77" +
                                    ("" if args.no_prefix_reuse else "; prefix reuse: rows before the edited token come "
                                     "from the clean caption's per-layer K/V cache (bit-identical outputs)"),
             "executed_gemm_tflop_per_step": gemm_total_fl / args.steps / 1e12,
+            "kernel_sources_sha16": kernel_sources_hash(),
             "loss": float(loss),
         }
+    # ---- dense leg: the same step with every exact work-skipping switched off (outside the timed region, all ranks)
+    if not args.no_dense_leg and not args.dense and args.attack == "leaf" and world == 1:
+        n_dense = 3
+        run_steps(1, None, False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_steps(n_dense, None, False)
+        torch.cuda.synchronize()
+        d_dt = time.perf_counter() - t1
+        if rank == 0:
+            out["dense"] = {"value": B * n_dense / d_dt, "unit": "samples/s", "steps": n_dense, "ms_per_step": d_dt / n_dense * 1e3,
+                            "note": "every sequence 77 rows, no prefix reuse (the reference's own amount of arithmetic)"}
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline and args.attack == "leaf":
             oracle_name = args.model if args.model in ("ViT-L-14", "ViT-L-14-quickgelu", "ViT-H-14", "ViT-g-14", "ViT-bigG-14") else "ViT-L-14"
-            out["cpu_baseline"] = cpu_baseline(oracle_name, args.rho, args.k_adv, args.cpu_batch, seed=1234)
+            out["cpu_baseline"] = cpu_baseline(oracle_name, args.rho, args.k_adv, args.cpu_batch, seed=1234, budget_s=args.cpu_budget_s)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

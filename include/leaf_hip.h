@@ -172,6 +172,8 @@ int leaf_tok_mutate_encode(leaf_tok_t tk, const char* const* sentences, const in
  * 4 = gemm_nt256_half_kernel, 5 = gemm_nt256_halfp_kernel, 6 = gemm_nt64_ring_kernel; keys < 128). */
 int leaf_prof_begin(void);
 int leaf_prof_end(double* ms, double* flops, double* bytes /* algorithmic, may be NULL */, int64_t* count, int n_keys);
+/* same records grouped by (key, N, K): info[4 i] = {key, N, K, launches}, rows[i] = sum of M; *n_out groups written */
+int leaf_prof_end_shapes(double* ms, double* flops, double* bytes, int64_t* rows, int32_t* info, int max_groups, int* n_out);
 
 /* ---- single-kernel hooks (used by the parity tests to check each HIP kernel against the oracle) ---- */
 /* C[M,N] = epilogue(A[M,K] * B[N,K]^T): epi 0 store16(+bias), 1 act16(+bias, aux = pre-activation), 2 fp32 += ,

@@ -71,6 +71,8 @@ _SIGS = {
     "leaf_prof_begin": (C.c_int, []),
     "leaf_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                C.c_int]),
+    "leaf_prof_end_shapes": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64),
+                                      C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int)]),
     "leaf_op_gemm": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "leaf_op_gemm_ld": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,

@@ -146,7 +146,7 @@ extern "C" int leaf_text_pack_weights(leaf_text_t h, const float* params, void* 
 // ------------------------------------------------------------------ forward
 // ------------------------------------------------------------------ per-launch GEMM profiler (bench.py roofline)
 namespace {
-struct ProfRec { hipEvent_t a, b; int key; double flops, bytes; };
+struct ProfRec { hipEvent_t a, b; int key, M, N, K; double flops, bytes; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 }  // namespace
@@ -160,6 +160,7 @@ int leaf_gemm(int dtype, int epi, const void* A, int lda, const void* B, int ldb
     if (!g_prof_on) return leaf_check(leaf_launch_gemm(g, dtype, epi, s), "gemm");
     ProfRec r;
     r.key = leaf_gemm_family(g, epi) * 16 + dtype * 8 + epi;
+    r.M = M; r.N = N; r.K = K;
     r.flops = 2.0 * (double)M * (double)N * (double)K;
     {   // algorithmic bytes of the launch: both operands once + the output (+ the fp32 read of a residual/accumulate)
         const double out_b = (epi == EPI_RESID_F32 || epi == EPI_STORE_F32) ? 4.0 : 2.0;
@@ -195,6 +196,34 @@ extern "C" int leaf_prof_end(double* ms, double* flops, double* bytes, int64_t* 
         (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
     }
     g_prof.clear();
+    return 0;
+}
+
+// Same as leaf_prof_end but grouped by (key, N, K) -- one line per GEMM SHAPE of each kernel, so that e.g. the two
+// residual GEMMs (out_proj: N = K = d, HBM-bound; c_proj: K = 4d, MFMA-bound) are reported separately.  info[i] =
+// {key, N, K, launches}; rows[i] = sum of M over the launches.  Returns the number of groups in *n_out (<= max_groups).
+extern "C" int leaf_prof_end_shapes(double* ms, double* flops, double* bytes, int64_t* rows, int32_t* info, int max_groups,
+                                    int* n_out) {
+    g_prof_on = false;
+    int n = 0;
+    for (auto& r : g_prof) {
+        LEAF_TRY(hipEventSynchronize(r.b));
+        float t = 0.f;
+        LEAF_TRY(hipEventElapsedTime(&t, r.a, r.b));
+        int i = 0;
+        for (; i < n; ++i)
+            if (info[4 * i] == r.key && info[4 * i + 1] == r.N && info[4 * i + 2] == r.K) break;
+        if (i == n) {
+            if (n == max_groups) continue;
+            info[4 * n] = r.key; info[4 * n + 1] = r.N; info[4 * n + 2] = r.K; info[4 * n + 3] = 0;
+            ms[n] = 0; flops[n] = 0; bytes[n] = 0; rows[n] = 0;
+            ++n;
+        }
+        ms[i] += t; flops[i] += r.flops; bytes[i] += r.bytes; rows[i] += r.M; info[4 * i + 3] += 1;
+    }
+    for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    g_prof.clear();
+    if (n_out) *n_out = n;
     return 0;
 }
 

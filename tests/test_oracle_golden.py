@@ -139,3 +139,33 @@ def test_normalize_fare_matches_reference(golden_dir):
         if k.startswith("g:"):
             assert rel_l2(g[k[2:]], z[k]) < 2e-4, k
     assert rel_l2(g["token_embedding.weight"][z["tok_rows"]], z["g_tok_rows"]) < 2e-4
+
+
+def _sample_index(numel, n_sample=257):
+    """Same walk as tests/golden/make_golden_vitl_grads.py:sample_index."""
+    n = min(n_sample, numel)
+    stride = max(1, numel // n) | 1
+    return (np.arange(n, dtype=np.int64) * stride * 7 + 3) % numel
+
+
+def test_vitl_grad_fixture(golden_dir):
+    """The oracle's backward at PRODUCTION shape (ViT-L, 12 layers) against the reference's torch.autograd result:
+    loss, features, the norm and a fixed sample of every one of the 149 parameter gradients (fp32 reorder noise only)."""
+    z = np.load(os.path.join(golden_dir, "vitl_grads_quickgelu.npz"))
+    cfg = O.CONFIGS["ViT-L-14-quickgelu"]
+    w = O.init_weights(cfg, seed=1)
+    toks = z["tokens"].astype(np.int64)
+    L = int(toks.argmax(-1).max()) + 1
+    loss, feat, g = O.encode_text_backward(w, cfg, toks[:, :L], z["anchor"])
+    assert abs(loss - float(z["loss"])) < 1e-5 * float(z["loss"])
+    assert rel_l2(feat, z["feat"]) < 5e-6
+    names = [k[2:] for k in z.files if k.startswith("n:")]
+    assert len(names) == 149 == len(w)
+    for k in names:
+        gk = g[k] if k != "positional_embedding" else g[k]       # rows >= L of the positional table get no gradient either way
+        flat = gk.reshape(-1)
+        assert abs(np.linalg.norm(flat.astype(np.float64)) / float(z["n:" + k]) - 1) < 1e-4, k
+        if k != "token_embedding.weight":
+            assert rel_l2(flat[_sample_index(flat.size)], z["s:" + k]) < 2e-4, k
+    rows = z["tok_rows"].astype(np.int64)
+    assert rel_l2(g["token_embedding.weight"][rows], z["g_tok_rows"].astype(np.float32)) < 1e-3   # fixture rows stored in fp16
