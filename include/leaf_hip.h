@@ -168,8 +168,7 @@ int leaf_tok_mutate_encode(leaf_tok_t tk, const char* const* sentences, const in
 
 /* ---- per-launch GEMM timing (bench.py roofline): between begin/end every GEMM launch is bracketed by HIP events on
  * its stream; end() sums duration / algorithmic FLOPs / algorithmic bytes / launches per key = kernel_family*16 + operand_dtype*8 + epilogue id
- * (family 0 = gemm_nt_kernel, 1 = gemm_nt256_kernel, 2 = gemm_nt256_ring_kernel, 3 = persistent ring,
- * 4 = gemm_nt256_half_kernel, 5 = gemm_nt256_halfp_kernel, 6 = gemm_nt64_ring_kernel; keys < 128). */
+ * (family 0 = gemm_nt_kernel, 1 = gemm_nt256_kernel, 4 = gemm_nt256_half_kernel, 6 = gemm_nt64_ring_kernel; keys < 128). */
 int leaf_prof_begin(void);
 int leaf_prof_end(double* ms, double* flops, double* bytes /* algorithmic, may be NULL */, int64_t* count, int n_keys);
 /* same records grouped by (key, N, K): info[4 i] = {key, N, K, launches}, rows[i] = sum of M; *n_out groups written */

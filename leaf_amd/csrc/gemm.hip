@@ -315,13 +315,13 @@ static bool use_gemm64(const GemmArgs& p) {
     return on && leaf_gemm64_eligible(p);
 }
 
-// which kernel leaf_launch_gemm will pick: 0 = gemm_nt_kernel (128^2), 1 = gemm_nt256_kernel, 2 = ring, 3 = persistent,
-// 4 = half-stage ring (gemm256h.hip, the default where eligible), 5 = its persistent form, 6 = 64 x 128 ring (gemm64.hip)
+// which kernel leaf_launch_gemm will pick: 4 = half-stage ring (gemm256h.hip; every launch with >= 128 tiles of 256^2 it can
+// take), 1 = gemm_nt256_kernel (two-stage 256^2: the act'(pre) epilogue of the backward), 6 = 64 x 128 ring (gemm64.hip, small
+// launches), 0 = gemm_nt_kernel (register-staged; K < 192 and the tiny test config)
 int leaf_gemm_family(const GemmArgs& p, int epi) {
-    static int ver = -1;
-    if (ver < 0) { const char* e = getenv("LEAF_GEMM_V"); ver = e ? atoi(e) : 4; }
-    if ((ver == 4 || ver == 5) && p.M > 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && leaf_gemm256h_eligible(p, epi)) return ver;
-    if (ver >= 2 && p.M > 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && leaf_gemm256_eligible(p, epi)) return ver == 3 ? 3 : 2;
+    static int use256h = -1;   // LEAF_GEMM256H=0: A/B and test switch (the two-stage kernel then takes the big launches)
+    if (use256h < 0) { const char* e = getenv("LEAF_GEMM256H"); use256h = (e && e[0] == '0') ? 0 : 1; }
+    if (use256h && p.M > 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && leaf_gemm256h_eligible(p, epi)) return 4;
     static int use256 = -1;
     if (use256 < 0) { const char* e = getenv("LEAF_GEMM256"); use256 = (e && e[0] == '0') ? 0 : 1; }
     if (use256 && p.N % 256 == 0 && (long)((p.M + 255) / 256) * (p.N / 256) >= 128) return 1;
@@ -334,19 +334,10 @@ void leaf_gemm_set_stamps(void* p) { g_stamps = p; }
 hipError_t leaf_launch_gemm(const GemmArgs& p_in, int dtype, int epi, hipStream_t s) {
     GemmArgs p = p_in;
     p.stamps = g_stamps;
-    // LEAF_GEMM_V: 1 = previous-generation kernels, 2 = 32-deep ring kernel, 3 = persistent ring (gemm256p.hip; measured
-    // 3-4 % SLOWER than 2 on the text-tower shapes), 4 = 64-deep half-stage ring with full-line DMA pieces (gemm256h.hip,
-    // default: +8 % over 2 on the layer's four GEMMs), 5 = persistent form of 4 (gemm256hp.hip: next tile's first
-    // half-stages land under the epilogue; measured equal to 4: 844.5 vs 845.2 TF/s over a layer's GEMMs, so not the
-    // default); shapes a kernel cannot take fall through to the next one down
-    static int ver = -1;
-    if (ver < 0) { const char* e = getenv("LEAF_GEMM_V"); ver = e ? atoi(e) : 4; }
-    if ((ver == 4 || ver == 5) && p.M > 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && leaf_gemm256h_eligible(p, epi))
-        return ver == 5 ? leaf_launch_gemm256hp(p, dtype, epi, s) : leaf_launch_gemm256h(p, dtype, epi, s);
-    if (ver >= 2 && p.M > 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && leaf_gemm256_eligible(p, epi))
-        return ver == 3 ? leaf_launch_gemm256p(p, dtype, epi, s) : leaf_launch_gemm256(p, dtype, epi, s);
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.N % BN || p.K % BK || p.lda % 8 || p.ldb % 8 || p.ldc % 4)
         return hipErrorInvalidValue;
-    if (leaf_gemm_family(p, epi) == 6) return leaf_launch_gemm64(p, dtype, epi, s);
+    const int fam = leaf_gemm_family(p, epi);
+    if (fam == 4) return leaf_launch_gemm256h(p, dtype, epi, s);
+    if (fam == 6) return leaf_launch_gemm64(p, dtype, epi, s);
     return dtype == LEAF_F16 ? launch_t<F16>(p, epi, s) : launch_t<BF16>(p, epi, s);
 }

@@ -1,7 +1,7 @@
-// NT GEMM, 256x256 output tile, FULL-LINE LDS-DMA pieces in a 5-slot half-stage ring -- experiment (LEAF_GEMM_V=4).
+// NT GEMM, 256x256 output tile, FULL-LINE LDS-DMA pieces in a 5-slot half-stage ring: the GEMM of every launch with >= 128 tiles.
 //
-// Same wave tiling, software-pipelined fragment reads, spread DMA issue and LDS-staged epilogue as gemm256.hip, but K is
-// streamed as 64-deep HALF-stages: one half-stage = ONE operand panel of 256 rows x 64 k (32 KiB, rows of 128 B), so a
+// 8 waves (2 x 4, 128 x 64 each), software-pipelined fragment reads, DMA issue spread between MFMA row groups, LDS-staged
+// epilogue.  K is streamed as 64-deep HALF-stages: one half-stage = ONE operand panel of 256 rows x 64 k (32 KiB, rows of 128 B), so a
 // DMA piece is 8 rows x 128 B = whole 128-B lines (tools/dma_probe*.hip: 45 B/clk/CU L2-hit fill against 25 B/clk/CU
 // for the 16 x 64 B pieces of the 32-deep stages).  Five half-slots = all 160 KiB of LDS: while tile t (A_t, B_t) is
 // multiplied, A_{t+1}, B_{t+1} and A_{t+2} are in flight; ONE barrier per 64 k.

@@ -32,21 +32,14 @@ struct GemmArgs {
 
 hipError_t leaf_launch_gemm(const GemmArgs& p, int dtype, int epi, hipStream_t s);
 void leaf_gemm_set_stamps(void* p);
-int leaf_gemm_family(const GemmArgs& p, int epi);   // 0 = 128^2, 1 = 256^2 two-stage, 2 = ring, 3 = persistent ring
-// 256x256 4-stage LDS-DMA ring kernel (gemm256.hip); eligible() says whether a problem may use it
-bool leaf_gemm256_eligible(const GemmArgs& p, int epi);
-hipError_t leaf_launch_gemm256(const GemmArgs& p, int dtype, int epi, hipStream_t s);
-// same tile/pipeline with persistent workgroups (gemm256p.hip): the DMA ring runs across tile seams
-hipError_t leaf_launch_gemm256p(const GemmArgs& p, int dtype, int epi, hipStream_t s);
-// 64-deep half-stage ring with full-line DMA pieces (gemm256h.hip)
+int leaf_gemm_family(const GemmArgs& p, int epi);   // 0 = gemm_nt_kernel, 1 = gemm_nt256_kernel (gemm.hip), 4 = half-stage ring, 6 = gemm64
+// 256 x 256 tile, 64-deep half-stage LDS-DMA ring with full-line pieces (gemm256h.hip): the kernel of every launch with >= 128 tiles
 bool leaf_gemm256h_eligible(const GemmArgs& p, int epi);
 int leaf_gemm256h_pick_ngroup(const GemmArgs& p);   // N tiles per L2-sized group (0 = one group)
 hipError_t leaf_launch_gemm256h(const GemmArgs& p, int dtype, int epi, hipStream_t s);
 // 64 x 128 tiles on a 3-slot LDS-DMA ring for small launches (gemm64.hip)
 bool leaf_gemm64_eligible(const GemmArgs& p);
 hipError_t leaf_launch_gemm64(const GemmArgs& p, int dtype, int epi, hipStream_t s);
-// persistent form of the same kernel (gemm256hp.hip): next tile's first half-stages land under the epilogue
-hipError_t leaf_launch_gemm256hp(const GemmArgs& p, int dtype, int epi, hipStream_t s);
 
 // ---- forward elementwise / reduction kernels (elementwise.hip)
 // x[r,:] = tok_emb[tokens[r],:] + pos_emb[r % ctx,:]   and   xn = LN(x) (16-bit)

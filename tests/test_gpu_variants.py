@@ -10,9 +10,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 VARIANTS = [
-    {"LEAF_GEMM_V": "5"},                            # persistent half-stage ring
-    {"LEAF_GEMM_V": "2"},                            # 32-deep 4-slot ring
-    {"LEAF_GEMM_V": "1"},                            # two-stage 256^2 + register-staged kernels
+    {"LEAF_GEMM256H": "0"},                          # two-stage 256^2 + register-staged kernels instead of the half-stage ring
     {"LEAF_GEMM64_DEEP": "1", "LEAF_GEMM64_MI": "2"},  # 6-slot small-launch ring
     {"LEAF_GEMM64": "0", "LEAF_GEMM_BM64": "1"},     # register-staged 64-row tiles
 ]

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Correctness of whichever GEMM kernel variant the environment selects (LEAF_GEMM_V, LEAF_GEMM64, LEAF_GEMM64_DEEP,
+"""Correctness of whichever GEMM kernel variant the environment selects (LEAF_GEMM256H, LEAF_GEMM64, LEAF_GEMM64_DEEP,
 LEAF_GEMM64_MI, LEAF_GEMM_BM64 are read once per process): a few shapes x epilogues through the C-ABI hook against a
 float64 product of the rounded operands.  Used by tests/test_gpu_variants.py in a subprocess per variant; exits non-zero
 on the first mismatch."""
