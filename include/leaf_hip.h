@@ -182,8 +182,19 @@ int leaf_op_gemm(int dtype, int epi, const void* A, const void* B, void* C, cons
 /* same with explicit row strides (elements) */
 int leaf_op_gemm_ld(int dtype, int epi, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias,
                     void* aux, int M, int N, int K, int act, float beta, int aux_f16, leaf_stream_t s);
-/* diagnostic builds (-DLEAF_GEMM_STAMPS) only: 8 x uint64 s_memtime stamps per GEMM workgroup land in buf */
+/* LayerNorm folded into the GEMMs of the forward-only passes (leaf_amd/csrc/lnfold.h; replaces the LayerNorm launches between
+ * the GEMMs of transformer.py:254-265).  Producer: C32[M,N] += A B^T + bias, x16 = 16-bit copy of the result, stat = float2
+ * [N/64][M] (sum, M2 = sum (x - group mean)^2) of each row's 64-column groups.  Finalize: rowstat[m] = (mean, rstd) merged from
+ * stat [ngroups][ld] (Chan).  Consumer: C16 = [act](rstd[m] (A Bp^T - mean[m] s[n]) + c[n]), Bp = 16-bit(gamma * W), s[n] =
+ * sum_k Bp[n,k], c[n] = beta . W[n,:] + bias[n]; act: -1 none, 0 GELU, 1 QuickGELU. */
+int leaf_op_gemm_resid_ln(int dtype, const void* A, const void* B, float* C, const float* bias, void* x16, void* stat, int M, int N,
+                          int K, leaf_stream_t s);
+int leaf_op_ln_finalize(const void* stat, int ld, int rows, int ngroups, float eps, void* rowstat, leaf_stream_t s);
+int leaf_op_gemm_lnfold(int dtype, int act, const void* A, const void* Bp, void* C16, const float* c_vec, const float* s_vec,
+                        const void* rowstat, int M, int N, int K, leaf_stream_t s);
 int leaf_debug_gemm_stamps(void* buf);
+/* dispatch tuning (tools/small_gemm_sweep.py): fewest 256 x 256 tiles for which the half-stage ring kernel takes a launch */
+int leaf_debug_gemm_min_tiles(int n);
 int leaf_op_attention_fwd(const void* qkv, void* out, int n_seq, int ctx, int heads, int width, int dtype,
                           leaf_stream_t s);
 int leaf_op_layernorm(const float* x, const float* g, const float* b, float eps, void* out16, int rows, int width,

@@ -77,7 +77,13 @@ _SIGS = {
                                C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "leaf_op_gemm_ld": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                   C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
+    "leaf_op_gemm_resid_ln": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                        C.c_int, C.c_int, C.c_void_p]),
+    "leaf_op_ln_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    "leaf_op_gemm_lnfold": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "leaf_debug_gemm_stamps": (C.c_int, [C.c_void_p]),
+    "leaf_debug_gemm_min_tiles": (C.c_int, [C.c_int]),
     "leaf_op_attention_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "leaf_op_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int,
                                     C.c_int, C.c_void_p]),

@@ -40,6 +40,7 @@ extern "C" int leaf_text_create(const leaf_text_cfg* cfg, int fwd_dtype, leaf_te
     h->chunk = 4096;
     h->streams = 1;   // 2 measured no faster on MI355X: the option stays for A/B runs
     { const char* e = getenv("LEAF_LAST_TRIM"); h->last_trim = (e && e[0] == '0') ? 0 : 1; }
+    { const char* e = getenv("LEAF_LN_FOLD"); h->ln_fold = (e && e[0] == '0') ? 0 : 1; }
     {   // gradient path: fp16 + per-step power-of-two loss scale unless LEAF_GRAD_DTYPE=bf16
         const char* e = getenv("LEAF_GRAD_DTYPE");
         h->grad_dtype = (e && (e[0] == 'b' || e[0] == 'B')) ? LEAF_DTYPE_BF16 : LEAF_DTYPE_FP16;
@@ -104,6 +105,7 @@ extern "C" int leaf_text_set_option(leaf_text_t h, const char* name, int value) 
     if (!strcmp(name, "last_layer_trim")) { h->last_trim = value ? 1 : 0; return 0; }
     if (!strcmp(name, "streams")) { h->streams = value >= 2 ? 2 : 1; return 0; }
     if (!strcmp(name, "normalize_fare")) { h->normalize_fare = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "ln_fold")) { h->ln_fold = (value && h->cfg.width % 64 == 0) ? 1 : 0; return 0; }
     leaf_set_error("unknown option '%s'", name);
     return 1;
 }
@@ -122,7 +124,7 @@ extern "C" int leaf_text_param_info(leaf_text_t h, int index, char* name, size_t
     return 0;
 }
 
-extern "C" size_t leaf_text_w16_bytes(leaf_text_t h) { return h->w16_layer_elems() * h->cfg.layers * 2; }
+extern "C" size_t leaf_text_w16_bytes(leaf_text_t h) { return h->w16_total_bytes(); }
 
 extern "C" int leaf_text_pack_weights(leaf_text_t h, const float* params, void* w16_fwd, void* w16_bwd,
                                       leaf_stream_t s_) {
@@ -138,7 +140,19 @@ extern "C" int leaf_text_pack_weights(leaf_text_t h, const float* params, void* 
             leaf_set_error("unexpected parameter layout");
             return 1;
         }
-    if (w16_fwd) LEAF_TRY(leaf_launch_cast(w32, w16_fwd, h->w16_layer_elems() * L, h->fwd_dtype, s));
+    if (w16_fwd) {
+        LEAF_TRY(leaf_launch_cast(w32, w16_fwd, h->w16_layer_elems() * L, h->fwd_dtype, s));
+        // LN folding (lnfold.h): gamma-scaled QKV / c_fc weights + their s[n], c[n] vectors, all layers in one launch
+        const LayerOff& o = h->layer[0];
+        const size_t vstride = L > 1 ? h->layer[1].ln1_w - o.ln1_w : 0;
+        for (int l = 1; l < L; ++l)
+            if (h->layer[l].ln1_w != o.ln1_w + l * vstride || h->layer[l].fc_b != o.fc_b + l * vstride) { leaf_set_error("unexpected parameter layout"); return 1; }
+        LEAF_TRY(leaf_launch_fold_pack(params + o.qkv_w, params + o.fc_w, h->w16_layer_elems(), params + o.ln1_w, params + o.ln1_b,
+                                       params + o.qkv_b, params + o.ln2_w, params + o.ln2_b, params + o.fc_b, vstride,
+                                       (uint16_t*)w16_fwd + h->w16_fold_qkv(0), (uint16_t*)w16_fwd + h->w16_fold_fc(0),
+                                       (size_t)7 * d * d, const_cast<float*>(h->fold_aux(w16_fwd, 0)), (size_t)14 * d, d, L,
+                                       h->fwd_dtype, s));
+    }
     if (w16_bwd) LEAF_TRY(leaf_launch_pack_transpose(w32, w16_bwd, h->grad_dtype, d, L, s));
     return 0;
 }
@@ -152,20 +166,34 @@ std::vector<ProfRec> g_prof;
 }  // namespace
 
 int leaf_gemm(int dtype, int epi, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias,
-              void* aux, int M, int N, int K, int act, hipStream_t s, float beta, int aux_f16, const float* alpha) {
+              void* aux, int M, int N, int K, int act, hipStream_t s, float beta, int aux_f16, const float* alpha,
+              const GemmLn* ln) {
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.aux = aux;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.act = act; g.aux_f16 = aux_f16; g.beta = beta; g.stamps = nullptr; g.alpha = alpha; g.ngroup = 0;
+    g.ln_s = nullptr; g.rowstat = nullptr; g.stat_out = nullptr; g.x16 = nullptr; g.stat_ld = 0; g.ldx16 = 0; g.ln_eps = 0.f;
+    if (epi == EPI_LNFOLD_T || epi == EPI_LNFOLD_ACT_T || epi == EPI_RESID_LN) {
+        const bool fold = epi != EPI_RESID_LN;
+        if (!ln || (fold && (!ln->ln_s || !ln->rowstat || !bias)) || (!fold && (!ln->x16 || !ln->stat_out || N % 64 || ln->stat_ld < M))) {
+            leaf_set_error("gemm: LN-folding operands missing or misshapen (epilogue %d)", epi);
+            return 1;
+        }
+        g.ln_s = ln->ln_s; g.rowstat = ln->rowstat; g.stat_out = ln->stat_out; g.x16 = ln->x16;
+        g.stat_ld = ln->stat_ld; g.ldx16 = ln->ldx16; g.ln_eps = ln->eps;
+    }
     if (!g_prof_on) return leaf_check(leaf_launch_gemm(g, dtype, epi, s), "gemm");
     ProfRec r;
     r.key = leaf_gemm_family(g, epi) * 16 + dtype * 8 + epi;
     r.M = M; r.N = N; r.K = K;
     r.flops = 2.0 * (double)M * (double)N * (double)K;
     {   // algorithmic bytes of the launch: both operands once + the output (+ the fp32 read of a residual/accumulate)
-        const double out_b = (epi == EPI_RESID_F32 || epi == EPI_STORE_F32) ? 4.0 : 2.0;
-        const double rmw = (epi == EPI_RESID_F32 || (epi == EPI_STORE_F32 && beta != 0.f)) ? 4.0 : 0.0;
-        r.bytes = 2.0 * ((double)M * K + (double)N * K) + (double)M * N * (out_b + rmw) + (epi == EPI_ACTGRAD_T ? 2.0 * M * N : 0.0);
+        const bool resid = epi == EPI_RESID_F32 || epi == EPI_RESID_LN;
+        const double out_b = (resid || epi == EPI_STORE_F32) ? 4.0 : 2.0;
+        const double rmw = (resid || (epi == EPI_STORE_F32 && beta != 0.f)) ? 4.0 : 0.0;
+        r.bytes = 2.0 * ((double)M * K + (double)N * K) + (double)M * N * (out_b + rmw) + (epi == EPI_ACTGRAD_T ? 2.0 * M * N : 0.0) +
+                  (epi == EPI_RESID_LN ? 2.0 * M * N + 8.0 * M * (N / 64) : 0.0) +                    // 16-bit copy + statistics
+                  ((epi == EPI_LNFOLD_T || epi == EPI_LNFOLD_ACT_T) ? 8.0 * M : 0.0);                  // (mean, rstd) per row
     }
     LEAF_TRY(hipEventCreate(&r.a));
     LEAF_TRY(hipEventCreate(&r.b));
@@ -235,12 +263,16 @@ struct FwdBuf {
     uint16_t* qkv; // [rows,3d]
     uint16_t* hh;  // [rows,4d]
     int32_t* eot;  // [seqs] pooled position per sequence (last-layer trimming)
+    uint16_t* x16; // [rows,d]   LN folding: 16-bit copy of the residual stream (A operand of the QKV / c_fc GEMMs)
+    float2* stat;  // [d/64][rows] LN folding: (sum, M2) per row and 64-column group
+    float2* rowstat; // [rows]     LN folding: (mean, rstd) per row
 };
 
 size_t fwd_chunk_bytes(const leaf_text* h, int cs) {
     const size_t rows = (size_t)cs * h->cfg.context_length, d = h->cfg.width;
     Carver c(nullptr, 0);
     c.take(rows * d * 4); c.take(rows * d * 2); c.take(rows * 3 * d * 2); c.take(rows * 4 * d * 2); c.take(rows * 4);
+    c.take(rows * d * 2); c.take(rows * (d / 64) * 8); c.take(rows * 8);
     return align_up(c.off, 256);
 }
 
@@ -252,6 +284,9 @@ FwdBuf carve_fwd(const leaf_text* h, Carver& c, int cs) {
     b.qkv = (uint16_t*)c.take(rows * 3 * d * 2);
     b.hh = (uint16_t*)c.take(rows * 4 * d * 2);
     b.eot = (int32_t*)c.take(rows * 4);   // one per sequence; a sequence has >= 1 row
+    b.x16 = (uint16_t*)c.take(rows * d * 2);
+    b.stat = (float2*)c.take(rows * (d / 64) * 8);
+    b.rowstat = (float2*)c.take(rows * 8);
     return b;
 }
 
@@ -271,33 +306,68 @@ int forward_chunk(const leaf_text* h, const float* P, const uint16_t* W, const i
     const leaf_text_cfg& c = h->cfg;
     const int d = c.width, dt = h->fwd_dtype;
     const LayerOff& o0 = h->layer[0];
-    LEAF_TRY(leaf_launch_embed_ln(tokens, P + h->tok_emb, P + h->pos_emb, P + o0.ln1_w, P + o0.ln1_b, c.ln_eps, b.x,
-                                  b.a, rows, cs, map, d, c.vocab_size, dt, s));
+    // LN folding (lnfold.h): no LayerNorm kernel between the GEMMs.  The embedding kernel and the residual GEMMs (out_proj,
+    // c_proj) emit the 16-bit copy of the residual row + its per-group statistics; the QKV / c_fc GEMMs multiply that raw
+    // row with the gamma-scaled weights and apply mean / rstd in their epilogue.
+    const bool fold = h->ln_fold != 0;
+    GemmLn ln;                       // statistics / 16-bit copy of the FULL row set of this chunk
+    ln.rowstat = b.rowstat; ln.stat_out = b.stat; ln.stat_ld = rows; ln.x16 = b.x16; ln.ldx16 = d; ln.eps = c.ln_eps;
+    // x = residual stream; qkv_gemm / fc_gemm: LN + linear of `m` rows whose (folded) statistics live in `g`
+    auto qkv_gemm = [&](int l, int m, const GemmLn& g, const void* xn) -> int {
+        const LayerOff& o = h->layer[l];
+        if (!fold) return leaf_gemm(dt, EPI_STORE_T, xn, d, W + h->w16_qkv(l), d, b.qkv, 3 * d, P + o.qkv_b, nullptr, m, 3 * d, d, 0, s);
+        GemmLn q = g; q.ln_s = h->fold_s_qkv(W, l);
+        return leaf_gemm(dt, EPI_LNFOLD_T, g.x16, d, W + h->w16_fold_qkv(l), d, b.qkv, 3 * d, h->fold_c_qkv(W, l), nullptr, m, 3 * d, d,
+                         0, s, 0.f, 0, nullptr, &q);
+    };
+    auto fc_gemm = [&](int l, int m, const GemmLn& g, const void* xn, void* hid) -> int {
+        const LayerOff& o = h->layer[l];
+        if (!fold) return leaf_gemm(dt, EPI_ACT_T, xn, d, W + h->w16_fc(l), d, hid, 4 * d, P + o.fc_b, nullptr, m, 4 * d, d, c.activation, s);
+        GemmLn q = g; q.ln_s = h->fold_s_fc(W, l);
+        return leaf_gemm(dt, EPI_LNFOLD_ACT_T, g.x16, d, W + h->w16_fold_fc(l), d, hid, 4 * d, h->fold_c_fc(W, l), nullptr, m, 4 * d, d,
+                         c.activation, s, 0.f, 0, nullptr, &q);
+    };
+    // residual GEMM x += A W^T + bias; with folding (and a LayerNorm following) it also emits x16 / statistics
+    // ... and the tiny finalize launch turns the [group][row] partials into (mean, rstd) per row for the consuming GEMM
+    auto resid_gemm = [&](const void* A, int K, size_t w_off, const float* bias, float* x, int m, const GemmLn* g) -> int {
+        if (!(fold && g)) return leaf_gemm(dt, EPI_RESID_F32, A, K, W + w_off, K, x, d, bias, nullptr, m, d, K, 0, s);
+        if (leaf_gemm(dt, EPI_RESID_LN, A, K, W + w_off, K, x, d, bias, nullptr, m, d, K, 0, s, 0.f, 0, nullptr, g)) return 1;
+        return leaf_check(leaf_launch_ln_finalize(g->stat_out, g->stat_ld, m, d / 64, g->eps, const_cast<float2*>(g->rowstat), s), "ln_finalize");
+    };
+    if (fold) {
+        LEAF_TRY(leaf_launch_embed_fold(tokens, P + h->tok_emb, P + h->pos_emb, b.x, b.x16, b.stat, rows, rows, cs, map, d,
+                                        c.vocab_size, dt, s));
+        LEAF_TRY(leaf_launch_ln_finalize(b.stat, rows, rows, d / 64, c.ln_eps, b.rowstat, s));
+    }
+    else
+        LEAF_TRY(leaf_launch_embed_ln(tokens, P + h->tok_emb, P + h->pos_emb, P + o0.ln1_w, P + o0.ln1_b, c.ln_eps, b.x,
+                                      b.a, rows, cs, map, d, c.vocab_size, dt, s));
     for (int l = 0; l < c.layers; ++l) {
         const LayerOff& o = h->layer[l];
-        if (l > 0) LEAF_TRY(leaf_launch_layernorm(b.x, P + o.ln1_w, P + o.ln1_b, c.ln_eps, b.a, rows, d, dt, s));
+        const bool last = l == c.layers - 1;
+        if (l > 0 && !fold) LEAF_TRY(leaf_launch_layernorm(b.x, P + o.ln1_w, P + o.ln1_b, c.ln_eps, b.a, rows, d, dt, s));
         if (kv.kv_write) b.qkv = kv.kv_write + (size_t)l * kv.kv_stride;
-        if (leaf_gemm(dt, EPI_STORE_T, b.a, d, W + h->w16_qkv(l), d, b.qkv, 3 * d, P + o.qkv_b, nullptr, rows, 3 * d, d, 0, s))
-            return 1;
+        if (qkv_gemm(l, rows, ln, b.a)) return 1;
         const void* kvl = kv.kv_read ? kv.kv_read + (size_t)l * kv.kv_stride : nullptr;
-        if (l == c.layers - 1 && !out) break;          // K/V-only pass (clean captions for the cache): nothing consumes the rest
-        if (l == c.layers - 1 && h->last_trim && !kv.kv_write) {
+        if (last && !out) break;          // K/V-only pass (clean captions for the cache): nothing consumes the rest
+        if (last && h->last_trim && !kv.kv_write) {
             // Last block: only the pooled row (first maximum token id = EOT) of each sequence reaches the output, and every later op is
             // row-wise, so attention output, out-projection, LN2 and the MLP run on ONE row per sequence (bit-identical).
             // Scratch: after attention and the gather, the qkv and fc buffers (carved back to back, 14*d*rows bytes) are
             // dead; the gathered residual rows xg (fp32 [cs,d]) and the MLP hidden rows hb (16-bit [cs,4d]) need
-            // 12*d*cs <= 14*d*rows bytes.
+            // 12*d*cs <= 14*d*rows bytes.  With folding the chunk's x16 / statistics buffers (dead after the QKV GEMM above)
+            // take the pooled rows' 16-bit copy and statistics (row stride cs).
             LEAF_TRY(leaf_launch_eot_positions(tokens, b.eot, cs, map, s));
             LEAF_TRY(leaf_launch_attention_fwd(b.qkv, kvl, b.a, cs, map, c.heads, d, dt, s, b.eot, max_len));
             float* xg = (float*)b.qkv;
             uint16_t* hb = (uint16_t*)((char*)b.qkv + align_up((size_t)cs * d * 4, 256));
             LEAF_TRY(leaf_launch_gather_rows(b.x, b.eot, xg, cs, map, d, s));
-            if (leaf_gemm(dt, EPI_RESID_F32, b.a, d, W + h->w16_out(l), d, xg, d, P + o.out_b, nullptr, cs, d, d, 0, s)) return 1;
-            LEAF_TRY(leaf_launch_layernorm(xg, P + o.ln2_w, P + o.ln2_b, c.ln_eps, b.a, cs, d, dt, s));
-            if (leaf_gemm(dt, EPI_ACT_T, b.a, d, W + h->w16_fc(l), d, hb, 4 * d, P + o.fc_b, nullptr, cs, 4 * d, d, c.activation, s))
-                return 1;
-            if (leaf_gemm(dt, EPI_RESID_F32, hb, 4 * d, W + h->w16_proj(l), 4 * d, xg, d, P + o.proj_b, nullptr, cs, d, 4 * d, 0, s))
-                return 1;
+            GemmLn lg = ln;
+            lg.stat_ld = cs;
+            if (resid_gemm(b.a, d, h->w16_out(l), P + o.out_b, xg, cs, &lg)) return 1;
+            if (!fold) LEAF_TRY(leaf_launch_layernorm(xg, P + o.ln2_w, P + o.ln2_b, c.ln_eps, b.a, cs, d, dt, s));
+            if (fc_gemm(l, cs, lg, b.a, hb)) return 1;
+            if (resid_gemm(hb, 4 * d, h->w16_proj(l), P + o.proj_b, xg, cs, nullptr)) return 1;
             if (leaf_project_rows_ok(d, c.embed_dim)) {   // hb is dead after the c_proj GEMM: its space takes LN(xg)
                 LEAF_TRY(leaf_launch_project_rows(xg, P + h->lnf_w, P + h->lnf_b, c.ln_eps, P + h->text_proj, (float*)hb, out,
                                                   cs, d, c.embed_dim, normalize, s));
@@ -308,15 +378,10 @@ int forward_chunk(const leaf_text* h, const float* P, const uint16_t* W, const i
             return 0;
         }
         LEAF_TRY(leaf_launch_attention_fwd(b.qkv, kvl, b.a, cs, map, c.heads, d, dt, s, nullptr, max_len));
-        if (leaf_gemm(dt, EPI_RESID_F32, b.a, d, W + h->w16_out(l), d, b.x, d, P + o.out_b, nullptr, rows, d, d, 0, s))
-            return 1;
-        LEAF_TRY(leaf_launch_layernorm(b.x, P + o.ln2_w, P + o.ln2_b, c.ln_eps, b.a, rows, d, dt, s));
-        if (leaf_gemm(dt, EPI_ACT_T, b.a, d, W + h->w16_fc(l), d, b.hh, 4 * d, P + o.fc_b, nullptr, rows, 4 * d, d,
-                      c.activation, s))
-            return 1;
-        if (leaf_gemm(dt, EPI_RESID_F32, b.hh, 4 * d, W + h->w16_proj(l), 4 * d, b.x, d, P + o.proj_b, nullptr, rows, d,
-                      4 * d, 0, s))
-            return 1;
+        if (resid_gemm(b.a, d, h->w16_out(l), P + o.out_b, b.x, rows, &ln)) return 1;
+        if (!fold) LEAF_TRY(leaf_launch_layernorm(b.x, P + o.ln2_w, P + o.ln2_b, c.ln_eps, b.a, rows, d, dt, s));
+        if (fc_gemm(l, rows, ln, b.a, b.hh)) return 1;
+        if (resid_gemm(b.hh, 4 * d, h->w16_proj(l), P + o.proj_b, b.x, rows, last ? nullptr : &ln)) return 1;   // ln_final runs on the pooled rows
     }
     if (out && leaf_project_rows_ok(d, c.embed_dim)) {
         // same op sequence as the trimmed path (bit-identical features): gather the pooled rows, LN, fp32 projection.
@@ -529,7 +594,26 @@ extern "C" int leaf_op_gemm_ld(int dtype, int epi, const void* A, int lda, const
                                leaf_stream_t s) {
     return leaf_gemm(dtype, epi, A, lda, B, ldb, C, ldc, bias, aux, M, N, K, act, (hipStream_t)s, beta, aux_f16);
 }
+// LN folding (lnfold.h): the producing residual GEMM (C32 += A B^T + bias, x16 = 16-bit(C32), stat[N/64][M] = (sum, M2)) ...
+extern "C" int leaf_op_gemm_resid_ln(int dtype, const void* A, const void* B, float* C, const float* bias, void* x16, void* stat,
+                                     int M, int N, int K, leaf_stream_t s) {
+    GemmLn ln;
+    ln.x16 = x16; ln.ldx16 = N; ln.stat_out = (float2*)stat; ln.stat_ld = M;
+    return leaf_gemm(dtype, EPI_RESID_LN, A, K, B, K, C, N, bias, nullptr, M, N, K, 0, (hipStream_t)s, 0.f, 0, nullptr, &ln);
+}
+// ... the merge of the partials into rowstat[M] = (mean, rstd), and the consuming GEMM: C16 = [act](rstd[m] (A Bp^T - mean[m] s[n]) + c[n]); act < 0: none
+extern "C" int leaf_op_ln_finalize(const void* stat, int ld, int rows, int ngroups, float eps, void* rowstat, leaf_stream_t s) {
+    return leaf_check(leaf_launch_ln_finalize((const float2*)stat, ld, rows, ngroups, eps, (float2*)rowstat, (hipStream_t)s), "ln_finalize");
+}
+extern "C" int leaf_op_gemm_lnfold(int dtype, int act, const void* A, const void* Bp, void* C16, const float* c_vec,
+                                   const float* s_vec, const void* rowstat, int M, int N, int K, leaf_stream_t s) {
+    GemmLn ln;
+    ln.ln_s = s_vec; ln.rowstat = (const float2*)rowstat;
+    return leaf_gemm(dtype, act < 0 ? EPI_LNFOLD_T : EPI_LNFOLD_ACT_T, A, K, Bp, K, C16, N, c_vec, nullptr, M, N, K, act < 0 ? 0 : act,
+                     (hipStream_t)s, 0.f, 0, nullptr, &ln);
+}
 extern "C" int leaf_debug_gemm_stamps(void* buf) { leaf_gemm_set_stamps(buf); return 0; }
+extern "C" int leaf_debug_gemm_min_tiles(int n) { leaf_gemm256h_set_min_tiles(n); return 0; }
 extern "C" int leaf_op_attention_fwd(const void* qkv, void* out, int n_seq, int ctx, int heads, int width, int dtype,
                                      leaf_stream_t s) {
     return leaf_check(leaf_launch_attention_fwd(qkv, nullptr, out, n_seq, RowMap{nullptr, 0, 0, ctx, nullptr, nullptr, 1}, heads, width, dtype,

@@ -77,6 +77,22 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// x + (x of another lane of the same 16-lane row), as ONE VALU instruction (v_add_f32 with a DPP source): quad_perm
+// [1,0,3,2] / [2,3,0,1] exchange inside a quad, row_half_mirror reverses each 8-lane half, row_mirror the 16-lane row.
+// Applied in that order to a value they form an all-reduce over 16 lanes whose pairing is the xor-butterfly 1, 2, 4, 8
+// (after the first two steps every lane of a quad holds the quad sum, so "mirror" pairs quad q with q ^ 1, half h with h ^ 1).
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float x) {
+    return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_sum(float x) {
+    x = dpp_add<0xB1>(x);    // quad_perm [1,0,3,2]
+    x = dpp_add<0x4E>(x);    // quad_perm [2,3,0,1]
+    x = dpp_add<0x141>(x);   // row_half_mirror
+    x = dpp_add<0x140>(x);   // row_mirror
+    return x;
+}
+
 enum { ACT_GELU = 0, ACT_QUICKGELU = 1 };
 
 // erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the 16-bit rounding of the activation) on the hardware

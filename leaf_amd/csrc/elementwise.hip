@@ -8,6 +8,7 @@
 // every global access is a coalesced 16-B-per-lane load/store.
 #include "common.h"
 #include "kernels.h"
+#include "lnfold.h"
 
 namespace {
 
@@ -85,6 +86,93 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x_in,
         }
     }
     ln_row_store<TT>(v, nq, lane, g, b, eps, d, xn + (size_t)row * d);
+}
+
+// Token gather + positional add for the LN-folded forward (lnfold.h): writes the fp32 residual row, its 16-bit copy (the A
+// operand of the first QKV GEMM) and the (sum, M2) statistics of each 64-column group.  One wave per row; a lane holds the
+// 4-element chunks lane, lane + 64, ...: a group is 16 consecutive lanes of one iteration, reduced in the same tree as the
+// GEMM epilogues (row16_sum).
+template <class TT>
+__global__ __launch_bounds__(256) void embed_fold_kernel(const float* __restrict__ delta, const int32_t* __restrict__ tokens,
+                                                         const float* __restrict__ tok_emb, const float* __restrict__ pos_emb,
+                                                         float* __restrict__ x_out, u16* __restrict__ x16,
+                                                         float2* __restrict__ stat, int stat_ld, int rows, int n_seq, RowMap map,
+                                                         int d, int vocab) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nq = d >> 2;
+    const int sq = seq_of_row(map, row, n_seq);
+    const int pos = row - seq_row(map, sq) + seq_prefix(map, sq);
+    int tok = tokens[(size_t)sq * map.ctx + pos];
+    tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
+    const float* te = tok_emb + (size_t)tok * d;
+    const float* pe = pos_emb + (size_t)pos * d;
+    float* xo = x_out + (size_t)row * d;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int c = lane + 64 * i;
+        if (64 * i >= nq) break;                       // wave-uniform
+        float4 v = float4{0.f, 0.f, 0.f, 0.f};
+        if (c < nq) {
+            float4 a = *(const float4*)(te + 4 * c), p = *(const float4*)(pe + 4 * c);
+            if (delta) {
+                const float4 dl = *(const float4*)(delta + (size_t)row * d + 4 * c);
+                a = float4{a.x + dl.x, a.y + dl.y, a.z + dl.z, a.w + dl.w};
+            }
+            v = float4{a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w};
+            *(float4*)(xo + 4 * c) = v;
+            *(uint2*)(x16 + (size_t)row * d + 4 * c) = pack4<TT>(v.x, v.y, v.z, v.w);
+        }
+        const float gs = row16_sum(lnfold_sum4(v.x, v.y, v.z, v.w));
+        const float gq = row16_sum(lnfold_dev4(v.x, v.y, v.z, v.w, gs * (1.0f / 64.0f)));
+        if (c < nq && (lane & 15) == 0) stat[(size_t)(c >> 4) * stat_ld + row] = float2{gs, gq};
+    }
+}
+
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float2* __restrict__ stat, int ld, int rows, int ngroups, float eps,
+                                                          float2* __restrict__ rowstat) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m < rows) rowstat[m] = lnfold_row_stat(stat, ld, m, ngroups, eps);
+}
+
+// Weight side of the LN folding, one wave per output row of W [N, K = d] (fp32): W'[n,k] = 16-bit(g[k] W[n,k]),
+// s[n] = sum_k W'[n,k] (of the ROUNDED values), c[n] = sum_k b[k] W[n,k] + bias[n].  ONE launch for all layers:
+// blockIdx.y = 2 * layer + (0: QKV with ln_1, 1: c_fc with ln_2); layers are regularly strided in the flat parameter buffer.
+struct FoldPackArgs {
+    const float* W[2]; const float* g[2]; const float* b[2]; const float* bias[2];   // layer 0
+    size_t w_stride, v_stride;       // floats between consecutive layers (weights / vectors)
+    u16* Wp[2]; size_t wp_stride;    // 16-bit outputs of layer 0, elements between layers
+    float* s[2]; float* c[2]; size_t aux_stride;
+    int N[2], d;
+};
+template <class TT>
+__global__ __launch_bounds__(256) void fold_pack_kernel(FoldPackArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int l = blockIdx.y >> 1, w = blockIdx.y & 1;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= a.N[w]) return;
+    const int d = a.d;
+    const float* wr = a.W[w] + l * a.w_stride + (size_t)n * d;
+    const float* g = a.g[w] + l * a.v_stride;
+    const float* b = a.b[w] + l * a.v_stride;
+    u16* Wp = a.Wp[w] + l * a.wp_stride + (size_t)n * d;
+    float ss = 0.f, cc = 0.f;
+    for (int c = lane; c < (d >> 2); c += 64) {
+        const float4 wv = *(const float4*)(wr + 4 * c), gv = *(const float4*)(g + 4 * c), bv = *(const float4*)(b + 4 * c);
+        const uint2 pk = pack4<TT>(gv.x * wv.x, gv.y * wv.y, gv.z * wv.z, gv.w * wv.w);
+        *(uint2*)(Wp + 4 * c) = pk;
+        float r[4];
+        unpack4<TT>(pk, r);
+        ss += (r[0] + r[1]) + (r[2] + r[3]);
+        cc += (bv.x * wv.x + bv.y * wv.y) + (bv.z * wv.z + bv.w * wv.w);
+    }
+    ss = wave_sum(ss);
+    cc = wave_sum(cc);
+    if (lane == 0) {
+        a.s[w][l * a.aux_stride + n] = ss;
+        a.c[w][l * a.aux_stride + n] = cc + (a.bias[w] + l * a.v_stride)[n];
+    }
 }
 
 // ---------------------------------------------------------------- pooling + final LN + projection
@@ -309,6 +397,43 @@ hipError_t leaf_launch_embed_ln(const int32_t* tokens, const float* tok_emb, con
     else
         hipLaunchKernelGGL((ln_kernel<BF16, true>), grid, blk, 0, s, delta, tokens, tok_emb, pos_emb, g, b, eps, x,
                            (u16*)xn, rows, n_seq, map, d, vocab);
+    return hipGetLastError();
+}
+
+hipError_t leaf_launch_embed_fold(const int32_t* tokens, const float* tok_emb, const float* pos_emb, float* x, void* x16,
+                                  float2* stat, int stat_ld, int rows, int n_seq, RowMap map, int d, int vocab, int dtype,
+                                  hipStream_t s, const float* delta) {
+    if (d % 64 || d > 256 * MAXCH) return hipErrorInvalidValue;
+    dim3 grid((rows + 3) / 4), blk(256);
+    if (dtype == LEAF_F16)
+        hipLaunchKernelGGL((embed_fold_kernel<F16>), grid, blk, 0, s, delta, tokens, tok_emb, pos_emb, x, (u16*)x16, stat, stat_ld,
+                           rows, n_seq, map, d, vocab);
+    else
+        hipLaunchKernelGGL((embed_fold_kernel<BF16>), grid, blk, 0, s, delta, tokens, tok_emb, pos_emb, x, (u16*)x16, stat, stat_ld,
+                           rows, n_seq, map, d, vocab);
+    return hipGetLastError();
+}
+
+hipError_t leaf_launch_ln_finalize(const float2* stat, int ld, int rows, int ngroups, float eps, float2* rowstat, hipStream_t s) {
+    if (ngroups < 1 || ngroups > LNFOLD_MAXG || rows < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, stat, ld, rows, ngroups, eps, rowstat);
+    return hipGetLastError();
+}
+
+hipError_t leaf_launch_fold_pack(const float* qkv_w, const float* fc_w, size_t w_stride, const float* ln1_w, const float* ln1_b,
+                                 const float* qkv_b, const float* ln2_w, const float* ln2_b, const float* fc_b, size_t v_stride,
+                                 void* qkv_p, void* fc_p, size_t wp_stride, float* aux, size_t aux_stride, int d, int layers,
+                                 int dtype, hipStream_t s) {
+    if (d % 4) return hipErrorInvalidValue;
+    FoldPackArgs a;
+    a.W[0] = qkv_w; a.W[1] = fc_w; a.g[0] = ln1_w; a.g[1] = ln2_w; a.b[0] = ln1_b; a.b[1] = ln2_b; a.bias[0] = qkv_b; a.bias[1] = fc_b;
+    a.w_stride = w_stride; a.v_stride = v_stride;
+    a.Wp[0] = (u16*)qkv_p; a.Wp[1] = (u16*)fc_p; a.wp_stride = wp_stride;
+    a.s[0] = aux; a.c[0] = aux + 3 * d; a.s[1] = aux + 6 * d; a.c[1] = aux + 10 * d; a.aux_stride = aux_stride;
+    a.N[0] = 3 * d; a.N[1] = 4 * d; a.d = d;
+    dim3 grid((4 * d + 3) / 4, 2 * layers), blk(256);
+    if (dtype == LEAF_F16) hipLaunchKernelGGL((fold_pack_kernel<F16>), grid, blk, 0, s, a);
+    else hipLaunchKernelGGL((fold_pack_kernel<BF16>), grid, blk, 0, s, a);
     return hipGetLastError();
 }
 

@@ -41,14 +41,38 @@ struct leaf_text {
     size_t w16_out(int l) const { return w16_qkv(l) + (size_t)3 * cfg.width * cfg.width; }
     size_t w16_fc(int l) const { return w16_out(l) + (size_t)cfg.width * cfg.width; }
     size_t w16_proj(int l) const { return w16_fc(l) + (size_t)4 * cfg.width * cfg.width; }
+    // ---- LN folding (lnfold.h), forward-only passes.  The 16-bit forward pack continues behind the standard copies with the
+    // gamma-scaled QKV and c_fc weights of every layer (7 d^2 per layer), followed (256-B aligned) by the fp32 vectors
+    // s_qkv[3d], c_qkv[3d], s_fc[4d], c_fc[4d] per layer.
+    int ln_fold = 1;          // option 'ln_fold' / LEAF_LN_FOLD=0: separate LayerNorm kernels instead
+    size_t w16_std_elems() const { return w16_layer_elems() * cfg.layers; }
+    size_t w16_fold_qkv(int l) const { return w16_std_elems() + (size_t)l * 7 * cfg.width * cfg.width; }
+    size_t w16_fold_fc(int l) const { return w16_fold_qkv(l) + (size_t)3 * cfg.width * cfg.width; }
+    size_t w16_aux_byte_off() const { return ((w16_std_elems() + (size_t)cfg.layers * 7 * cfg.width * cfg.width) * 2 + 255) / 256 * 256; }
+    size_t w16_total_bytes() const { return w16_aux_byte_off() + (size_t)cfg.layers * 14 * cfg.width * 4; }
+    // fp32 aux vectors of layer l inside a forward pack at `w16`
+    const float* fold_aux(const void* w16, int l) const { return (const float*)((const char*)w16 + w16_aux_byte_off()) + (size_t)l * 14 * cfg.width; }
+    const float* fold_s_qkv(const void* w16, int l) const { return fold_aux(w16, l); }
+    const float* fold_c_qkv(const void* w16, int l) const { return fold_aux(w16, l) + 3 * cfg.width; }
+    const float* fold_s_fc(const void* w16, int l) const { return fold_aux(w16, l) + 6 * cfg.width; }
+    const float* fold_c_fc(const void* w16, int l) const { return fold_aux(w16, l) + 10 * cfg.width; }
 };
 
 size_t leaf_train_ws_bytes(const leaf_text* h, int n_seq);  // api_train.hip
 // GEMM launch shared by both API files; when the profiler is armed (leaf_prof_begin) each launch is bracketed
 // by HIP events on its own stream and accounted under its epilogue id.
+// LN folding operands of leaf_gemm (EPI_LNFOLD_* consume rowstat / ln_s, EPI_RESID_LN produces x16 / stat_out)
+struct GemmLn {
+    const float* ln_s = nullptr;
+    const float2* rowstat = nullptr;
+    float2* stat_out = nullptr;
+    void* x16 = nullptr;
+    int stat_ld = 0, ldx16 = 0;
+    float eps = 1e-5f;
+};
 int leaf_gemm(int dtype, int epi, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias,
               void* aux, int M, int N, int K, int act, hipStream_t s, float beta = 0.f, int aux_f16 = 0,
-              const float* alpha = nullptr);
+              const float* alpha = nullptr, const GemmLn* ln = nullptr);
 void leaf_set_error(const char* fmt, ...);
 int leaf_check(hipError_t e, const char* what);
 

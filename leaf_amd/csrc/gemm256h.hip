@@ -9,6 +9,7 @@
 
 #include "common.h"
 #include "kernels.h"
+#include "lnfold.h"
 
 namespace {
 
@@ -84,6 +85,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
 #define ISSUE_B(so, kt, q) DMA16(B + (size_t)((kt) * (BK * 2) + (q) * bstep) + b0, smem + (so) + piece + (q) * 1024)
 #define ISSUE_HALF_A(so, kt) ISSUE_A(so, kt, 0); ISSUE_A(so, kt, 1); ISSUE_A(so, kt, 2); ISSUE_A(so, kt, 3);
 #define ISSUE_HALF_B(so, kt) ISSUE_B(so, kt, 0); ISSUE_B(so, kt, 1); ISSUE_B(so, kt, 2); ISSUE_B(so, kt, 3);
+
+    // LN folding: thread t < 256 fetches (mean, rstd) of A row m0 + t now (2 registers held across the K loop), so the epilogue
+    // waits for no memory
+    constexpr bool FOLD = (EPI == EPI_LNFOLD_T || EPI == EPI_LNFOLD_ACT_T);
+    float2 my_rowstat = float2{0.f, 0.f};
+    if constexpr (FOLD) {
+        if (tid < BM && m0 + tid < p.M) my_rowstat = p.rowstat[m0 + tid];
+    }
 
     f32x4 acc[8][4];
 #pragma unroll
@@ -230,6 +239,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] *= al;
     }
+    if constexpr (FOLD) {
+        // (mean, rstd) of this tile's 256 A rows (loaded before the K loop) -> a 2-KiB table above the staging slices
+        if (tid < BM) *(float2*)(smem + 8 * SLICE + tid * 8) = my_rowstat;
+        __syncthreads();
+    }
     char* sl = smem + wid * SLICE;
     const int fq = lane >> 4;
     const int nb = n0 + wn * 64;          // first column of this wave's sub-tile
@@ -239,7 +253,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
     for (int j = 0; j < 4; ++j)
         bias4[j] = p.bias ? *(const float4*)(p.bias + nb + 16 * j + 4 * fq) : float4{0.f, 0.f, 0.f, 0.f};
 
-    if constexpr (EPI == EPI_STORE_T || EPI == EPI_ACT_T) {
+    float4 s4[4];   // LN folding: row sums of the gamma-scaled weights for this lane's columns
+    if constexpr (FOLD) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s4[j] = *(const float4*)(p.ln_s + nb + 16 * j + 4 * fq);
+    }
+
+    if constexpr (EPI == EPI_STORE_T || EPI == EPI_ACT_T || FOLD) {
         // two passes of 64 rows x 64 cols of 16-bit: LDS rows of 128 B, 16-B chunks XOR-swizzled by (row & 7)
         // ACTC: std::integral_constant<int, -1 | ACT_GELU | ACT_QUICKGELU> - the activation is fixed at compile time inside
         // the element loops (a run-time id there costs one branch per element and serialises the transcendental chains)
@@ -250,10 +270,21 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
                 const int i = 4 * pass + ii;
                 const int row = 16 * ii + frow;
                 float v[4][4];
+                if constexpr (FOLD) {
+                    const float2 rs = *(const float2*)(smem + 8 * SLICE + (wm * 128 + 16 * i + frow) * 8);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    v[j][0] = acc[i][j][0] + bias4[j].x; v[j][1] = acc[i][j][1] + bias4[j].y;
-                    v[j][2] = acc[i][j][2] + bias4[j].z; v[j][3] = acc[i][j][3] + bias4[j].w;
+                    for (int j = 0; j < 4; ++j) {
+                        v[j][0] = lnfold_apply(acc[i][j][0], rs.x, rs.y, s4[j].x, bias4[j].x);
+                        v[j][1] = lnfold_apply(acc[i][j][1], rs.x, rs.y, s4[j].y, bias4[j].y);
+                        v[j][2] = lnfold_apply(acc[i][j][2], rs.x, rs.y, s4[j].z, bias4[j].z);
+                        v[j][3] = lnfold_apply(acc[i][j][3], rs.x, rs.y, s4[j].w, bias4[j].w);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[j][0] = acc[i][j][0] + bias4[j].x; v[j][1] = acc[i][j][1] + bias4[j].y;
+                        v[j][2] = acc[i][j][2] + bias4[j].z; v[j][3] = acc[i][j][3] + bias4[j].w;
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -281,21 +312,23 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
                 }
             }
         };
+        constexpr bool ACTIVE = (EPI == EPI_ACT_T || EPI == EPI_LNFOLD_ACT_T);
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
             if (EPI == EPI_ACT_T && p.aux) {   // training forward: pre-activation stash first
                 stage16(pass, NoAct());
                 flush16(pass, (u16*)p.aux);
             }
-            if (EPI != EPI_ACT_T) stage16(pass, NoAct());
+            if (!ACTIVE) stage16(pass, NoAct());
             else if (p.act == ACT_QUICKGELU) stage16(pass, QuickGelu());
             else stage16(pass, Gelu());
             flush16(pass, (u16*)p.C);
         }
     } else {
         // fp32 outputs: four passes of 32 rows x 64 cols: LDS rows of 256 B, 16-B chunks XOR-swizzled by (row & 15)
-        const float beta = (EPI == EPI_RESID_F32) ? 1.f : p.beta;
-        const float* rsrc = (EPI == EPI_RESID_F32 && p.aux) ? (const float*)p.aux : (const float*)p.C;   // out-of-place residual
+        constexpr bool RESID = (EPI == EPI_RESID_F32 || EPI == EPI_RESID_LN);
+        const float beta = RESID ? 1.f : p.beta;
+        const float* rsrc = (RESID && p.aux) ? (const float*)p.aux : (const float*)p.C;   // out-of-place residual
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
             float4 res[8];
@@ -332,6 +365,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
                 if (m < p.M) {
                     typedef float f32x4_t __attribute__((ext_vector_type(4)));
                     __builtin_nontemporal_store(f32x4_t{v.x, v.y, v.z, v.w}, (f32x4_t*)((float*)p.C + (size_t)m * p.ldc + nb + ((pc ^ (row & 15)) << 2)));
+                }
+                if constexpr (EPI == EPI_RESID_LN) {
+                    // LN folding: 16-bit copy of the finished row segment + (sum, M2) of its 64 columns (the 16 lanes of the row)
+                    const float gs = row16_sum(lnfold_sum4(v.x, v.y, v.z, v.w));
+                    const float gq = row16_sum(lnfold_dev4(v.x, v.y, v.z, v.w, gs * (1.0f / 64.0f)));
+                    if (m < p.M) {
+                        typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                        __builtin_nontemporal_store(__builtin_bit_cast(u32x2_t, pack4<TT>(v.x, v.y, v.z, v.w)),
+                                                    (u32x2_t*)((u16*)p.x16 + (size_t)m * p.ldx16 + nb + ((pc ^ (row & 15)) << 2)));
+                        if (pc == 0) p.stat_out[(size_t)(nb >> 6) * p.stat_ld + m] = float2{gs, gq};
+                    }
                 }
             }
         }
@@ -383,6 +427,9 @@ hipError_t launch256h(const GemmArgs& p_in, int epi, hipStream_t s) {
         LEAF_CASE(EPI_ACT_T)
         LEAF_CASE(EPI_RESID_F32)
         LEAF_CASE(EPI_STORE_F32)
+        LEAF_CASE(EPI_LNFOLD_T)
+        LEAF_CASE(EPI_LNFOLD_ACT_T)
+        LEAF_CASE(EPI_RESID_LN)
         default: return hipErrorInvalidValue;
     }
 #undef LEAF_CASE
@@ -393,11 +440,16 @@ hipError_t launch256h(const GemmArgs& p_in, int epi, hipStream_t s) {
 
 int leaf_gemm256h_pick_ngroup(const GemmArgs& p) { return pick_ngroup(p); }
 
+// fewest 256^2 tiles for which this kernel is dispatched (tuned default below; leaf_debug_gemm_min_tiles / LEAF_GEMM256H_MIN_TILES)
+static int g_min_tiles = -1;
+void leaf_gemm256h_set_min_tiles(int n) { g_min_tiles = n; }
+
 bool leaf_gemm256h_eligible(const GemmArgs& p, int epi) {
+    if (g_min_tiles < 0) { const char* e = getenv("LEAF_GEMM256H_MIN_TILES"); g_min_tiles = e ? atoi(e) : 128; }
     const long tiles = (long)((p.M + BM - 1) / BM) * (p.N / BN);
     // the DMA sources are 32-bit byte offsets from the operand bases (saddr + voffset): both operands must span < 4 GiB
     const bool fits32 = (unsigned long long)p.M * p.lda * 2ull < (1ull << 32) && (unsigned long long)p.N * p.ldb * 2ull < (1ull << 32);
-    return p.N % BN == 0 && tiles >= 128 && p.K % BK == 0 && p.K >= 4 * BK && p.ldc % 8 == 0 && epi != EPI_ACTGRAD_T && fits32;
+    return p.N % BN == 0 && tiles >= g_min_tiles && p.K % BK == 0 && p.K >= 4 * BK && p.ldc % 8 == 0 && epi != EPI_ACTGRAD_T && fits32;
 }
 
 hipError_t leaf_launch_gemm256h(const GemmArgs& p, int dtype, int epi, hipStream_t s) {

@@ -170,6 +170,9 @@ hipError_t launch64(const GemmArgs& p, int epi, hipStream_t s) {
         LEAF_CASE(EPI_RESID_F32)
         LEAF_CASE(EPI_STORE_F32)
         LEAF_CASE(EPI_ACTGRAD_T)
+        LEAF_CASE(EPI_LNFOLD_T)
+        LEAF_CASE(EPI_LNFOLD_ACT_T)
+        LEAF_CASE(EPI_RESID_LN)
         default: return hipErrorInvalidValue;
     }
 #undef LEAF_CASE

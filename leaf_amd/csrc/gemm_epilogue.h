@@ -5,6 +5,7 @@
 
 #include "common.h"
 #include "kernels.h"
+#include "lnfold.h"
 
 namespace {
 
@@ -21,32 +22,61 @@ __device__ __forceinline__ void epilogue_block(const GemmArgs& p, const int (&m)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) acc[i][j] *= al;
     }
-    if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32) {
+    if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32 || EPI == EPI_RESID_LN) {
+        constexpr bool RESID = (EPI == EPI_RESID_F32 || EPI == EPI_RESID_LN);
         float4 r[NI][NJ];
-        const bool rd = (EPI == EPI_RESID_F32) || p.beta != 0.f;
+        const bool rd = RESID || p.beta != 0.f;
         // residual source: p.aux when given (out-of-place: the training forward keeps both x and x + f(x)), else C itself
-        const float* rsrc = (EPI == EPI_RESID_F32 && p.aux) ? (const float*)p.aux : (const float*)p.C;
+        const float* rsrc = (RESID && p.aux) ? (const float*)p.aux : (const float*)p.C;
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
                 r[i][j] = (rd && m[i] < p.M) ? *(const float4*)(rsrc + (size_t)m[i] * p.ldc + nbase + 16 * j)
                                              : float4{0.f, 0.f, 0.f, 0.f};
-        const float beta = (EPI == EPI_RESID_F32) ? 1.f : p.beta;
+        const float beta = RESID ? 1.f : p.beta;
 #pragma unroll
-        for (int i = 0; i < NI; ++i)
+        for (int i = 0; i < NI; ++i) {
+            float4 o[NJ];
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                if (m[i] >= p.M) continue;
                 // (acc + bias) first, then ONE fused multiply-add with the residual: the same association in every GEMM
                 // kernel, so a row's result does not depend on which kernel the tile-count dispatch picked
-                float4 o;
-                o.x = __builtin_fmaf(r[i][j].x, beta, acc[i][j][0] + bias[j].x);
-                o.y = __builtin_fmaf(r[i][j].y, beta, acc[i][j][1] + bias[j].y);
-                o.z = __builtin_fmaf(r[i][j].z, beta, acc[i][j][2] + bias[j].z);
-                o.w = __builtin_fmaf(r[i][j].w, beta, acc[i][j][3] + bias[j].w);
-                *(float4*)((float*)p.C + (size_t)m[i] * p.ldc + nbase + 16 * j) = o;
+                o[j].x = __builtin_fmaf(r[i][j].x, beta, acc[i][j][0] + bias[j].x);
+                o[j].y = __builtin_fmaf(r[i][j].y, beta, acc[i][j][1] + bias[j].y);
+                o[j].z = __builtin_fmaf(r[i][j].z, beta, acc[i][j][2] + bias[j].z);
+                o[j].w = __builtin_fmaf(r[i][j].w, beta, acc[i][j][3] + bias[j].w);
+                if (m[i] < p.M) *(float4*)((float*)p.C + (size_t)m[i] * p.ldc + nbase + 16 * j) = o[j];
             }
+            if constexpr (EPI == EPI_RESID_LN) {
+                // LN folding (lnfold.h): 16-bit copy + (sum, M2) of the row's 64-column group.  This lane holds chunk 4 j + fq
+                // of the group (fq = lane >> 4): butterfly over the chunk bits 0, 1 (lanes ^ 16, ^ 32), then 2, 3 (registers) --
+                // the same tree as the 16-lane row reduction of gemm256h.hip
+                static_assert(EPI != EPI_RESID_LN || NJ == 4, "a wave owns whole 64-column groups");
+                float t[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    t[j] = lnfold_sum4(o[j].x, o[j].y, o[j].z, o[j].w);
+                    t[j] += __shfl_xor(t[j], 16, 64);
+                    t[j] += __shfl_xor(t[j], 32, 64);
+                }
+                const float gs = (t[0] + t[1]) + (t[2] + t[3]);
+                const float gm = gs * (1.0f / 64.0f);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    t[j] = lnfold_dev4(o[j].x, o[j].y, o[j].z, o[j].w, gm);
+                    t[j] += __shfl_xor(t[j], 16, 64);
+                    t[j] += __shfl_xor(t[j], 32, 64);
+                }
+                const float gq = (t[0] + t[1]) + (t[2] + t[3]);
+                if (m[i] < p.M) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        *(uint2*)((u16*)p.x16 + (size_t)m[i] * p.ldx16 + nbase + 16 * j) = pack4<TT>(o[j].x, o[j].y, o[j].z, o[j].w);
+                    if ((threadIdx.x & 63) < 16) p.stat_out[(size_t)((nbase & ~63) >> 6) * p.stat_ld + m[i]] = float2{gs, gq};
+                }
+            }
+        }
     } else if constexpr (EPI == EPI_ACTGRAD_T) {
         uint2 u[NI][NJ];
 #pragma unroll
@@ -67,6 +97,18 @@ __device__ __forceinline__ void epilogue_block(const GemmArgs& p, const int (&m)
                 *(uint2*)((u16*)p.C + (size_t)m[i] * p.ldc + nbase + 16 * j) = pack4<TT>(v[0], v[1], v[2], v[3]);
             }
     } else {
+        constexpr bool FOLD = (EPI == EPI_LNFOLD_T || EPI == EPI_LNFOLD_ACT_T);
+        constexpr bool ACTIVE = (EPI == EPI_ACT_T || EPI == EPI_LNFOLD_ACT_T);
+        // LN folding: (mean, rstd) of this lane's rows, s[n] for its columns
+        float2 rs[NI];
+        float4 s4[NJ];
+        if constexpr (FOLD) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                rs[i] = m[i] < p.M ? p.rowstat[m[i]] : float2{0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) s4[j] = *(const float4*)(p.ln_s + nbase + 16 * j);
+        }
         // the activation id is fixed at compile time inside the element loops (act_fwd_t, common.h)
         auto body = [&](auto ACTC) {
             constexpr int ACT = decltype(ACTC)::value;
@@ -75,18 +117,26 @@ __device__ __forceinline__ void epilogue_block(const GemmArgs& p, const int (&m)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     if (m[i] >= p.M) continue;
-                    float v[4] = {acc[i][j][0] + bias[j].x, acc[i][j][1] + bias[j].y, acc[i][j][2] + bias[j].z,
-                                  acc[i][j][3] + bias[j].w};
+                    float v[4];
+                    if constexpr (FOLD) {
+                        v[0] = lnfold_apply(acc[i][j][0], rs[i].x, rs[i].y, s4[j].x, bias[j].x);
+                        v[1] = lnfold_apply(acc[i][j][1], rs[i].x, rs[i].y, s4[j].y, bias[j].y);
+                        v[2] = lnfold_apply(acc[i][j][2], rs[i].x, rs[i].y, s4[j].z, bias[j].z);
+                        v[3] = lnfold_apply(acc[i][j][3], rs[i].x, rs[i].y, s4[j].w, bias[j].w);
+                    } else {
+                        v[0] = acc[i][j][0] + bias[j].x; v[1] = acc[i][j][1] + bias[j].y;
+                        v[2] = acc[i][j][2] + bias[j].z; v[3] = acc[i][j][3] + bias[j].w;
+                    }
                     const size_t o = (size_t)m[i] * p.ldc + nbase + 16 * j;
-                    if constexpr (EPI == EPI_ACT_T) {
-                        if (p.aux) *(uint2*)((u16*)p.aux + o) = pack4<TT>(v[0], v[1], v[2], v[3]);
+                    if constexpr (ACTIVE) {
+                        if (EPI == EPI_ACT_T && p.aux) *(uint2*)((u16*)p.aux + o) = pack4<TT>(v[0], v[1], v[2], v[3]);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = act_fwd_t<ACT>(v[e]);
                     }
                     *(uint2*)((u16*)p.C + o) = pack4<TT>(v[0], v[1], v[2], v[3]);
                 }
         };
-        if constexpr (EPI != EPI_ACT_T) body(std::integral_constant<int, -1>());
+        if constexpr (!ACTIVE) body(std::integral_constant<int, -1>());
         else if (p.act == ACT_QUICKGELU) body(std::integral_constant<int, ACT_QUICKGELU>());
         else body(std::integral_constant<int, ACT_GELU>());
     }

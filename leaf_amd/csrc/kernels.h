@@ -13,7 +13,14 @@ enum {
     EPI_RESID_F32 = 2,  // C32 += acc + bias        (residual stream, in place)
     EPI_STORE_F32 = 3,  // C32 = beta*C32 + acc + bias
     EPI_ACTGRAD_T = 4,  // C16 = acc * act'(aux16)
+    // ---- LayerNorm folded into the GEMMs of the forward-only passes (lnfold.h): the residual GEMMs also emit the 16-bit
+    // copy of the new residual row and its per-64-column statistics; the consuming GEMM multiplies that RAW 16-bit row with
+    // gamma-scaled weights and applies mean / rstd in its epilogue.  No LayerNorm kernel, no LayerNorm output in HBM.
+    EPI_LNFOLD_T = 5,     // C16 = rstd[m] * (acc - mean[m] * ln_s[n]) + bias[n]   ((mean, rstd) = rowstat[m]; bias = LN-beta . W^T + linear bias)
+    EPI_LNFOLD_ACT_T = 6, // C16 = act(the same)
+    EPI_RESID_LN = 7,     // C32 += acc + bias;  x16[m,n] = 16-bit(C32);  stat_out[n / 64][m] = (sum, M2) of that row's 64 columns
 };
+
 
 struct GemmArgs {
     const void* A;  // [M,K] 16-bit, row stride lda (elements)
@@ -28,6 +35,14 @@ struct GemmArgs {
     void* stamps; // diagnostic builds only (-DLEAF_GEMM_STAMPS)
     const float* alpha;  // optional DEVICE scalar multiplying the accumulator (gradient un-scaling), or null
     int ngroup;   // tile order of the 256^2 kernels: N tiles per group (0 = all: M-major / N-minor over the whole matrix)
+    // LayerNorm folding (EPI_LNFOLD_* read rowstat / ln_s, EPI_RESID_LN writes x16 / stat_out); the partial statistics are
+    // laid out [64-column group][row] with row stride stat_ld, one (sum, M2) pair per (group, row)
+    const float* ln_s;        // [N] row sums of the gamma-scaled 16-bit weights
+    const float2* rowstat;    // [M] (mean, rstd) of the A rows (leaf_launch_ln_finalize of the producer's partials)
+    float2* stat_out;         // [N / 64][stat_ld]
+    void* x16;                // [M, N] 16-bit copy of the fp32 output, row stride ldx16
+    int stat_ld, ldx16;
+    float ln_eps;
 };
 
 hipError_t leaf_launch_gemm(const GemmArgs& p, int dtype, int epi, hipStream_t s);
@@ -35,6 +50,7 @@ void leaf_gemm_set_stamps(void* p);
 int leaf_gemm_family(const GemmArgs& p, int epi);   // 0 = gemm_nt_kernel, 1 = gemm_nt256_kernel (gemm.hip), 4 = half-stage ring, 6 = gemm64
 // 256 x 256 tile, 64-deep half-stage LDS-DMA ring with full-line pieces (gemm256h.hip): the kernel of every launch with >= 128 tiles
 bool leaf_gemm256h_eligible(const GemmArgs& p, int epi);
+void leaf_gemm256h_set_min_tiles(int n);
 int leaf_gemm256h_pick_ngroup(const GemmArgs& p);   // N tiles per L2-sized group (0 = one group)
 hipError_t leaf_launch_gemm256h(const GemmArgs& p, int dtype, int epi, hipStream_t s);
 // 64 x 128 tiles on a 3-slot LDS-DMA ring for small launches (gemm64.hip)
@@ -47,6 +63,18 @@ hipError_t leaf_launch_embed_ln(const int32_t* tokens, const float* tok_emb, con
                                 const float* b, float eps, float* x, void* xn, int rows, int n_seq, RowMap map, int d,
                                 int vocab, int dtype, hipStream_t s, const float* delta = nullptr /* [rows,d] additive embedding perturbation */);
 hipError_t leaf_launch_layernorm(const float* x, const float* g, const float* b, float eps, void* xn, int rows, int d,
+                                 int dtype, hipStream_t s);
+// LN-folded forward (lnfold.h): x = tok_emb[token] + pos_emb[pos] (+ delta), its 16-bit copy and per-64-column (sum, M2)
+hipError_t leaf_launch_embed_fold(const int32_t* tokens, const float* tok_emb, const float* pos_emb, float* x, void* x16,
+                                  float2* stat, int stat_ld, int rows, int n_seq, RowMap map, int d, int vocab, int dtype,
+                                  hipStream_t s, const float* delta = nullptr);
+// rowstat[m] = (mean, rstd) of row m from the [ngroups][ld] (sum, M2) partials (Chan merge, lnfold.h)
+hipError_t leaf_launch_ln_finalize(const float2* stat, int ld, int rows, int ngroups, float eps, float2* rowstat, hipStream_t s);
+// gamma-scaled 16-bit QKV / c_fc weights W'[n,:] = 16-bit(g * W[n,:]) of ALL layers and their vectors s[n] = sum W'[n,:],
+// c[n] = b . W[n,:] + bias[n] in one launch; layer l's operands sit l * {w,v,wp,aux}_stride elements behind layer 0's
+hipError_t leaf_launch_fold_pack(const float* qkv_w, const float* fc_w, size_t w_stride, const float* ln1_w, const float* ln1_b,
+                                 const float* qkv_b, const float* ln2_w, const float* ln2_b, const float* fc_b, size_t v_stride,
+                                 void* qkv_p, void* fc_p, size_t wp_stride, float* aux, size_t aux_stride, int d, int layers,
                                  int dtype, hipStream_t s);
 // out[n,:] = LN_final(x[n*ctx + eot(n),:]) @ P  (fp32 math), optional L2 normalisation; pooled (optional) keeps
 // the normalised EOT row and eot_idx the pooled position (training stash).

@@ -263,3 +263,115 @@ def test_gemm_rows_do_not_depend_on_the_kernel(env, N, K):
 
     for epi, act in ((0, 0), (1, 0), (1, 1), (2, 0), (3, 0)):
         assert torch.equal(run(epi, M, act), run(epi, CH, act)), f"epilogue {epi} act {act}"
+
+
+def _fold_problem(rng, M, d, N, dev, torch):
+    """A residual GEMM that PRODUCES a row (out_proj shape d x d) followed by the LN-folded consumer (N x d)."""
+    A = rng.standard_normal((M, d), dtype=np.float32)
+    Wo = (rng.standard_normal((d, d), dtype=np.float32) * 0.05).astype(np.float32)
+    bo = rng.standard_normal(d).astype(np.float32)
+    x0 = (rng.standard_normal((M, d)) * 2.0 + rng.standard_normal((M, 1)) * 3.0).astype(np.float32)   # rows with a sizeable mean
+    x0[:, 5] += 300.0                                                                                  # and one outlier channel
+    g = (1.0 + 0.1 * rng.standard_normal(d)).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(d)).astype(np.float32)
+    W = (rng.standard_normal((N, d)) * 0.05 + np.arange(N)[:, None] * 1e-4).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    return A, Wo, bo, x0, g, beta, W, bias
+
+
+@pytest.mark.parametrize("M,d,N", [(300, 128, 256), (3000, 768, 2304), (40000, 768, 3072), (9000, 1280, 1280)])
+def test_lnfold_gemm_pair_vs_numpy(env, M, d, N):
+    """lnfold.h: producer epilogue (fp32 residual + 16-bit copy + per-group statistics) and consumer epilogue
+    (rstd (acc - mean s) + c [+ activation]) against a float64 LayerNorm + linear of the same rows; small launches run the
+    register-direct kernels, the 40,000-row one the 256^2 half-stage kernel."""
+    lib, torch, dev = env
+    from leaf_amd import _lib
+    rng = np.random.default_rng(M + d + N)
+    A, Wo, bo, x0, g, beta, W, bias = _fold_problem(rng, M, d, N, dev, torch)
+    a16, wo16 = to16(A, "fp16", dev), to16(Wo, "fp16", dev)
+    x = torch.from_numpy(x0).to(dev)
+    x16 = torch.zeros(M, d, dtype=torch.float16, device=dev)
+    stat = torch.zeros(d // 64, M, 2, dtype=torch.float32, device=dev)
+    _lib.check(lib.leaf_op_gemm_resid_ln(1, ptr(a16), ptr(wo16), ptr(x), ptr(torch.from_numpy(bo).to(dev)), ptr(x16), ptr(stat),
+                                         M, d, d, stream()), "resid_ln")
+    torch.cuda.synchronize()
+    xr = x.cpu().numpy()
+    want_x = x0 + O.round_fp16(A).astype(np.float64) @ O.round_fp16(Wo).astype(np.float64).T + bo
+    assert rel_l2(xr, want_x) < 1e-5
+    assert torch.equal(x16, x.half()), "x16 must be the 16-bit rounding of the fp32 result"
+    grp = xr.astype(np.float64).reshape(M, d // 64, 64)
+    st = stat.cpu().numpy()
+    assert np.allclose(st[:, :, 0].T, grp.sum(-1), rtol=1e-5, atol=1e-3)
+    assert np.allclose(st[:, :, 1].T, ((grp - grp.mean(-1, keepdims=True)) ** 2).sum(-1), rtol=1e-4)
+    # consumer: gamma-scaled weights, s, c as the pack kernel builds them
+    wp = O.round_fp16((W * g[None, :]).astype(np.float32))
+    s_vec = wp.sum(-1, dtype=np.float64).astype(np.float32)
+    c_vec = (W.astype(np.float64) @ beta + bias).astype(np.float32)
+    wp16 = to16(wp, "fp16", dev)
+    ts, tc = torch.from_numpy(s_vec).to(dev), torch.from_numpy(c_vec).to(dev)
+    x64 = xr.astype(np.float64)
+    mu = x64.mean(-1, keepdims=True)
+    rstd = 1.0 / np.sqrt(x64.var(-1, keepdims=True) + 1e-5)
+    ln16 = ((x16.float().cpu().numpy().astype(np.float64) - mu) * rstd)                # what the folded GEMM effectively multiplies
+    want = ln16 @ wp.astype(np.float64).T + c_vec
+    exact = ((x64 - mu) * rstd * g + beta) @ W.astype(np.float64).T + bias             # the unrounded LayerNorm + linear
+    rowstat = torch.zeros(M, 2, dtype=torch.float32, device=dev)
+    _lib.check(lib.leaf_op_ln_finalize(ptr(stat), M, M, d // 64, 1e-5, ptr(rowstat), stream()), "ln_finalize")
+    torch.cuda.synchronize()
+    rsn = rowstat.cpu().numpy()
+    assert np.allclose(rsn[:, 0], mu[:, 0], rtol=1e-5, atol=1e-5) and np.allclose(rsn[:, 1], rstd[:, 0], rtol=2e-6)
+    for act, fn in ((-1, None), (0, O.gelu), (1, O.quick_gelu)):
+        y = torch.zeros(M, N, dtype=torch.float16, device=dev)
+        _lib.check(lib.leaf_op_gemm_lnfold(1, act, ptr(x16), ptr(wp16), ptr(y), ptr(tc), ptr(ts), ptr(rowstat), M, N, d, stream()),
+                   "lnfold")
+        torch.cuda.synchronize()
+        w_ = want if fn is None else fn(want.astype(np.float32))
+        e_ = exact if fn is None else fn(exact.astype(np.float32))
+        got = y.float().cpu().numpy()
+        assert rel_l2(got, w_) < 1e-3, act          # same operands: fp32 accumulation + one fp16 rounding of the output
+        assert rel_l2(got, e_) < 3e-3, act          # against the exact LN + linear: operand rounding only
+
+
+@pytest.mark.parametrize("d,N", [(768, 2304), (768, 3072), (1024, 4096)])
+def test_lnfold_rows_do_not_depend_on_the_kernel(env, d, N):
+    """The folded pair must give BIT-identical rows whichever kernel family the tile-count dispatch picks for the producer and
+    for the consumer (one big launch: 256^2 half-stage ring; chunks of 1,500 rows: the 64 x 128 ring; both orders mixed)."""
+    lib, torch, dev = env
+    from leaf_amd import _lib
+    M, CH = 24000, 1500
+    rng = np.random.default_rng(d + N)
+    A, Wo, bo, x0, g, beta, W, bias = _fold_problem(rng, M, d, N, dev, torch)
+    a16, wo16 = to16(A, "fp16", dev), to16(Wo, "fp16", dev)
+    tbo = torch.from_numpy(bo).to(dev)
+    wp = O.round_fp16((W * g[None, :]).astype(np.float32))
+    wp16 = to16(wp, "fp16", dev)
+    ts = torch.from_numpy(wp.sum(-1, dtype=np.float64).astype(np.float32)).to(dev)
+    tc = torch.from_numpy((W.astype(np.float64) @ beta + bias).astype(np.float32)).to(dev)
+
+    def run(rows_p, rows_c):
+        x = torch.from_numpy(x0).to(dev)
+        x16 = torch.zeros(M, d, dtype=torch.float16, device=dev)
+        stat_chunks, ys = [], []
+        for r0 in range(0, M, rows_p):
+            r1 = min(M, r0 + rows_p)
+            st = torch.zeros(d // 64, r1 - r0, 2, dtype=torch.float32, device=dev)
+            _lib.check(lib.leaf_op_gemm_resid_ln(1, ptr(a16[r0:r1]), ptr(wo16), ptr(x[r0:r1]), ptr(tbo), ptr(x16[r0:r1]), ptr(st),
+                                                 r1 - r0, d, d, stream()), "resid_ln")
+            stat_chunks.append(st)
+        stat = torch.cat(stat_chunks, 1).contiguous()
+        rowstat = torch.zeros(M, 2, dtype=torch.float32, device=dev)
+        _lib.check(lib.leaf_op_ln_finalize(ptr(stat), M, M, d // 64, 1e-5, ptr(rowstat), stream()), "ln_finalize")
+        for r0 in range(0, M, rows_c):
+            r1 = min(M, r0 + rows_c)
+            y = torch.zeros(r1 - r0, N, dtype=torch.float16, device=dev)
+            _lib.check(lib.leaf_op_gemm_lnfold(1, 1, ptr(x16[r0:r1]), ptr(wp16), ptr(y), ptr(tc), ptr(ts), ptr(rowstat[r0:r1]), r1 - r0, N, d,
+                                               stream()), "lnfold")
+            ys.append(y)
+        torch.cuda.synchronize()
+        return x, x16, stat, torch.cat(ys)
+
+    ref = run(M, M)
+    for rp, rc in ((CH, CH), (M, CH), (CH, M)):
+        got = run(rp, rc)
+        for name, a, b in zip(("x", "x16", "stat", "y"), ref, got):
+            assert torch.equal(a, b), f"{name} differs between launch sizes producer={rp} consumer={rc}"
