@@ -39,7 +39,10 @@ def main(argv=None):
     ap.add_argument("--dictionary-file", default=None)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--out-dir", default="results_textfare")
+    ap.add_argument("--random-init", action="store_true", help="allow --clean to be omitted (seeded random weights)")
     a = ap.parse_args(argv)
+    if not a.clean and not a.random_init and not a.model.startswith("tiny-test"):
+        raise SystemExit("--clean is empty: pass the clean checkpoint, or --random-init to evaluate seeded random weights on purpose")
     V = [-1] + [ord(c) for c in string.ascii_lowercase + ' ' + string.ascii_uppercase + string.digits + string.punctuation]
     np.random.seed(a.seed)
     clean = create_model(a.model, pretrained=a.clean, seed=1)

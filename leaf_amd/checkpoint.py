@@ -4,7 +4,9 @@ The map restates what the reference's converters do tensor by tensor
 (conversion/convert_2.py:37-99, conversion/convert_to_openclip.py:78-121): q/k/v are the three row chunks
 of ``in_proj_*``; ``text_projection.weight`` (HF, nn.Linear) is ``text_projection`` (OpenCLIP, applied as
 ``x @ P``) transposed; ``fc1/fc2`` are ``c_fc/c_proj``; ``layer_norm1/2`` are ``ln_1/ln_2``.
-The training checkpoint dict layout is the reference's (train_AT_text_only.py:516-525).
+The training checkpoint dict layout is the reference's (train_AT_text_only.py:516-525): ``optimizer`` is a
+``torch.optim.AdamW.state_dict()`` with the reference's two parameter groups in its ``named_parameters`` order
+(:326-341), so ``--resume`` of either code base loads the other's ``epoch_latest.pt`` (:351-372).
 """
 from __future__ import annotations
 
@@ -81,6 +83,137 @@ def to_openclip_text_keys(sd, cfg) -> Dict[str, torch.Tensor]:
     return out
 
 
+def non_text_tensors(sd) -> Dict[str, torch.Tensor]:
+    """Every tensor of an OpenCLIP checkpoint that is NOT part of the text tower (visual.*, logit_bias, ...), on the host; {} for
+    HF checkpoints.  Carried through training so that the written state_dict stays loadable by the reference."""
+    if "state_dict" in sd and isinstance(sd["state_dict"], dict):
+        sd = sd["state_dict"]
+    if any(k.startswith("text_model.") for k in sd):
+        return {}
+    out = {}
+    for k, v in sd.items():
+        k2 = k[len("module."):] if k.startswith("module.") else k
+        if not k2.startswith(_TEXT_PREFIXES) and k2 != "logit_scale" and hasattr(v, "shape"):
+            out[k2] = _t(v).detach().cpu()
+    return out
+
+
+# ----------------------------------------------------------------------------- reference AdamW state_dict layout
+def reference_param_groups(layers: int):
+    """Names of the reference's two AdamW groups in ITS order (train_AT_text_only.py:323-341 over CLIP.named_parameters() with the
+    image tower frozen, :489-490): group 0 = excluded from weight decay (p.ndim < 2 or 'bn' / 'ln' / 'bias' / 'logit_scale' in the
+    name), group 1 = the rest.  Module registration order of open_clip's CLIP: positional_embedding, text_projection, logit_scale,
+    (visual.*), transformer.resblocks.*, token_embedding, ln_final.  Pinned by tests/golden/ckpt_structure.json."""
+    order = ["positional_embedding", "text_projection", "logit_scale"]
+    for i in range(layers):
+        p = f"transformer.resblocks.{i}."
+        order += [p + n for n in ("ln_1.weight", "ln_1.bias", "attn.in_proj_weight", "attn.in_proj_bias", "attn.out_proj.weight",
+                                  "attn.out_proj.bias", "ln_2.weight", "ln_2.bias", "mlp.c_fc.weight", "mlp.c_fc.bias",
+                                  "mlp.c_proj.weight", "mlp.c_proj.bias")]
+    order += ["token_embedding.weight", "ln_final.weight", "ln_final.bias"]
+    one_d = lambda n: n in ("logit_scale",) or n.endswith((".bias", "ln_1.weight", "ln_2.weight", "ln_final.weight"))
+    excl = lambda n: one_d(n) or "bn" in n or "ln" in n or "bias" in n or "logit_scale" in n
+    return [n for n in order if excl(n)], [n for n in order if not excl(n)]
+
+
+_GROUP_DEFAULTS = dict(amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
+                       decoupled_weight_decay=True)
+
+
+def optimizer_state_to_torch(layout, layers, exp_avg, exp_avg_sq, step, lr, betas, eps, weight_decay, lrs=None):
+    """Flat fp32 moments (engine layout: name -> (offset, shape)) -> torch.optim.AdamW.state_dict() as the reference's optimizer
+    would write it: param ids number group 0 then group 1; ``logit_scale`` (id 0) never receives a gradient, so -- exactly as in
+    the reference -- it has no state entry; every other parameter carries the common ``step`` as a 0-d fp32 tensor."""
+    g0, g1 = reference_param_groups(layers)
+    names = g0 + g1
+    state = {}
+    for pid, n in enumerate(names):
+        if n not in layout:
+            continue
+        off, shape = layout[n]
+        numel = int(np.prod(shape))
+        if step > 0:
+            state[pid] = {"step": torch.tensor(float(step), dtype=torch.float32),
+                          "exp_avg": exp_avg[off:off + numel].reshape(shape).detach().cpu().clone(),
+                          "exp_avg_sq": exp_avg_sq[off:off + numel].reshape(shape).detach().cpu().clone()}
+    lrs = lrs or (lr, lr)
+    groups = [dict(lr=lrs[0], betas=tuple(betas), eps=eps, weight_decay=0.0, **_GROUP_DEFAULTS, params=list(range(len(g0)))),
+              dict(lr=lrs[1], betas=tuple(betas), eps=eps, weight_decay=weight_decay, **_GROUP_DEFAULTS,
+                   params=list(range(len(g0), len(names))))]
+    return {"state": state, "param_groups": groups}
+
+
+def optimizer_state_from_torch(osd, layout, layers, exp_avg, exp_avg_sq) -> int:
+    """Inverse of ``optimizer_state_to_torch`` (also reads a checkpoint the REFERENCE wrote): copies every parameter's moments
+    into the flat buffers, returns the step count.  Raises when the groups do not have the reference's sizes."""
+    g0, g1 = reference_param_groups(layers)
+    names = g0 + g1
+    pg = osd["param_groups"]
+    if len(pg) != 2 or len(pg[0]["params"]) != len(g0) or len(pg[1]["params"]) != len(g1):
+        raise ValueError(f"optimizer state does not have the reference's two groups ({len(g0)} + {len(g1)} parameters)")
+    ids = list(pg[0]["params"]) + list(pg[1]["params"])
+    step = 0
+    exp_avg.zero_()
+    exp_avg_sq.zero_()
+    for pid, n in zip(ids, names):
+        st = osd["state"].get(pid)
+        if st is None or n not in layout:
+            continue
+        off, shape = layout[n]
+        numel = int(np.prod(shape))
+        if tuple(st["exp_avg"].shape) != tuple(shape):
+            raise ValueError(f"optimizer state of {n}: shape {tuple(st['exp_avg'].shape)} != {tuple(shape)}")
+        exp_avg[off:off + numel].copy_(st["exp_avg"].reshape(-1))
+        exp_avg_sq[off:off + numel].copy_(st["exp_avg_sq"].reshape(-1))
+        step = max(step, int(float(st["step"])))
+    return step
+
+
+# ----------------------------------------------------------------------------- open_clip_config.json / HF export
+def read_open_clip_config(path: str):
+    """``open_clip_config.json`` next to a hub checkpoint (src/open_clip/factory.py:200-207 ``_get_hf_config``):
+    {"model_cfg": {"embed_dim", "quick_gelu"?, "text_cfg": {"context_length", "vocab_size", "width", "heads", "layers"}}, ...}.
+    ``path`` may be the json, the checkpoint file beside it or the directory.  Returns a TextConfig or None."""
+    import json
+    from .model import TextConfig
+    if os.path.isdir(path):
+        cand = os.path.join(path, "open_clip_config.json")
+    elif os.path.basename(path) == "open_clip_config.json":
+        cand = path
+    else:
+        cand = os.path.join(os.path.dirname(path) or ".", "open_clip_config.json")
+    if not os.path.exists(cand):
+        return None
+    with open(cand) as f:
+        cfg = json.load(f)
+    mc = cfg.get("model_cfg", cfg)
+    t = mc["text_cfg"]
+    return TextConfig(width=t.get("width", 512), heads=t.get("heads", 8), layers=t.get("layers", 12), embed_dim=mc["embed_dim"],
+                      context_length=t.get("context_length", 77), vocab_size=t.get("vocab_size", 49408),
+                      quick_gelu=bool(mc.get("quick_gelu", False)))
+
+
+def write_hf_text_model(out_dir: str, sd: Dict[str, torch.Tensor], cfg, with_projection: bool = True):
+    """The release format of the reference (README.md:98; conversion/convert_2.py:37-99,133-203): a HuggingFace
+    ``CLIPTextModelWithProjection`` (``CLIPTextModel`` when ``with_projection`` is False: its embedding is the pooled EOT
+    state, utils_attacks.py:49-53) as ``model.safetensors`` + ``config.json``; ``hidden_act`` = quick_gelu for the OpenAI-lineage
+    B/L towers, gelu for H/g/bigG (convert_2.py:133,154,185,203)."""
+    import json
+    from safetensors.torch import save_file
+    os.makedirs(out_dir, exist_ok=True)
+    hf = openclip_to_hf({k: _t(v).detach().cpu().float() for k, v in sd.items()}, cfg, with_projection=with_projection)
+    save_file({k: v.contiguous() for k, v in hf.items()}, os.path.join(out_dir, "model.safetensors"), metadata={"format": "pt"})
+    config = {"architectures": ["CLIPTextModelWithProjection" if with_projection else "CLIPTextModel"], "model_type": "clip_text_model",
+              "hidden_size": cfg.width, "intermediate_size": 4 * cfg.width, "num_attention_heads": cfg.heads,
+              "num_hidden_layers": cfg.layers, "hidden_act": "quick_gelu" if cfg.quick_gelu else "gelu",
+              "projection_dim": cfg.embed_dim, "max_position_embeddings": cfg.context_length, "vocab_size": cfg.vocab_size,
+              "layer_norm_eps": cfg.ln_eps, "attention_dropout": 0.0, "initializer_range": 0.02, "initializer_factor": 1.0,
+              "pad_token_id": 1, "bos_token_id": cfg.vocab_size - 2, "eos_token_id": cfg.vocab_size - 1, "torch_dtype": "float32"}
+    with open(os.path.join(out_dir, "config.json"), "w") as f:
+        json.dump(config, f, indent=2)
+    return out_dir
+
+
 def load_checkpoint_file(path: str) -> Dict[str, torch.Tensor]:
     """open_clip_pytorch_model.bin / epoch_latest.pt / *.safetensors / a directory holding one of them."""
     if os.path.isdir(path):
@@ -98,8 +231,8 @@ def load_checkpoint_file(path: str) -> Dict[str, torch.Tensor]:
 
 def save_training_checkpoint(path: str, epoch: int, name: str, model, optimizer_state: dict):
     """Atomic write of the reference's checkpoint dict (train_AT_text_only.py:516-525): tmp file + os.replace."""
-    ck = {"epoch": epoch, "name": name, "state_dict": {k: v.cpu() for k, v in model.state_dict().items()},
-          "optimizer": optimizer_state}
+    sd = {k: v.cpu() for k, v in model.state_dict().items()}
+    ck = {"epoch": epoch, "name": name, "state_dict": sd, "optimizer": optimizer_state}
     tmp = os.path.join(os.path.dirname(path) or ".", "tmp.pt")
     torch.save(ck, tmp)
     os.replace(tmp, path)

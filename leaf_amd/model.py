@@ -106,6 +106,9 @@ class LeafCLIPText:
             self.layout[name.value.decode()] = (off.value, shape)
             self.params[name.value.decode()] = self.flat[off.value: off.value + int(np.prod(shape))].view(shape)
         self.logit_scale = torch.tensor(math.log(1 / 0.07), device=self.device)  # carried for checkpoints only
+        # tensors of a loaded checkpoint outside the text tower (visual.*, ...): kept on the host and written back by
+        # state_dict(), so that epoch_latest.pt stays a FULL CLIP state_dict the reference's --resume / converters can load
+        self.extra_state: Dict[str, torch.Tensor] = {}
         self._ws: Dict[int, torch.Tensor] = {}
         self._packed = False
         # exact work skipping: compute only rows up to EOT (include/leaf_hip.h, "EOT trimming"); LEAF_PACK=0 disables
@@ -190,7 +193,10 @@ class LeafCLIPText:
     def load_state_dict(self, sd, strict: bool = True):
         """OpenCLIP text-tower keys (a full CLIP state_dict is accepted: visual.* is ignored, 'module.' stripped,
         factory.py:138-139) or HF CLIPTextModel / CLIPModel keys (conversion/convert_to_openclip.py:78-121)."""
-        from .checkpoint import to_openclip_text_keys
+        from .checkpoint import non_text_tensors, to_openclip_text_keys
+        extra = non_text_tensors(sd)
+        if extra:
+            self.extra_state = extra
         sd = to_openclip_text_keys(sd, self.cfg)
         missing = [k for k in self.params if k not in sd]
         if missing and strict:
@@ -208,13 +214,17 @@ class LeafCLIPText:
         return self
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
+        """OpenCLIP keys: the text tower (device tensors), ``logit_scale`` and every non-text tensor of the checkpoint this
+        model was loaded from (``visual.*`` etc., host tensors) -- a full CLIP ``state_dict`` when it started from one."""
         out = {k: v.detach().clone() for k, v in self.params.items()}
         out["logit_scale"] = self.logit_scale.detach().clone()
+        out.update(self.extra_state)
         return out
 
     def copy_from(self, other: "LeafCLIPText"):
         self.flat.copy_(other.flat)
         self.logit_scale = other.logit_scale.clone()
+        self.extra_state = dict(other.extra_state)
         self._packed = False
         return self
 
@@ -470,8 +480,13 @@ def create_model(name: str, device="cuda:0", dtype: str = None, pretrained: Opti
                  trainable: bool = False, seed: int = 1) -> LeafCLIPText:
     """open_clip.create_model equivalent for the text tower: random init (seeded) or a local checkpoint
     (OpenCLIP .bin/.pt or HF safetensors / directory).  ``hf-hub:`` ids map to their architecture; weights must be
-    given as a local path (there is no network on the build or GPU boxes)."""
-    m = LeafCLIPText(get_config(name), device=device, dtype=dtype, trainable=trainable)
+    given as a local path (there is no network on the build or GPU boxes).  An ``open_clip_config.json`` next to the
+    checkpoint (the hub layout, src/open_clip/factory.py:200-207) defines the architecture when present."""
+    cfg = None
+    if pretrained:
+        from .checkpoint import read_open_clip_config
+        cfg = read_open_clip_config(pretrained)
+    m = LeafCLIPText(cfg or get_config(name), device=device, dtype=dtype, trainable=trainable)
     if pretrained:
         from .checkpoint import load_checkpoint_file
         m.load_state_dict(load_checkpoint_file(pretrained))

@@ -92,6 +92,11 @@ def parse_args(args):
                                        "*bf16 -> bf16 operands; fp32 is not offered by the MFMA path")
     p.add_argument("--model", type=str, default="RN50")
     p.add_argument("--pretrained", default='', type=str, help="local checkpoint (OpenCLIP .bin/.pt, HF safetensors or a directory)")
+    p.add_argument("--random-init", default=False, action='store_true',
+                   help="train from seeded random weights on purpose (without it an empty --pretrained is an error)")
+    p.add_argument("--export-hf", type=str, default=None,
+                   help="after the last epoch also write the text tower as a HuggingFace CLIPTextModelWithProjection "
+                        "(model.safetensors + config.json) into this directory")
     p.add_argument("--force-quick-gelu", default=False, action='store_true')
     p.add_argument("--accum-freq", type=int, default=1)
     p.add_argument("--dist-backend", default="nccl", type=str)

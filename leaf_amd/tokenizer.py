@@ -147,11 +147,10 @@ def get_tokenizer(model_name: str = "", context_length: int = DEFAULT_CONTEXT_LE
     if _default is None or _default.context_length != context_length:
         _default = None
         if os.environ.get("LEAF_NATIVE_HOST", "1") != "0":
-            try:   # C++ threads for the batch paths (leaf_amd/csrc/host_text.cpp); same results
-                from .native_text import NativeTokenizer
-                _default = NativeTokenizer(context_length=context_length)
-            except Exception:
-                _default = None
-        if _default is None:
+            # C++ threads for the batch paths (leaf_amd/csrc/host_text.cpp); same results.  No silent fallback: if the
+            # library is missing or fails to load this raises (LEAF_NATIVE_HOST=0 selects the Python tokenizer on purpose).
+            from .native_text import NativeTokenizer
+            _default = NativeTokenizer(context_length=context_length)
+        else:
             _default = SimpleTokenizer(context_length=context_length)
     return _default

@@ -3,7 +3,7 @@
 Mirrors the reference's host orchestration around the hot path:
 
 * ``train_one_epoch_text_only``  utils_AT.py:262-426 (same argument list; ``loss`` and ``scaler`` are accepted and
-  unused -- the reference never uses ``loss`` either, and bf16 gradient operands need no loss scaling)
+  unused -- the reference never uses ``loss`` either; the fp16 gradient path carries its own device-side power-of-two loss scale)
 * ``cosine_lr`` / ``const_lr``   src/open_clip_train/scheduler.py:4-53
 * ``LeafAdamW``                  torch.optim.AdamW with the two groups of train_AT_text_only.py:323-341, executed
   by ONE fused HIP kernel over the flat parameter buffer after ONE flat RCCL all-reduce
@@ -110,18 +110,30 @@ class LeafAdamW:
         self.model.zero_grad()
 
     def state_dict(self):
-        m = self.model
-        return {"step": m.opt_step, "exp_avg": m.exp_avg.cpu(), "exp_avg_sq": m.exp_avg_sq.cpu(),
-                "layout": {k: (off, list(shape)) for k, (off, shape) in m.layout.items()},
-                "param_groups": [{k: v for k, v in g.items()} for g in self.param_groups]}
+        """torch.optim.AdamW.state_dict() of the reference's optimizer (two groups in its parameter order, per-parameter
+        step / exp_avg / exp_avg_sq views of the flat moments): what --resume of the reference loads (train_AT_text_only.py:366)."""
+        from .checkpoint import optimizer_state_to_torch
+        m, g = self.model, self.param_groups[1]
+        return optimizer_state_to_torch(m.layout, m.cfg.layers, m.exp_avg, m.exp_avg_sq, m.opt_step, g["lr"], g["betas"], g["eps"],
+                                        g["weight_decay"], lrs=(self.param_groups[0]["lr"], g["lr"]))
 
     def load_state_dict(self, sd):
+        """Accepts the torch AdamW layout (written here or by the reference) and the flat layout of round-1 checkpoints."""
         m = self.model
-        m.opt_step = int(sd["step"])
-        m.exp_avg.copy_(sd["exp_avg"])
-        m.exp_avg_sq.copy_(sd["exp_avg_sq"])
-        for g, s in zip(self.param_groups, sd["param_groups"]):
-            g.update({k: v for k, v in s.items() if k != "params"})
+        if "state" in sd and "param_groups" in sd:
+            from .checkpoint import optimizer_state_from_torch
+            m.opt_step = optimizer_state_from_torch(sd, m.layout, m.cfg.layers, m.exp_avg, m.exp_avg_sq)
+            saved = sd["param_groups"]
+        elif "exp_avg" in sd:
+            m.opt_step = int(sd["step"])
+            m.exp_avg.copy_(sd["exp_avg"])
+            m.exp_avg_sq.copy_(sd["exp_avg_sq"])
+            saved = sd["param_groups"]
+        else:
+            raise ValueError("unrecognised optimizer state (neither torch.optim.AdamW.state_dict() nor the flat layout)")
+        for g, s in zip(self.param_groups, saved):
+            g.update({k: v for k, v in s.items() if k in ("lr", "betas", "eps", "weight_decay")})
+            g["betas"] = tuple(g["betas"])
 
 
 # ----------------------------------------------------------------------------- data (captions only)
@@ -166,19 +178,31 @@ class TextLoader:
         self.epoch = epoch
 
     def _stream(self) -> Iterator[str]:
+        """Endless stream of this rank's captions.  A full pass that yields nothing (missing / unreadable shards, no .txt
+        members, fewer captions than ranks) raises instead of spinning forever -- under data parallelism a rank that hangs
+        here would deadlock the others' all-reduce."""
         rng = random.Random(self.seed + self.epoch)
         if self.captions is not None:
             idx = list(range(len(self.captions)))
             rng.shuffle(idx)
+            mine = idx[self.rank::self.world] or idx
+            if not mine:
+                raise RuntimeError("the caption source is empty")
             while True:
-                for i in idx[self.rank::self.world]:
+                for i in mine:
                     yield self.captions[i]
         else:
             shards = list(self.shards)
             rng.shuffle(shards)
             mine = shards[self.rank::self.world] or shards
             while True:
-                yield from _iter_tar_captions(mine)
+                n = 0
+                for cap in _iter_tar_captions(mine):
+                    n += 1
+                    yield cap
+                if n == 0:
+                    raise RuntimeError(f"rank {self.rank}: no caption (.txt member) found in a full pass over {len(mine)} shard(s), "
+                                       f"first: {mine[0] if mine else '<none>'} -- check --train-data")
 
     def __iter__(self):
         it = self._stream()
@@ -323,13 +347,21 @@ def save_checkpoint(path, epoch, name, model, optimizer):
 
 
 def load_checkpoint(path, model, optimizer=None):
+    """train_AT_text_only.py:351-372: a training checkpoint ({'epoch', 'name', 'state_dict', 'optimizer'}, written here or by
+    the reference) restores weights, AdamW moments and step; a bare state_dict restores the weights only.  Returns the epoch."""
     ck = torch.load(path, map_location="cpu", weights_only=False)
     if "epoch" in ck:
         model.load_state_dict(ck["state_dict"])
-        if optimizer is not None and "optimizer" in ck and "exp_avg" in ck["optimizer"]:
-            optimizer.load_state_dict(ck["optimizer"])
+        if optimizer is not None:
+            if "optimizer" in ck:
+                optimizer.load_state_dict(ck["optimizer"])
+                logging.info(f"=> optimizer state restored (step {model.opt_step})")
+            else:
+                logging.warning(f"=> checkpoint '{path}' carries no optimizer state: AdamW moments and step start from zero")
         model.pack()
         return ck["epoch"]
     model.load_state_dict(ck)
+    if optimizer is not None:
+        logging.warning(f"=> '{path}' is a bare state_dict: AdamW moments and step start from zero")
     model.pack()
     return 0

@@ -20,15 +20,54 @@ def test_train_cli_checkpoint_and_resume(tmp_path, monkeypatch):
     ck = torch.load(out / "epoch_latest.pt", map_location="cpu", weights_only=False)
     assert set(ck) == {"epoch", "name", "state_dict", "optimizer"} and ck["epoch"] == 1      # train_AT_text_only.py:516-525
     assert "transformer.resblocks.1.attn.in_proj_weight" in ck["state_dict"] and "logit_scale" in ck["state_dict"]
-    assert ck["optimizer"]["step"] == 3
+    # "optimizer" is torch.optim.AdamW.state_dict() in the reference's grouping (tests/test_checkpoint_cpu.py pins the layout)
+    osd = ck["optimizer"]
+    assert set(osd) == {"state", "param_groups"} and len(osd["param_groups"]) == 2 and 0 not in osd["state"]
+    assert float(osd["state"][1]["step"]) == 3 and osd["param_groups"][0]["weight_decay"] == 0.0
+    from leaf_amd.checkpoint import reference_param_groups
+    g0, g1 = reference_param_groups(2)
+    shapes = {k: tuple(v.shape) for k, v in ck["state_dict"].items()}
+    params = {k: torch.nn.Parameter(torch.zeros(shapes[k])) for k in g0 + g1}
+    ref_opt = torch.optim.AdamW([{"params": [params[k] for k in g0], "weight_decay": 0.0},
+                                 {"params": [params[k] for k in g1], "weight_decay": 1e-4}], lr=1e-4)
+    ref_opt.load_state_dict(osd)                       # what the reference's --resume does (train_AT_text_only.py:366)
+    assert float(ref_opt.state[params["text_projection"]]["exp_avg"].abs().sum()) > 0
     rows = open(out / "results.csv").read().strip().splitlines()
     assert len(rows) == 2 and "loss" in rows[0]
     assert os.path.exists(tmp_path / "logs" / "run" / "params.txt")
     assert cli.main(common + ["--epochs", "1"]) == -1                                         # experiment exists
     assert cli.main(common[:-1] + ["run2", "--epochs", "2", "--resume", str(out / "epoch_latest.pt")]) == 0
     ck2 = torch.load(out / "epoch_latest.pt", map_location="cpu", weights_only=False)
-    assert ck2["epoch"] == 2 and ck2["optimizer"]["step"] == 6
+    assert ck2["epoch"] == 2 and float(ck2["optimizer"]["state"][1]["step"]) == 6
     assert not torch.equal(ck["state_dict"]["text_projection"], ck2["state_dict"]["text_projection"])
+    rows = open(out / "results.csv").read().strip().splitlines()
+    assert len(rows) == 3 and rows[1].split(",")[0] in ("1", "1.0") and rows[2].split(",")[0] in ("2", "2.0"), "results.csv continues on resume"
+    # --resume latest finds the checkpoint in the results folder (the reference looks where it never writes)
+    assert cli.main(common[:-1] + ["run2", "--epochs", "3", "--resume", "latest"]) == 0
+    assert torch.load(out / "epoch_latest.pt", map_location="cpu", weights_only=False)["epoch"] == 3
+
+
+def test_full_clip_checkpoint_is_carried_through(tmp_path, monkeypatch):
+    """A --pretrained FULL CLIP state_dict (visual.* included) comes back out of epoch_latest.pt complete, so the reference's
+    strict model.load_state_dict (train_AT_text_only.py:363) and its converters accept it; --export-hf writes the release format."""
+    import torch
+    import train_AT_text_only as cli
+    from leaf_amd.model import create_model
+    monkeypatch.chdir(tmp_path)
+    m = create_model("tiny-test-quickgelu", seed=3)
+    full = {k: v.cpu() for k, v in m.state_dict().items()}
+    full.update({"visual.conv1.weight": torch.randn(8, 3, 4, 4), "visual.proj": torch.randn(8, 64), "visual.ln_post.bias": torch.zeros(8)})
+    torch.save(full, tmp_path / "clip_full.pt")
+    args = ["--model", "tiny-test-quickgelu", "--pretrained", str(tmp_path / "clip_full.pt"), "--dataset-type", "synthetic",
+            "--train-num-samples", "8", "--batch-size", "8", "--lr", "1e-4", "--wd", "1e-4", "--warmup", "2", "--rho", "4", "--k_adv", "1",
+            "--seed", "4", "--epochs", "1", "--custom_out_folder", "f_", "--logs", str(tmp_path / "logs"), "--name", "runf",
+            "--export-hf", str(tmp_path / "hf_out")]
+    assert cli.main(args) == 0
+    ck = torch.load(tmp_path / "results" / "f_text_only_k1_rho4_seed4" / "epoch_latest.pt", map_location="cpu", weights_only=False)
+    assert set(full) == set(ck["state_dict"])
+    assert torch.equal(ck["state_dict"]["visual.proj"], full["visual.proj"])
+    assert not torch.equal(ck["state_dict"]["text_projection"], full["text_projection"])
+    assert os.path.exists(tmp_path / "hf_out" / "model.safetensors") and os.path.exists(tmp_path / "hf_out" / "config.json")
 
 
 def test_hf_key_roundtrip_gives_same_embeddings():

@@ -74,14 +74,26 @@ def main(argv):
             return -1
         handlers.append(logging.FileHandler(log_path))
     logging.basicConfig(level=logging.INFO, format="%(asctime)s | %(levelname)s | %(message)s", handlers=handlers)
+    out_dir = f'./results/{args.custom_out_folder}text_only_k{args.k_adv}_rho{args.rho}_seed{args.seed}'
     if args.resume == "latest":
-        args.resume = get_latest_checkpoint(args.checkpoint_path)
+        # the reference looks under logs/<name>/checkpoints, where it never writes (its checkpoints go to ./results/...,
+        # train_AT_text_only.py:483,560-569); look in both places so that --resume latest really resumes
+        args.resume = get_latest_checkpoint(args.checkpoint_path) or get_latest_checkpoint(out_dir)
+        if args.resume is None:
+            logging.warning(f"--resume latest: no checkpoint under {args.checkpoint_path} or {out_dir}; starting from epoch 0")
 
     from leaf_amd.model import LeafCLIPText, create_model
     dtype = "bf16" if "bf16" in args.precision or "bfloat16" in args.precision else "fp16"
     if args.precision == "fp32":
         logging.warning("--precision fp32 is not offered by the MFMA path; using fp16 operands with fp32 accumulation")
     name = args.model + ("-quickgelu" if args.force_quick_gelu and not args.model.endswith("quickgelu") and not args.model.startswith("hf-hub:") else "")
+    if not args.pretrained and not args.resume and not args.random_init and not name.startswith("tiny-test"):
+        # the reference would download the hub weights; training a randomly initialised tower against a random frozen copy of
+        # itself is meaningless, so it has to be asked for
+        raise SystemExit(f"--pretrained is empty: pass a local checkpoint for '{args.model}' (OpenCLIP .bin/.pt, HF safetensors or a "
+                         "directory; there is no network here), or --random-init to train from seeded random weights on purpose")
+    if not args.pretrained and is_master(args):
+        logging.warning("no --pretrained checkpoint: the text tower (and its frozen TextFARE anchor) start from seeded RANDOM weights")
     model = create_model(name, device=device, dtype=dtype, pretrained=args.pretrained or None, trainable=True, seed=args.seed)
     random_seed(args.seed, args.rank)
     if is_master(args):
@@ -110,10 +122,15 @@ def main(argv):
         frozen.copy_from(model)
     frozen.pack()
     model.pack()
-    out_dir = f'./results/{args.custom_out_folder}text_only_k{args.k_adv}_rho{args.rho}_seed{args.seed}'
     if is_master(args):
         os.makedirs(out_dir, exist_ok=True)
     results = []
+    if args.resume and is_master(args):   # train_AT_text_only.py:371-372: results.csv beside the checkpoint continues
+        prev = os.path.join(os.path.abspath(os.path.join(args.resume, os.pardir)), "results.csv")
+        if os.path.exists(prev):
+            import pandas as pd
+            results = [r for r in pd.read_csv(prev).to_dict(orient="records") if r.get("epoch", 0) <= start_epoch]
+            logging.info(f"=> {len(results)} earlier epochs of {prev} carried over")
     for epoch in range(start_epoch, args.epochs):
         if is_master(args):
             logging.info(f'Start epoch {epoch}')
@@ -125,6 +142,11 @@ def main(argv):
             pd.DataFrame(results).to_csv(os.path.join(out_dir, "results.csv"), index=False)
             if completed == args.epochs or (args.save_frequency > 0 and completed % args.save_frequency == 0):
                 save_checkpoint(os.path.join(out_dir, LATEST_CHECKPOINT_NAME), completed, args.name, model, optimizer)
+            if completed == args.epochs and args.export_hf:
+                # release format of the reference (README.md:98, conversion/convert_2.py): HF CLIPTextModel(WithProjection)
+                from leaf_amd.checkpoint import write_hf_text_model
+                write_hf_text_model(args.export_hf, model.state_dict(), model.cfg, with_projection=True)
+                logging.info(f"=> HuggingFace CLIPTextModelWithProjection written to {args.export_hf}")
     if args.distributed:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
