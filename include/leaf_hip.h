@@ -166,6 +166,18 @@ int leaf_tok_mutate_encode(leaf_tok_t tk, const char* const* sentences, const in
                            const int32_t* c, int rho, int ctx, int32_t* tokens, int32_t* lens, uint8_t* fallback,
                            int n_threads);
 
+/* --constrain (utils_attacks.py:110-143,321-325,360-364): valid[b * rho + r] = 1 iff candidate generate_sentence(S_b, z, c,
+ * alternative = -1) holds STRICTLY FEWER distinct dictionary words than S_b.  The word set is built once (leaf_dict_create:
+ * '\n'-separated words); only the whitespace-delimited window around the edit is re-tokenised.  tokenizer_kind 0 = the regex
+ * tokenizer [A-Za-z0-9]+|[^\sA-Za-z0-9] (exact for all ASCII), 1 = nltk.word_tokenize (exact for letters / digits /
+ * whitespace without the Treebank contraction words; everything else gets fallback = 1 and is decided by the caller). */
+typedef struct leaf_dict* leaf_dict_t;
+int leaf_dict_create(const char* words, size_t len, leaf_dict_t* out);
+void leaf_dict_destroy(leaf_dict_t d);
+int64_t leaf_dict_size(leaf_dict_t d);
+int leaf_tok_constrain(leaf_dict_t d, int tokenizer_kind, const char* const* sentences, const int32_t* sent_len, int B,
+                       const int32_t* z, const int32_t* c, int rho, uint8_t* valid, uint8_t* fallback, int n_threads);
+
 /* ---- per-launch GEMM timing (bench.py roofline): between begin/end every GEMM launch is bracketed by HIP events on
  * its stream; end() sums duration / algorithmic FLOPs / algorithmic bytes / launches per key = kernel_family*16 + operand_dtype*8 + epilogue id
  * (family 0 = gemm_nt_kernel, 1 = gemm_nt256_kernel, 4 = gemm_nt256_half_kernel, 6 = gemm_nt64_ring_kernel; keys < 128). */

@@ -82,16 +82,42 @@ class Dictionary:
     """Word list + word tokenizer behind ``--constrain``.  The reference uses nltk (``words`` corpus,
     ``word_tokenize``) and rebuilds the set on every call (utils_attacks.py:125); here it is built once."""
 
-    def __init__(self, words: Sequence[str], tokenize: Optional[Callable[[str], List[str]]] = None):
+    def __init__(self, words: Sequence[str], tokenize: Optional[Callable[[str], List[str]]] = None, kind: Optional[str] = None):
         self.words = frozenset(words)
         self.tokenize = tokenize or (lambda s: re.findall(r"[A-Za-z0-9]+|[^\sA-Za-z0-9]", s))
+        # which word tokenizer the native constraint (leaf_tok_constrain) has to reproduce: 'regex' = the stand-in above,
+        # 'nltk' = nltk.word_tokenize (native only for letters/digits/whitespace), None = custom callable (Python only)
+        self.kind = kind if kind is not None else ("regex" if tokenize is None else None)
+        self._native = None
 
     @classmethod
     def from_nltk(cls):
         import nltk  # noqa: F401  (absent in the build image; present where the reference runs)
         from nltk.corpus import words
         from nltk.tokenize import word_tokenize
-        return cls(words.words(), word_tokenize)
+        return cls(words.words(), word_tokenize, kind="nltk")
+
+    def native_handle(self):
+        """leaf_dict_t of this word set (built once), or None when the tokenizer has no native restatement."""
+        if self.kind is None:
+            return None
+        if self._native is None:
+            import ctypes as C
+            from . import _lib
+            blob = "\n".join(self.words).encode("utf-8")
+            h = C.c_void_p()
+            _lib.check(_lib.lib().leaf_dict_create(blob, len(blob), C.byref(h)), "leaf_dict_create")
+            self._native = h
+        return self._native
+
+    def __del__(self):
+        try:
+            if self._native is not None:
+                from . import _lib
+                _lib.lib().leaf_dict_destroy(self._native)
+                self._native = None
+        except Exception:
+            pass
 
     @classmethod
     def from_file(cls, path: str):
@@ -147,11 +173,21 @@ def _stage_candidates(tokenizer, sentences, z, c, constrain, trace):
     (leaf_amd/csrc/host_text.cpp); strings are only materialised for --constrain, traces and fast-path misses."""
     B, rho = z.shape
     native = hasattr(tokenizer, "mutate_encode")
-    need_strings = constrain or trace is not None or not native
+    native_constrain = constrain and native and hasattr(tokenizer, "constrain_mask") and get_dictionary().kind is not None
+    if native_constrain:
+        # --constrain without materialising strings: the C++ side re-tokenises only the word(s) around each edit and
+        # compares distinct dictionary-word counts (leaf_tok_constrain); what it declines is decided here in Python
+        D = get_dictionary()
+        valid, fb = tokenizer.constrain_mask(D, sentences, z, c)
+        for i in np.nonzero(fb.reshape(-1))[0]:
+            b, r = divmod(int(i), rho)
+            valid[b, r] = D.count(_apply_edit(sentences[b], int(z[b, r]), int(c[b, r]))) < D.count(sentences[b])
+        z[~valid], c[~valid] = 0, -1                      # the no-op edit: candidate == original sentence
+    need_strings = (constrain and not native_constrain) or trace is not None or not native
     SS = None
     if need_strings:
         SS = [[_apply_edit(S, int(z[b, r]), int(c[b, r])) for r in range(rho)] for b, S in enumerate(sentences)]
-        if constrain:
+        if constrain and not native_constrain:
             valid = valid_sentence_batched(sentences, SS)
             for b, S in enumerate(sentences):
                 for r in range(rho):

@@ -17,6 +17,7 @@
 #include <string>
 #include <thread>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/leaf_hip.h"
@@ -274,6 +275,141 @@ extern "C" int leaf_tok_mutate_encode(leaf_tok_t tk, const char* const* sentence
         if (!ascii_fast_path_ok(m.data(), m.size())) { fallback[i] = 1; return; }
         fallback[i] = 0;
         lens[i] = encode_row(*tk, tk->caches[t], m, ctx, tokens + (size_t)i * ctx);
+    });
+    return bad ? 3 : 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// --constrain (utils_attacks.py:110-143, :321-325, :360-364): a candidate is valid iff it holds STRICTLY FEWER distinct
+// dictionary words than its sentence: len(W & set(word_tokenize(lower(candidate)))) < len(W & set(word_tokenize(lower(sentence)))).
+// The reference rebuilds the 236k-word set and tokenises all 2 B rho strings in Python on every call.  Here the set is built
+// once; a sentence is tokenised once into {dictionary word -> multiplicity}; a single-edit candidate differs from it only
+// in the whitespace-delimited window around the edit, so only that window is re-tokenised and the distinct count is updated
+// from the multiplicities.  No candidate string is materialised.
+//
+// Two word tokenizers (the caller says which one its Dictionary uses):
+//   kind 0  the regex stand-in  [A-Za-z0-9]+ | [^\sA-Za-z0-9]  (leaf_amd/attacks.py, used when nltk is absent): tokens never
+//           span whitespace, so the window logic is exact for every ASCII string;
+//   kind 1  nltk.word_tokenize: for text made of letters, digits and whitespace only it is a whitespace split, except for the
+//           Treebank contraction words (cannot, gimme, gonna, gotta, lemme, wanna); any other sentence / candidate (punctuation,
+//           quotes, periods ...) is declined (fallback = 1) and decided by the caller with the real tokenizer.
+namespace {
+
+struct Dict {
+    std::unordered_set<std::string> words;
+};
+
+inline bool is_alnum(unsigned char c) { return is_letter(c) || is_digit(c); }
+inline char lower(unsigned char c) { return (char)((c >= 'A' && c <= 'Z') ? c + 32 : c); }
+
+bool treebank_special(const std::string& w) {
+    return w == "cannot" || w == "gimme" || w == "gonna" || w == "gotta" || w == "lemme" || w == "wanna";
+}
+
+// tokens of a whitespace-free-bounded piece of text, lower-cased; returns false when the text leaves the fast path of `kind`
+template <class F>
+bool tokenize_piece(const char* s, size_t n, int kind, F emit) {
+    size_t i = 0;
+    std::string w;
+    while (i < n) {
+        const unsigned char c = (unsigned char)s[i];
+        if (is_space(c)) { ++i; continue; }
+        if (c >= 128) return false;
+        if (is_alnum(c)) {
+            w.clear();
+            while (i < n && is_alnum((unsigned char)s[i])) { w += lower((unsigned char)s[i]); ++i; }
+            if (kind == 1 && treebank_special(w)) return false;
+            emit(w);
+        } else {
+            if (kind == 1) return false;          // punctuation: nltk's rules are not local
+            w.assign(1, (char)c);
+            emit(w);
+            ++i;
+        }
+    }
+    return true;
+}
+
+}  // namespace
+
+struct leaf_dict : Dict {};
+
+extern "C" int leaf_dict_create(const char* words, size_t len, leaf_dict_t* out) {
+    if (!words || !out) return 1;
+    leaf_dict* d = new leaf_dict();
+    d->words.reserve(len / 8 + 16);
+    size_t pos = 0;
+    while (pos < len) {
+        size_t e = pos;
+        while (e < len && words[e] != '\n') ++e;
+        size_t a = pos, b = e;
+        while (a < b && is_space((unsigned char)words[a])) ++a;
+        while (b > a && is_space((unsigned char)words[b - 1])) --b;
+        if (b > a) d->words.emplace(words + a, b - a);
+        pos = e + 1;
+    }
+    *out = d;
+    return 0;
+}
+
+extern "C" void leaf_dict_destroy(leaf_dict_t d) { delete d; }
+extern "C" int64_t leaf_dict_size(leaf_dict_t d) { return d ? (int64_t)d->words.size() : -1; }
+
+extern "C" int leaf_tok_constrain(leaf_dict_t d, int kind, const char* const* sentences, const int32_t* sent_len, int B,
+                                  const int32_t* z, const int32_t* c, int rho, uint8_t* valid, uint8_t* fallback, int n_threads) {
+    if (!d || !sentences || !sent_len || !z || !c || !valid || !fallback || rho < 1 || (kind != 0 && kind != 1)) return 1;
+    if (n_threads < 1) n_threads = 1;
+    std::atomic<int> bad(0);
+    // sentences are independent: one task per sentence (its rho candidates share the multiplicity map)
+    parallel_for(B, n_threads, [&](int b, int) {
+        const char* s = sentences[b];
+        const int n = sent_len[b];
+        uint8_t* v = valid + (size_t)b * rho;
+        uint8_t* fb = fallback + (size_t)b * rho;
+        std::unordered_map<std::string, int> mult;       // dictionary words of the sentence -> occurrences
+        const bool ok = tokenize_piece(s, (size_t)n, kind, [&](const std::string& w) { if (d->words.count(w)) ++mult[w]; });
+        if (!ok) { for (int r = 0; r < rho; ++r) { fb[r] = 1; v[r] = 0; } return; }
+        const int lo = (int)mult.size();
+        std::unordered_map<std::string, int> delta;
+        std::string win;
+        for (int r = 0; r < rho; ++r) {
+            const int zz = z[(size_t)b * rho + r], cc = c[(size_t)b * rho + r];
+            fb[r] = 0;
+            if (zz < 0 || zz > 2 * n || cc < -1) { bad = 1; fb[r] = 1; v[r] = 0; continue; }
+            if (cc > 126 || (cc >= 0 && cc < 32)) { fb[r] = 1; v[r] = 0; continue; }
+            // the edit in terms of the original string: characters [e0, e1) are replaced by `ins` (0 or 1 characters)
+            int e0, e1;
+            char ins = 0;
+            bool has_ins = false;
+            if (zz & 1) {
+                e0 = (zz - 1) / 2; e1 = e0 + 1;
+                if (!(cc == -1 || (unsigned char)s[e0] == (unsigned)cc)) { ins = (char)cc; has_ins = true; }
+            } else {
+                e0 = e1 = zz / 2;
+                if (!(cc == -1 || cc == '_')) { ins = (char)cc; has_ins = true; }
+            }
+            if (e0 == e1 && !has_ins) { v[r] = 0; continue; }          // no-op candidate: same count, never strictly fewer
+            // window = the edit extended to whitespace on both sides (tokens of both tokenizers never span whitespace)
+            int L = e0, R = e1;
+            while (L > 0 && !is_space((unsigned char)s[L - 1])) --L;
+            while (R < n && !is_space((unsigned char)s[R])) ++R;
+            delta.clear();
+            bool okw = tokenize_piece(s + L, (size_t)(R - L), kind, [&](const std::string& w) { if (d->words.count(w)) --delta[w]; });
+            win.assign(s + L, (size_t)(e0 - L));
+            if (has_ins) win += ins;
+            win.append(s + e1, (size_t)(R - e1));
+            okw = okw && tokenize_piece(win.data(), win.size(), kind, [&](const std::string& w) { if (d->words.count(w)) ++delta[w]; });
+            if (!okw) { fb[r] = 1; v[r] = 0; continue; }
+            int cnt = lo;
+            for (auto& kv : delta) {
+                if (kv.second == 0) continue;
+                auto it = mult.find(kv.first);
+                const int before = it == mult.end() ? 0 : it->second;
+                cnt += (before + kv.second > 0 ? 1 : 0) - (before > 0 ? 1 : 0);
+            }
+            v[r] = cnt < lo ? 1 : 0;
+        }
     });
     return bad ? 3 : 0;
 }

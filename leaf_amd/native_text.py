@@ -87,3 +87,24 @@ class NativeTokenizer(SimpleTokenizer):
             toks[i] = SimpleTokenizer.encode_batch(self, [make_candidate(i // rho, i % rho)], L)[0]
             lens[i] = int(toks[i].argmax()) + 1
         return toks, lens
+
+    def constrain_mask(self, dictionary, sentences: Sequence[str], z: np.ndarray, c: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        """--constrain validity of the B x rho single-edit candidates (strictly fewer distinct dictionary words than the
+        sentence, utils_attacks.py:110-143) computed natively: (valid bool [B, rho], fallback bool [B, rho]); entries with
+        fallback set were declined by the native path (non-ASCII, or text outside nltk's whitespace-split regime) and must
+        be decided with ``dictionary.count``."""
+        B, rho = z.shape
+        raw, arr, blen = self._c_strings(sentences)
+        valid = np.zeros((B, rho), dtype=np.uint8)
+        fb = np.zeros((B, rho), dtype=np.uint8)
+        zz = np.ascontiguousarray(z, dtype=np.int32)
+        cc = np.ascontiguousarray(c, dtype=np.int32)
+        kind = {"regex": 0, "nltk": 1}[dictionary.kind]
+        rc = self._lib.leaf_tok_constrain(dictionary.native_handle(), kind, arr, blen.ctypes.data, B, zz.ctypes.data, cc.ctypes.data,
+                                          rho, valid.ctypes.data, fb.ctypes.data, self.n_threads)
+        if rc not in (0, 3):
+            raise _lib.LeafHipError(f"leaf_tok_constrain failed ({rc})")
+        for b, (s_, r_) in enumerate(zip(sentences, raw)):      # byte offsets == character offsets only for ASCII sentences
+            if len(s_) != len(r_):
+                fb[b] = 1
+        return valid.astype(bool), fb.astype(bool)

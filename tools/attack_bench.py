@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
-"""Throughput of the REAL (string) search: attack_text on B captions, rho=50, k=1, ViT-L, native vs Python host side."""
+"""Throughput of the REAL (string) search: attack_text on B captions, rho=50, k=1, ViT-L, native vs Python host side,
+unconstrained and with --constrain (dictionary = the caption vocabulary + filler words written to a word-list file, the
+regex word tokenizer -- nltk is absent here; the native constraint of leaf_amd/csrc/host_text.cpp covers both)."""
+import argparse
 import os
+import random
 import sys
+import tempfile
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,19 +17,39 @@ from leaf_amd.model import create_model
 from leaf_amd.native_text import NativeTokenizer
 from leaf_amd.tokenizer import SimpleTokenizer
 from leaf_amd.train import _SYN_WORDS
-import random
 
-B, rho = 128, 50
+ap = argparse.ArgumentParser()
+ap.add_argument("--constrain", action="store_true", help="also time the constrained search")
+ap.add_argument("--dict-words", type=int, default=236736, help="size of the word list (nltk's `words` corpus has 236,736 entries)")
+ap.add_argument("--batch", type=int, default=128)
+ap.add_argument("--rho", type=int, default=50)
+a = ap.parse_args()
+
+B, rho = a.batch, a.rho
 rng = random.Random(0)
 caps = [" ".join(rng.choice(_SYN_WORDS) for _ in range(rng.randint(4, 16))) for _ in range(B)]
 m = create_model("ViT-L-14-quickgelu", seed=1)
-for name, tok in (("python", SimpleTokenizer()), ("native", NativeTokenizer())):
-    anchor = m.encode_text(tok.encode_batch(caps))
-    for it in range(3):
-        np.random.seed(it)
-        torch.cuda.synchronize()
-        t0 = time.time()
-        feats, adv = attacks.attack_text(m, tok, caps, anchor, objective="l2", n=rho, k=1)
-        torch.cuda.synchronize()
-        dt = time.time() - t0
-    print(f"{name}: attack_text B={B} rho={rho} k=1: {dt*1e3:.1f} ms  -> {B/dt:.0f} captions/s (search only)", flush=True)
+modes = [False, True] if a.constrain else [False]
+if a.constrain:
+    filler = set(_SYN_WORDS)
+    while len(filler) < a.dict_words:
+        filler.add("".join(rng.choice("abcdefghijklmnopqrstuvwxyz") for _ in range(rng.randint(2, 10))))
+    path = os.path.join(tempfile.gettempdir(), "leaf_words.txt")
+    with open(path, "w") as f:
+        f.write("\n".join(sorted(filler)))
+    attacks.set_dictionary(attacks.Dictionary.from_file(path))
+for constrain in modes:
+    for name, tok in (("python", SimpleTokenizer()), ("native", NativeTokenizer())):
+        anchor = m.encode_text(tok.encode_batch(caps))
+        ts = []
+        for it in range(4):
+            np.random.seed(it)
+            torch.cuda.synchronize()
+            t0 = time.time()
+            feats, adv = attacks.attack_text(m, tok, caps, anchor, objective="l2", n=rho, k=1, constrain=constrain)
+            torch.cuda.synchronize()
+            ts.append(time.time() - t0)
+        dt = min(ts[1:])
+        changed = sum(x != y for x, y in zip(adv, caps))
+        print(f"{name:6s} constrain={int(constrain)}: attack_text B={B} rho={rho} k=1: {dt * 1e3:.1f} ms -> {B / dt:.0f} captions/s "
+              f"(search only; {changed}/{B} captions changed)", flush=True)
