@@ -136,6 +136,14 @@ int leaf_textfare_backward(leaf_text_t h, const float* params, const void* w16_b
                            const float* anchor, float accum_scale, const void* stash, float* grads, float* loss_out,
                            void* ws, size_t ws_bytes, leaf_stream_t s);
 
+/* the same backward, recording completion events for the overlap of the data-parallel gradient reduction with the backward
+ * (SURVEY.md 8e): layer_events = L + 1 hipEvent_t (NULL entries skipped); [l] is recorded on `s` once every gradient of
+ * transformer block l is final in `grads` (blocks finish in the order L-1 .. 0), [L] after the last kernel. */
+int leaf_textfare_backward_events(leaf_text_t h, const float* params, const void* w16_bwd, const int32_t* tokens,
+                                  const int32_t* seq_lens, const int32_t* cu_rows, int n_seq, const float* feat,
+                                  const float* anchor, float accum_scale, const void* stash, float* grads, float* loss_out,
+                                  void* ws, size_t ws_bytes, leaf_stream_t s, void* const* layer_events);
+
 /* torch.optim.AdamW step over the flat buffers (train_AT_text_only.py:326-341): decoupled weight decay `wd`
  * on the first n_decay elements, 0 on the rest; step counts from 1; grads are multiplied by grad_scale first
  * (1/world_size after a sum all-reduce). */
@@ -144,8 +152,10 @@ int leaf_adamw_step(float* params, const float* grads, float* exp_avg, float* ex
                     leaf_stream_t s);
 /* the same step preceded by torch.nn.utils.clip_grad_norm_(parameters, max_norm, 2.0) (--grad-clip-norm,
  * utils_AT.py:348-357): total norm = grad_scale * ||grads||_2, gradients are multiplied by min(1, max_norm / (norm + 1e-6))
- * inside the AdamW kernel (grads themselves are left untouched).  clip_ws: fp32 device scratch [2 + 2048]; after the
- * call clip_ws[0] = coefficient, clip_ws[1] = total norm. */
+ * inside the AdamW kernel (grads themselves are left untouched).  clip_ws: fp32 device scratch [4 + 2048], zeroed once by the
+ * caller; after the call clip_ws[0] = coefficient, clip_ws[1] = total norm.  NON-FINITE GUARD: when the norm is inf / NaN the
+ * whole step is skipped (parameters and moments untouched, GradScaler.step semantics), clip_ws[0] = -1 and clip_ws[2] counts
+ * the skipped steps.  max_norm = +inf gives the guard without clipping. */
 int leaf_adamw_step_clip(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, size_t n_decay,
                          float lr, float beta1, float beta2, float eps, float wd, int step, float grad_scale,
                          float max_norm, float* clip_ws, leaf_stream_t s);

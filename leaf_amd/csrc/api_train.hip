@@ -150,7 +150,7 @@ extern "C" int leaf_text_forward_train(leaf_text_t h, const float* P, const void
 static int backward_impl(leaf_text_t h, const float* P, const void* w16_bwd, const int32_t* tokens,
                          const int32_t* seq_lens, const int32_t* cu_rows, int n_seq, const float* feat,
                          const float* anchor, float accum_scale, const void* stash, float* G, float* d_embed,
-                         float* loss_out, void* ws, size_t ws_bytes, leaf_stream_t s_) {
+                         float* loss_out, void* ws, size_t ws_bytes, leaf_stream_t s_, void* const* layer_events = nullptr) {
     if (!h || !P || !w16_bwd || !tokens || !feat || !anchor || !stash || (!G && !d_embed) || !ws || n_seq < 1) {
         leaf_set_error("null/invalid argument");
         return 1;
@@ -241,9 +241,12 @@ static int backward_impl(leaf_text_t h, const float* P, const void* w16_bwd, con
                  3 * d, 0, s)) return 1;
         LEAF_TRY(leaf_launch_layernorm_bwd(b.dxn, xin, P + o.ln1_w, cf.ln_eps, b.dx, b.dx16, gk, b.gscale,
                                            G ? G + o.ln1_w : nullptr, G ? G + o.ln1_b : nullptr, rows, d, s));
+        // every gradient of block l is final here: the caller may start reducing this block's bucket (step.py)
+        if (layer_events && layer_events[l]) LEAF_TRY(hipEventRecord((hipEvent_t)layer_events[l], s));
     }
     if (G) LEAF_TRY(leaf_launch_embed_bwd(b.dx, b.gscale, tokens, G + h->tok_emb, G + h->pos_emb, rows, n_seq, map, d, cf.vocab_size, s));
     if (d_embed) LEAF_TRY(leaf_launch_scale_copy(b.dx, inv_s, d_embed, rd, s));   // d loss / d (token embedding), un-scaled
+    if (layer_events && layer_events[L]) LEAF_TRY(hipEventRecord((hipEvent_t)layer_events[L], s));
     return 0;
 }
 
@@ -255,6 +258,19 @@ extern "C" int leaf_textfare_backward(leaf_text_t h, const float* P, const void*
     if (!G) { leaf_set_error("null/invalid argument"); return 1; }
     return backward_impl(h, P, w16_bwd, tokens, seq_lens, cu_rows, n_seq, feat, anchor, accum_scale, stash, G, nullptr,
                          loss_out, ws, ws_bytes, s_);
+}
+
+// The same backward with completion events for gradient-bucket overlap: layer_events[l], l = L-1 .. 0, is recorded
+// on the stream as soon as every gradient of transformer block l is final in `grads`, layer_events[L] after the last kernel
+// (embedding tables; ln_final / text_projection gradients are written first).  NULL entries are skipped.
+extern "C" int leaf_textfare_backward_events(leaf_text_t h, const float* P, const void* w16_bwd, const int32_t* tokens,
+                                             const int32_t* seq_lens, const int32_t* cu_rows, int n_seq, const float* feat,
+                                             const float* anchor, float accum_scale, const void* stash, float* G,
+                                             float* loss_out, void* ws, size_t ws_bytes, leaf_stream_t s_,
+                                             void* const* layer_events) {
+    if (!G) { leaf_set_error("null/invalid argument"); return 1; }
+    return backward_impl(h, P, w16_bwd, tokens, seq_lens, cu_rows, n_seq, feat, anchor, accum_scale, stash, G, nullptr,
+                         loss_out, ws, ws_bytes, s_, layer_events);
 }
 
 extern "C" int leaf_textfare_input_grad(leaf_text_t h, const float* P, const void* w16_bwd, const int32_t* tokens,

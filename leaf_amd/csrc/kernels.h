@@ -159,4 +159,4 @@ hipError_t leaf_launch_embed_bwd(const float* dx, const float* gscale, const int
                                  int rows, int n_seq, RowMap map, int d, int vocab, hipStream_t s);
 hipError_t leaf_launch_adamw(float* p, const float* g, float* m, float* v, size_t n, size_t n_decay, float lr,
                              float beta1, float beta2, float eps, float wd, int step, float grad_scale, hipStream_t s,
-                             float max_norm = 0.f /* > 0: clip_grad_norm_ first */, float* clip_ws = nullptr /* [2 + 2048] fp32 */);
+                             float max_norm = 0.f /* > 0: clip_grad_norm_ first */, float* clip_ws = nullptr /* [4 + 2048] fp32 */);

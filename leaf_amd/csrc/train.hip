@@ -487,7 +487,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     size_t n_decay, float lr, float b1, float b2, float eps, float wd,
                                                     float bc1, float sqrt_bc2, float gscale_host,
                                                     const float* __restrict__ clip_coef) {
-    // clip_coef: optional device scalar from clip_coef_kernel (--grad-clip-norm): gradients are multiplied by it
+    // clip_coef: optional device scalar from clip_coef_kernel (--grad-clip-norm / the non-finite guard): gradients are
+    // multiplied by it; a NEGATIVE value means the gradient norm was inf / NaN and the whole step is skipped (what
+    // torch.cuda.amp.GradScaler.step does, train_AT_text_only.py:347, utils_AT.py:339-362)
+    if (clip_coef && clip_coef[0] < 0.f) return;
     const float gscale = clip_coef ? gscale_host * clip_coef[0] : gscale_host;
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * 256;
@@ -535,8 +538,10 @@ __global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict_
     if (threadIdx.x == 0) {
         const float norm = grad_scale * (float)sqrt((red[0] + red[1]) + (red[2] + red[3]));
         const float coef = max_norm / (norm + 1e-6f);
-        out[0] = coef < 1.f ? coef : 1.f;
+        const bool finite = norm == norm && norm < 3.0e38f;
+        out[0] = !finite ? -1.f : (coef < 1.f ? coef : 1.f);    // -1: skip the step (adamw_kernel)
         out[1] = norm;
+        if (!finite) out[2] += 1.f;                               // skipped steps so far (the host reads it when it logs)
     }
 }
 
@@ -735,11 +740,11 @@ hipError_t leaf_launch_adamw(float* p, const float* g, float* m, float* v, size_
     const float bc2 = (float)(1.0 - pow((double)beta2, (double)step));
     size_t n4 = n / 4, nb = (n4 + 255) / 256;
     const float* coef = nullptr;
-    if (max_norm > 0.f) {   // clip_ws: [2 + 2048] floats: {coef, norm, partials...}
+    if (max_norm > 0.f) {   // clip_ws: [4 + 2048] floats: {coef (-1 = skip), norm, skipped steps, -, partials...}
         if (!clip_ws) return hipErrorInvalidValue;
         const int pb = (int)(nb < 2048 ? nb : 2048);
-        hipLaunchKernelGGL(sumsq_partial_kernel, dim3(pb), dim3(256), 0, s, g, n4, clip_ws + 2);
-        hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, s, clip_ws + 2, pb, grad_scale, max_norm, clip_ws);
+        hipLaunchKernelGGL(sumsq_partial_kernel, dim3(pb), dim3(256), 0, s, g, n4, clip_ws + 4);
+        hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, s, clip_ws + 4, pb, grad_scale, max_norm, clip_ws);
         coef = clip_ws;
     }
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)(nb < 16384 ? nb : 16384)), dim3(256), 0, s, p, g, m, v, n4, n_decay,

@@ -438,15 +438,26 @@ class LeafCLIPText:
                    "leaf_pgd_step")
         return delta
 
-    def backward(self, feat: torch.Tensor, anchor: torch.Tensor, accum_scale: float = 1.0) -> torch.Tensor:
+    def backward(self, feat: torch.Tensor, anchor: torch.Tensor, accum_scale: float = 1.0, layer_events=None) -> torch.Tensor:
         """TextFARE loss of (anchor, feat) + backward through the stash of the last ``forward_train``.
-        Accumulates into ``self.grads``; returns the (unscaled) loss as a 0-d CUDA tensor."""
+        Accumulates into ``self.grads``; returns the (unscaled) loss as a 0-d CUDA tensor.
+        ``layer_events``: optional list of cfg.layers + 1 ``torch.cuda.Event`` (already created, i.e. recorded once): event l
+        is recorded when every gradient of block l is final, the last one when everything is (gradient-bucket overlap)."""
         t = self._train_tokens
         n = t.shape[0]
         loss = torch.empty((), dtype=torch.float32, device=self.device)
         anchor = anchor.to(device=self.device, dtype=torch.float32).contiguous()
         ws = self._workspace(2, n)
         lens_p, cu, keep = self._train_plan
+        if layer_events is not None:
+            if len(layer_events) != self.cfg.layers + 1:
+                raise ValueError(f"layer_events must hold {self.cfg.layers + 1} events")
+            evs = (C.c_void_p * len(layer_events))(*[C.c_void_p(e.cuda_event) for e in layer_events])
+            _lib.check(self._lib.leaf_textfare_backward_events(self._h, _ptr(self.flat), _ptr(self.w16_bwd), _ptr(t), lens_p,
+                                                               _ptr(cu), n, _ptr(feat.contiguous()), _ptr(anchor), float(accum_scale),
+                                                               _ptr(self._stash), _ptr(self.grads), _ptr(loss), _ptr(ws),
+                                                               ws.numel(), self._stream(), evs), "leaf_textfare_backward_events")
+            return loss
         _lib.check(self._lib.leaf_textfare_backward(self._h, _ptr(self.flat), _ptr(self.w16_bwd), _ptr(t), lens_p,
                                                     _ptr(cu), n, _ptr(feat.contiguous()), _ptr(anchor), float(accum_scale),
                                                     _ptr(self._stash), _ptr(self.grads), _ptr(loss), _ptr(ws),
@@ -454,17 +465,22 @@ class LeafCLIPText:
         return loss
 
     def adamw_step(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
-                   grad_scale: float = 1.0, max_norm: Optional[float] = None):
+                   grad_scale: float = 1.0, max_norm: Optional[float] = None, guard: bool = True):
         """Fused AdamW over the flat buffers.  ``max_norm`` (--grad-clip-norm, utils_AT.py:348-357): clip the global L2
-        norm of grad_scale * grads first (torch.nn.utils.clip_grad_norm_ semantics); returns the 0-d total norm then."""
+        norm of grad_scale * grads first (torch.nn.utils.clip_grad_norm_ semantics).  ``guard`` (default): one extra read of
+        the gradients computes their global norm and SKIPS the whole step when it is inf / NaN (what GradScaler.step does in
+        the reference's fp16 regime; the 16-bit conversions of the gradient path saturate instead of producing inf, so this
+        catches fp32 overflow and NaNs before they reach the weights, the moments and -- through the all-reduce -- every rank).
+        Returns the 0-d total-norm tensor when clipping or guarding, else None; ``skipped_steps()`` counts skipped steps."""
         self.opt_step += 1
-        if max_norm is not None:
+        if max_norm is not None or guard:
             if getattr(self, "_clip_ws", None) is None:
-                self._clip_ws = torch.zeros(2 + 2048, dtype=torch.float32, device=self.device)
+                self._clip_ws = torch.zeros(4 + 2048, dtype=torch.float32, device=self.device)
             _lib.check(self._lib.leaf_adamw_step_clip(_ptr(self.flat), _ptr(self.grads), _ptr(self.exp_avg),
                                                       _ptr(self.exp_avg_sq), self.n_params, self.n_decay, float(lr),
                                                       float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
-                                                      self.opt_step, float(grad_scale), float(max_norm),
+                                                      self.opt_step, float(grad_scale),
+                                                      float(max_norm) if max_norm is not None else float("inf"),
                                                       _ptr(self._clip_ws), self._stream()), "leaf_adamw_step_clip")
             self._packed = False
             return self._clip_ws[1]
@@ -475,6 +491,10 @@ class LeafCLIPText:
         self._packed = False
         return None
 
+    def skipped_steps(self) -> int:
+        """Optimizer steps skipped by the non-finite guard so far (synchronises: call it where the loop already does)."""
+        ws = getattr(self, "_clip_ws", None)
+        return int(ws[2].item()) if ws is not None else 0
 
 def create_model(name: str, device="cuda:0", dtype: str = None, pretrained: Optional[str] = None,
                  trainable: bool = False, seed: int = 1) -> LeafCLIPText:

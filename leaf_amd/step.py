@@ -12,9 +12,10 @@ synthetic mode, SURVEY.md section 8d, and the inner engine of ``train_one_epoch_
     [one flat RCCL all-reduce of the gradient buffer]                   SURVEY.md section 8e
     AdamW, zero_grad                                                    :339-362
 
-Data parallelism: every rank holds a full replica and its own B captions; the only exchange is ONE
-``all_reduce(SUM)`` over the flat fp32 gradient buffer per optimizer step (the 1/world factor is folded into
-the AdamW kernel's ``grad_scale``).
+Data parallelism: every rank holds a full replica and its own B captions; the only exchange is the gradient sum
+(RCCL all-reduce) per optimizer step, issued per transformer block behind the backward so that it overlaps with it
+(``GradReducer``; one flat all-reduce with LEAF_DP_OVERLAP=0); the 1/world factor is folded into the AdamW kernel's
+``grad_scale``.
 """
 from __future__ import annotations
 
@@ -130,13 +131,110 @@ def _side_stream(device) -> "torch.cuda.Stream":
     return _SIDE[key]
 
 
+def _dp_active() -> bool:
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("LEAF_BENCH_FORCE_DIST") == "1")
+
+
 def allreduce_grads(model) -> float:
     """ONE flat all-reduce (sum) of the gradient buffer over RCCL; returns the factor AdamW must apply."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("LEAF_BENCH_FORCE_DIST") == "1"):
+    if _dp_active():
         dist.all_reduce(model.grads, op=dist.ReduceOp.SUM)
         return 1.0 / dist.get_world_size()
     return 1.0
+
+
+def bucket_plan(layout, n_params: int, layers: int):
+    """Gradient buckets in the order the backward finishes them: one per transformer block (its four GEMM weights, a
+    contiguous 12 d^2 run of the flat buffer -- 28 MB for ViT-L), blocks L-1 .. 0, then ONE last bucket list with everything
+    else (embedding tables + text_projection in front of the block weights; every bias / LayerNorm vector + ln_final behind
+    them), which is complete only after the backward's last kernel.  Returns [(event index, [(offset, numel), ...]), ...];
+    the ranges partition [0, n_params) (tests/test_dp_gloo.py)."""
+    def span(names):
+        lo = min(layout[k][0] for k in names)
+        hi = max(layout[k][0] + int(np.prod(layout[k][1])) for k in names)
+        return lo, hi
+    plan, w_lo, w_hi = [], None, None
+    for l in reversed(range(layers)):
+        p = f"transformer.resblocks.{l}."
+        lo, hi = span([p + "attn.in_proj_weight", p + "attn.out_proj.weight", p + "mlp.c_fc.weight", p + "mlp.c_proj.weight"])
+        plan.append((l, [(lo, hi - lo)]))
+        w_lo = lo if w_lo is None else min(w_lo, lo)
+        w_hi = hi if w_hi is None else max(w_hi, hi)
+    plan.append((layers, [(0, w_lo), (w_hi, n_params - w_hi)]))
+    return plan
+
+
+class GradReducer:
+    """Data-parallel gradient mean overlapped with the backward.  The backward records one
+    event per transformer block as soon as that block's gradients are final (leaf_textfare_backward_events); each block's
+    weight bucket is then all-reduced (RCCL, sum) on a side stream while the backward of the earlier blocks is still
+    running; only the last bucket (embedding tables + vectors) is exposed.  Every rank issues the same collectives in the
+    same order.  LEAF_DP_OVERLAP=0 (or world size 1) falls back to ONE flat all-reduce after the backward.
+    The 1/world factor is folded into the AdamW kernel (``finish()`` returns it)."""
+
+    def __init__(self, model):
+        self.model = model
+        self.plan = bucket_plan(model.layout, model.n_params, model.cfg.layers)
+        self.overlap = os.environ.get("LEAF_DP_OVERLAP", "1") != "0"
+        self.events = None
+        self.comm = None
+        self._launched = False
+
+    def _setup(self):
+        dev = self.model.device
+        self.comm = torch.cuda.Stream(device=dev)
+        self.events = [torch.cuda.Event() for _ in range(self.model.cfg.layers + 1)]
+        for e in self.events:          # an event's handle exists only once it has been recorded
+            e.record(torch.cuda.current_stream(dev))
+
+    def backward(self, feat, anchor, accum_scale: float = 1.0, last_micro: bool = True):
+        """model.backward + (on the last micro-batch of an optimizer step) the bucketed reduction queued behind it."""
+        import torch.distributed as dist
+        m = self.model
+        if not (_dp_active() and self.overlap and last_micro):
+            return m.backward(feat, anchor, accum_scale=accum_scale)
+        if self.events is None:
+            self._setup()
+        loss = m.backward(feat, anchor, accum_scale=accum_scale, layer_events=self.events)
+        for ev_idx, ranges in self.plan:
+            self.comm.wait_event(self.events[ev_idx])
+            with torch.cuda.stream(self.comm):
+                for off, numel in ranges:
+                    if numel:
+                        dist.all_reduce(m.grads[off:off + numel], op=dist.ReduceOp.SUM)
+        self._launched = True
+        return loss
+
+    def finish(self) -> float:
+        """Make the current stream wait for the reduction (launching the flat one if none is in flight); returns the
+        factor AdamW must apply to the summed gradients."""
+        import torch.distributed as dist
+        if self._launched:
+            torch.cuda.current_stream(self.model.device).wait_stream(self.comm)
+            self._launched = False
+            return 1.0 / dist.get_world_size()
+        return allreduce_grads(self.model)
+
+
+def reduce_buckets(flat: torch.Tensor, plan) -> None:
+    """The collectives of GradReducer without streams / events (CPU rehearsal under gloo, tests/test_dp_gloo.py)."""
+    import torch.distributed as dist
+    for _, ranges in plan:
+        for off, numel in ranges:
+            if numel:
+                dist.all_reduce(flat[off:off + numel], op=dist.ReduceOp.SUM)
+
+
+_REDUCERS = {}
+
+
+def get_reducer(model) -> GradReducer:
+    r = _REDUCERS.get(id(model))
+    if r is None or r.model is not model:
+        r = _REDUCERS[id(model)] = GradReducer(model)
+    return r
 
 
 def train_step_tokens(model, frozen, base: torch.Tensor, cfg: StepConfig, seed: int, lr: Optional[float] = None,
@@ -177,9 +275,11 @@ def train_step_tokens(model, frozen, base: torch.Tensor, cfg: StepConfig, seed: 
         feat = model.forward_train(adv, seq_lens=base_lens)
     if micro_index % cfg.accum_freq == 0:
         model.zero_grad()
-    loss = model.backward(feat, anchor, accum_scale=1.0 / cfg.accum_freq)
-    if (micro_index + 1) % cfg.accum_freq == 0:
-        scale = allreduce_grads(model)
+    last = (micro_index + 1) % cfg.accum_freq == 0
+    red = get_reducer(model)
+    loss = red.backward(feat, anchor, accum_scale=1.0 / cfg.accum_freq, last_micro=last)   # + bucketed all-reduce behind it
+    if last:
+        scale = red.finish()
         model.adamw_step(lr if lr is not None else cfg.lr, (cfg.beta1, cfg.beta2), cfg.eps, cfg.wd, grad_scale=scale)
         model.pack()
     return loss

@@ -29,7 +29,7 @@ import numpy as np
 import torch
 
 from .attacks import DEFAULT_V, attack_text
-from .step import allreduce_grads
+from .step import allreduce_grads, get_reducer
 
 LATEST_CHECKPOINT_NAME = "epoch_latest.pt"
 
@@ -101,7 +101,7 @@ class LeafAdamW:
         """``max_norm``: --grad-clip-norm (utils_AT.py:348-357), applied to the all-reduced, averaged gradients like
         clip_grad_norm_ on DDP-averaged .grad; returns the total norm (0-d tensor) when clipping."""
         g = self.param_groups[1]
-        scale = allreduce_grads(self.model)   # the single collective of the step
+        scale = get_reducer(self.model).finish()   # waits for the bucketed reduction queued behind the backward (or runs the flat one)
         total = self.model.adamw_step(g["lr"], g["betas"], g["eps"], g["weight_decay"], grad_scale=scale, max_norm=max_norm)
         self.model.pack()
         return total
@@ -286,7 +286,8 @@ def train_one_epoch_text_only(model, model_frozen, tokenizer, V, data, loss, epo
         model.train()
         feat = model.forward_train(adv_tokens, normalize=normalize_fare)
         data_time_m.update(time.time() - end)
-        loss_fare = model.backward(feat, anchor, accum_scale=1.0 / args.accum_freq)   # device scalar, no sync
+        loss_fare = get_reducer(model).backward(feat, anchor, accum_scale=1.0 / args.accum_freq,
+                                                last_micro=(i + 1) % args.accum_freq == 0)   # device scalar, no sync
         for key in ("loss", "loss_FARE_text"):
             losses_accum[key] = losses_accum.get(key, 0) + loss_fare / args.accum_freq
         if (i + 1) % args.accum_freq == 0:
@@ -307,6 +308,11 @@ def train_one_epoch_text_only(model, model_frozen, tokenizer, V, data, loss, epo
             percent_complete = 100.0 * batch_count / num_batches_per_epoch
             for key, val in losses_accum.items():
                 losses_m.setdefault(key, AverageMeter()).update(float(val), batch_size)
+            skipped = unwrap_model(model).skipped_steps()     # float(val) above already synchronised
+            if skipped != getattr(train_one_epoch_text_only, "_skipped_seen", 0):
+                logging.warning(f"non-finite gradient norm: {skipped} optimizer step(s) skipped so far (weights and AdamW moments "
+                                "left untouched for those steps, as torch.cuda.amp.GradScaler does)")
+                train_one_epoch_text_only._skipped_seen = skipped
             loss_log = " ".join(f"{n.capitalize()}: {m.val:#.5g} ({m.avg:#.5g})" for n, m in losses_m.items())
             sps = args.accum_freq * args.batch_size * args.world_size / batch_time_m.val
             sps_gpu = args.accum_freq * args.batch_size / batch_time_m.val

@@ -59,3 +59,71 @@ def test_flat_allreduce_equals_concatenated_batch(tmp_path):
     assert r0["rel"] < 1e-5 and r1["rel"] < 1e-5
     assert r0["batches"] == r1["batches"] == 4
     assert not set(r0["seen"]) & set(r1["seen"]) and len(set(r0["seen"]) | set(r1["seen"])) == 40
+
+
+def _layout_for(cfg):
+    """The engine's flat layout via host-only C calls (as tests/test_checkpoint_cpu.py)."""
+    import ctypes as C
+    from leaf_amd import _lib
+    lib = _lib.lib()
+    c = _lib.TextCfgC(cfg.layers, cfg.width, cfg.heads, cfg.embed_dim, cfg.context_length, cfg.vocab_size, int(cfg.quick_gelu), cfg.ln_eps)
+    h = C.c_void_p()
+    _lib.check(lib.leaf_text_create(C.byref(c), 1, C.byref(h)), "create")
+    out, name = {}, C.create_string_buffer(128)
+    off, rows, cols = C.c_size_t(), C.c_int64(), C.c_int64()
+    for i in range(lib.leaf_text_num_tensors(h)):
+        lib.leaf_text_param_info(h, i, name, 128, C.byref(off), C.byref(rows), C.byref(cols))
+        out[name.value.decode()] = (off.value, (rows.value, cols.value) if cols.value else (rows.value,))
+    n = lib.leaf_text_param_count(h)
+    lib.leaf_text_destroy(h)
+    return out, n
+
+
+@pytest.mark.parametrize("name", ["tiny-test", "ViT-L-14", "ViT-bigG-14"])
+def test_bucket_plan_partitions_the_gradient_buffer(name):
+    """GradReducer's buckets (one per transformer block in completion order + the rest) cover every gradient element exactly
+    once, each block bucket holds exactly that block's four GEMM weights, and the order is L-1 .. 0 then the remainder."""
+    sys.path.insert(0, ROOT)
+    from leaf_amd.model import MODEL_CONFIGS
+    from leaf_amd.step import bucket_plan
+    cfg = MODEL_CONFIGS[name]
+    layout, n = _layout_for(cfg)
+    plan = bucket_plan(layout, n, cfg.layers)
+    assert [ev for ev, _ in plan] == list(reversed(range(cfg.layers))) + [cfg.layers]
+    cover = np.zeros(n, dtype=np.int8) if n < 2e8 else None
+    spans = sorted((off, off + m) for _, ranges in plan for off, m in ranges if m)
+    assert spans[0][0] == 0 and spans[-1][1] == n and all(a[1] == b[0] for a, b in zip(spans, spans[1:])), "gap or overlap"
+    for ev, ranges in plan[:-1]:
+        (off, m), = ranges
+        p = f"transformer.resblocks.{ev}."
+        want = sum(int(np.prod(layout[p + k][1])) for k in ("attn.in_proj_weight", "attn.out_proj.weight", "mlp.c_fc.weight", "mlp.c_proj.weight"))
+        assert m == want == 12 * cfg.width ** 2
+        for k, (o, shp) in layout.items():
+            inside = off <= o < off + m
+            assert inside == (k.startswith(p) and k.endswith("weight") and "ln_" not in k), k
+
+
+def _bucket_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from leaf_amd.model import MODEL_CONFIGS
+    from leaf_amd.step import bucket_plan, reduce_buckets
+    cfg = MODEL_CONFIGS["tiny-test"]
+    layout, n = _layout_for(cfg)
+    g = torch.Generator().manual_seed(100 + rank)
+    mine = torch.randn(n, generator=g)
+    flat = mine.clone()
+    dist.all_reduce(flat)
+    bucketed = mine.clone()
+    reduce_buckets(bucketed, bucket_plan(layout, n, cfg.layers))
+    torch.save({"equal": bool(torch.equal(flat, bucketed))}, f"{out}.{rank}")
+    dist.destroy_process_group()
+
+
+def test_bucketed_reduction_equals_the_flat_allreduce(tmp_path):
+    """Same sums bit for bit (an all-reduce adds the same two operands per element whatever the bucket boundaries), same
+    collective order on every rank."""
+    port, out = _free_port(), str(tmp_path / "bk")
+    mp.spawn(_bucket_worker, args=(2, port, out), nprocs=2, join=True)
+    assert torch.load(out + ".0")["equal"] and torch.load(out + ".1")["equal"]

@@ -35,3 +35,33 @@ def test_synthetic_step_runs_and_selects_argmax():
     l0 = float(train_step_tokens(m, frozen, base, sc, seed=1))
     l1 = float(train_step_tokens(m, frozen, base, sc, seed=1))
     assert np.isfinite([l0, l1]).all()
+
+
+def test_overlapped_gradient_reduction_on_rccl_single_rank(tmp_path):
+    """The bucketed, event-driven gradient reduction (GradReducer: leaf_textfare_backward_events + RCCL all-reduces on a side
+    stream) rehearsed on the one GPU of this box: under torch.distributed.run with one rank and LEAF_BENCH_FORCE_DIST=1 the
+    step must give the same loss trajectory as the flat all-reduce and as no process group at all (a one-rank sum is the
+    identity), and bench.py must report the rank count it saw.  The N > 1 arithmetic is covered on CPU by tests/test_dp_gloo.py."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = ["--model", "tiny-test-quickgelu", "--batch", "16", "--rho", "8", "--steps", "4", "--warmup", "1", "--no-cpu-baseline",
+            "--no-dense-leg", "--gpus", "1"]
+    base_env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LEAF_BENCH_FORCE_DIST", "LEAF_DP_OVERLAP")}
+
+    def run(extra_env, launcher):
+        env = dict(base_env, **extra_env)
+        cmd = ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                "--master-port", "29611"] if launcher else [sys.executable]) + [os.path.join(root, "bench.py")] + args
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+        assert p.returncode == 0, p.stderr[-3000:]
+        line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        assert len(line) == 1, p.stdout[-2000:]
+        return json.loads(line[0])
+    plain = run({}, False)
+    overlap = run({"LEAF_BENCH_FORCE_DIST": "1"}, True)
+    flat = run({"LEAF_BENCH_FORCE_DIST": "1", "LEAF_DP_OVERLAP": "0"}, True)
+    assert plain["n_ranks_seen"] == 1 and overlap["n_ranks_seen"] == 1
+    assert plain["loss"] == overlap["loss"] == flat["loss"], (plain["loss"], overlap["loss"], flat["loss"])

@@ -187,3 +187,31 @@ def test_grad_clip_norm_vs_reference_fixture(torch_mod, golden_dir):
         # amplifies the 16-bit gradient noise: a few elements may differ by up to 2 lr (sign flip), the mean must not
         # (the key third of in_proj_bias has a mathematically zero gradient: pure noise over eps there)
         assert d.max() < 2.5 * lr and d.mean() < 5e-2 * lr, (k, d.max(), d.mean())
+
+
+def test_non_finite_gradients_skip_the_step(torch_mod):
+    """a NaN / inf anywhere in the gradient buffer must not reach the weights or the AdamW moments (and, through
+    the flat all-reduce, the other ranks): the fused step is skipped as a whole, as GradScaler.step does in the reference's
+    fp16 regime, and counted; the next finite step runs normally."""
+    from leaf_amd.model import create_model
+    m = create_model("tiny-test-quickgelu", seed=12, trainable=True)
+    toks = O.synthetic_tokens(6, seed=4)
+    anchor = m.encode_text(toks) + 0.3
+    f = m.forward_train(toks)
+    m.zero_grad()
+    m.backward(f, anchor)
+    good = m.grads.clone()
+    p0, m0, v0 = m.flat.clone(), m.exp_avg.clone(), m.exp_avg_sq.clone()
+    for poison in (float("nan"), float("inf")):
+        m.grads.copy_(good)
+        m.grads[12345] = poison
+        norm = m.adamw_step(lr=1e-3, weight_decay=0.1)
+        assert not bool(torch_mod.isfinite(norm))
+        assert torch_mod.equal(m.flat, p0) and torch_mod.equal(m.exp_avg, m0) and torch_mod.equal(m.exp_avg_sq, v0)
+    assert m.skipped_steps() == 2
+    m.grads.copy_(good)
+    norm = m.adamw_step(lr=1e-3, weight_decay=0.1)
+    assert bool(torch_mod.isfinite(norm)) and abs(float(norm) - float(good.double().norm())) < 1e-4 * float(norm)
+    assert not torch_mod.equal(m.flat, p0) and m.skipped_steps() == 2 and bool(torch_mod.isfinite(m.flat).all())
+    # guard off: the plain kernel (no extra pass over the gradients)
+    assert m.adamw_step(lr=1e-3, guard=False) is None
