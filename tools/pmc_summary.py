@@ -11,9 +11,12 @@ for the kernel with the largest summed fetch (or the one matching KERNEL_SUBSTR)
 import csv
 import glob
 import json
+import os
 import re
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def per_kernel(d, counter):
@@ -49,10 +52,12 @@ def main():
     gemms = {k: v for k, v in fe.items() if "gemm_nt" in k and (want is None or want in k)}
     k = max(gemms, key=lambda x: gemms[x][0])
     fkb, wkb = fe[k][0] / fe[k][1], wr[k][0] / wr[k][1]
+    from bench import kernel_sources_hash
     json.dump({
         "kernel": short(k),
+        "kernel_sources_sha16": kernel_sources_hash(),   # bench.py attaches this summary only to lines from the same kernel sources
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --steps 2 --warmup 1 "
-                  "--no-cpu-baseline`, mean over that kernel's dispatches (tools/pmc_summary.py)",
+                  "--no-cpu-baseline --no-dense-leg`, mean over that kernel's dispatches (tools/pmc_summary.py)",
         "fetch_kb_mean": fkb, "write_kb_mean": wkb,
         "correction": "gfx950: FETCH_SIZE counts 128-B requests at 64 B -> doubled (MI355X_MICROARCH.md, HBM)",
         "traffic_bytes_per_launch": (2 * fkb + wkb) * 1024,
