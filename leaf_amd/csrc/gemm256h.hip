@@ -36,42 +36,54 @@ typedef __attribute__((address_space(1))) const void glb_void_t;
 
 __device__ __forceinline__ int lds_off_h(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
-template <class TT, int EPI>
+// PERSIST (the 16-bit-output epilogues: QKV, c_fc): one workgroup per CU walks tiles v = blockIdx.x, + gridDim.x, ... in
+// the same logical order a plain launch is dispatched in, and requests the NEXT tile's first A / B half-stages before it
+// runs the epilogue of the current one, so that the 12-15 % first-DMA wait of a K = 768 tile (all 256 workgroups asking
+// L2 for their first 96 KiB at once) disappears under the epilogue.  The epilogue stages through 8 KiB per wave in ring
+// slots 3-4, slots 0-1 take the prefetch, slot 2 the LN-folding row table; the next tile's barrier protects all three.
+template <class TT, int EPI, bool PERSIST>
 __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 2, wn = wid & 3;
     const int tiles_n = p.N / BN;
-    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int ntiles = tiles_m * tiles_n;
     // Tile order: N tiles in groups of p.ngroup; inside a group M-major / N-minor.  An XCD (a contiguous range of logical
     // ids) then sweeps many M panels against ONE group's B panels, which stay in its 4-MiB L2 instead of being re-fetched
     // for every round of 32 tiles (the host picks the group size, launch256h).
-    int m0, n0;
-    {
+    auto tile_coords = [&](int v, int& m0_, int& n0_) {
+        const int logical = xcd_remap(v, ntiles);
         const int G = (p.ngroup > 0 && p.ngroup < tiles_n) ? p.ngroup : tiles_n;
-        const int tiles_m = (p.M + BM - 1) / BM;
         int g = logical / (tiles_m * G);
         const int ng = (tiles_n + G - 1) / G;
         if (g > ng - 1) g = ng - 1;
         const int rem = logical - g * tiles_m * G;
         const int gsz = g == ng - 1 ? tiles_n - g * G : G;
-        m0 = (rem / gsz) * BM;
-        n0 = (g * G + rem % gsz) * BN;
-    }
+        m0_ = (rem / gsz) * BM;
+        n0_ = (g * G + rem % gsz) * BN;
+    };
+    int v = blockIdx.x;
+    int m0, n0;
+    tile_coords(v, m0, n0);
 
     // ---- DMA sources: wave w moves pieces 4w..4w+3 (8 rows x 128 B) of whichever panel a half-stage carries
     const int prow = lane >> 3;
     const int schunk = (lane & 7) ^ prow;
     const char* __restrict__ A = (const char*)p.A;
     const char* __restrict__ B = (const char*)p.B;
-    auto arow = [&](int j) { int r = m0 + wid * 32 + 8 * j + prow; return r < p.M ? r : p.M - 1; };
     // 32-bit byte offsets from the (uniform) operand bases: saddr + voffset addressing, 5 VGPRs instead of 10
-    const unsigned a0 = (unsigned)arow(0) * (unsigned)p.lda * 2u + schunk * 16;
-    const unsigned a1 = (unsigned)arow(1) * (unsigned)p.lda * 2u + schunk * 16;
-    const unsigned a2 = (unsigned)arow(2) * (unsigned)p.lda * 2u + schunk * 16;
-    const unsigned a3 = (unsigned)arow(3) * (unsigned)p.lda * 2u + schunk * 16;
-    const unsigned b0 = (unsigned)(n0 + wid * 32 + prow) * (unsigned)p.ldb * 2u + schunk * 16;
+    unsigned a0, a1, a2, a3, b0;
+    auto set_sources = [&](int m0_, int n0_) {
+        auto arow = [&](int j) { int r = m0_ + wid * 32 + 8 * j + prow; return r < p.M ? r : p.M - 1; };
+        a0 = (unsigned)arow(0) * (unsigned)p.lda * 2u + schunk * 16;
+        a1 = (unsigned)arow(1) * (unsigned)p.lda * 2u + schunk * 16;
+        a2 = (unsigned)arow(2) * (unsigned)p.lda * 2u + schunk * 16;
+        a3 = (unsigned)arow(3) * (unsigned)p.lda * 2u + schunk * 16;
+        b0 = (unsigned)(n0_ + wid * 32 + prow) * (unsigned)p.ldb * 2u + schunk * 16;
+    };
+    set_sources(m0, n0);
     const unsigned bstep = 16u * (unsigned)p.ldb;   // 8 rows, bytes
     const int piece = wid * 4096;
 #ifdef LEAF_DIAG_NODMA   // diagnostic only: no operand traffic at all (results are garbage) - isolates the MFMA + LDS-read loop
@@ -86,19 +98,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
 #define ISSUE_HALF_A(so, kt) ISSUE_A(so, kt, 0); ISSUE_A(so, kt, 1); ISSUE_A(so, kt, 2); ISSUE_A(so, kt, 3);
 #define ISSUE_HALF_B(so, kt) ISSUE_B(so, kt, 0); ISSUE_B(so, kt, 1); ISSUE_B(so, kt, 2); ISSUE_B(so, kt, 3);
 
-    // LN folding: thread t < 256 fetches (mean, rstd) of A row m0 + t now (2 registers held across the K loop), so the epilogue
-    // waits for no memory
     constexpr bool FOLD = (EPI == EPI_LNFOLD_T || EPI == EPI_LNFOLD_ACT_T);
-    float2 my_rowstat = float2{0.f, 0.f};
-    if constexpr (FOLD) {
-        if (tid < BM && m0 + tid < p.M) my_rowstat = p.rowstat[m0 + tid];
-    }
-
     f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int frow = lane & 15, fkc = lane >> 4;
     const int fo0 = lds_off_h(frow, fkc), fo1 = lds_off_h(frow, 4 + fkc);   // k-step 0 / 1 inside a 64-deep tile
@@ -178,12 +179,39 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
     const int nt = p.K / BK;   // K tiles, >= 4 (host-checked)
     // half-stage u lives in ring slot u % 5; the offsets below are uniform and advance by two slots per K tile
 #define ADV(x) { x += 2 * HALF; if (x >= RING) x -= RING; }
+    bool first = true;        // PERSIST: first output tile of this workgroup (nothing prefetched yet)
+    bool counted = false;     // PERSIST: the previous epilogue issued exactly NSTORE stores behind the prefetch (full tile)
+  for (;;) {                  // output tiles of this workgroup (one pass unless PERSIST)
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     int sa = 0, sb = HALF;               // slots of (A, B) of the tile being multiplied: half-stages 2T, 2T+1
     int i0 = 3 * HALF, i1 = 4 * HALF;    // slots of the half-stages requested during tile T: 2T+3 (B), 2T+4 (A)
     STAMP(0)
-    ISSUE_HALF_A(0, 0) ISSUE_HALF_B(HALF, 0) ISSUE_HALF_A(2 * HALF, 1)
-    // ---- tile 0
-    SYNC_TILE(4)
+    // LN folding: thread t < 256 fetches (mean, rstd) of A row m0 + t now (2 registers held across the K loop), so the epilogue
+    // waits for no memory
+    float2 my_rowstat = float2{0.f, 0.f};
+    if constexpr (!PERSIST) {
+        if constexpr (FOLD) {
+            if (tid < BM && m0 + tid < p.M) my_rowstat = p.rowstat[m0 + tid];
+        }
+        ISSUE_HALF_A(0, 0) ISSUE_HALF_B(HALF, 0) ISSUE_HALF_A(2 * HALF, 1)
+        // ---- tile 0
+        SYNC_TILE(4)
+    } else {
+        // A0 / B0 of this tile: requested just now (first tile) or before the previous tile's epilogue, whose NSTORE output
+        // stores were issued after them (vmcnt completes in order: "all but the youngest NSTORE" = the prefetch has landed)
+        constexpr int NSTORE = 16;
+        if (first) { ISSUE_HALF_A(0, 0) ISSUE_HALF_B(HALF, 0) }
+        if (!first && counted) { SYNC_TILE(16) } else { SYNC_TILE(0) }
+        static_assert(NSTORE == 16, "the counted wait above");
+        // behind the barrier: every wave has left the previous epilogue, slot 2 (row table) and slots 3-4 (staging) are free
+        ISSUE_HALF_A(2 * HALF, 1)
+        if constexpr (FOLD) {
+            if (tid < BM && m0 + tid < p.M) my_rowstat = p.rowstat[m0 + tid];
+        }
+    }
     STAMP(1)
     READ_FRAGS(G, sa, sb, fo0)
     SB ISSUE_B(i0, 1, 0); ISSUE_B(i0, 1, 1); SB
@@ -210,25 +238,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
     KSTEP(G, F, sa, sb, fo1, NOP_, NOP_, NOP_, NOP_)
     SB MFMA_H2(F) SB
     STAMP(3)
-#undef ADV
-#undef DMA16
-#undef ISSUE_A
-#undef ISSUE_B
-#undef ISSUE_HALF_A
-#undef ISSUE_HALF_B
-#undef READ_FRAGS
-#undef MROW
-#undef MFMA_H1
-#undef MFMA_H2
-#undef SYNC_TILE
-#undef KSTEP
-#undef MF
-#undef RDW
-#undef RDX
-#undef NOP_
-#undef SB
-#undef LD
-
     // ---------------- epilogue through this wave's private LDS slice (ring is idle after one more barrier)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -239,13 +248,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] *= al;
     }
+    // staging slices / row table: above the whole ring's first 128 KiB normally; PERSIST keeps slots 0-1 for the prefetch
+    constexpr int TABLE_OFF = PERSIST ? 2 * HALF : 8 * SLICE;
     if constexpr (FOLD) {
-        // (mean, rstd) of this tile's 256 A rows (loaded before the K loop) -> a 2-KiB table above the staging slices
-        if (tid < BM) *(float2*)(smem + 8 * SLICE + tid * 8) = my_rowstat;
+        // (mean, rstd) of this tile's 256 A rows (loaded before the K loop) -> a 2-KiB table
+        if (tid < BM) *(float2*)(smem + TABLE_OFF + tid * 8) = my_rowstat;
         __syncthreads();
     }
-    char* sl = smem + wid * SLICE;
-    const int fq = lane >> 4;
+    char* sl = PERSIST ? smem + 3 * HALF + wid * 8192 : smem + wid * SLICE;
+    // epilogue addressing derives from an OPAQUE copy of the lane id: in the persistent form the compiler would otherwise hoist
+    // these per-lane offsets out of the tile loop and keep them in VGPRs across the K loop (spills)
+    int elane = lane;
+    if constexpr (PERSIST) asm volatile("" : "+v"(elane));
+    const int fq = elane >> 4, efrow = elane & 15;
     const int nb = n0 + wn * 64;          // first column of this wave's sub-tile
     const int mb = m0 + wm * 128;         // first row
     float4 bias4[4];
@@ -259,6 +274,31 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
         for (int j = 0; j < 4; ++j) s4[j] = *(const float4*)(p.ln_s + nb + 16 * j + 4 * fq);
     }
 
+    // (mean, rstd) of this lane's 8 rows, out of the table (before the prefetch below: see the note on LDS accesses there)
+    float2 rs_all[8];
+    if constexpr (FOLD) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rs_all[i] = *(const float2*)(smem + TABLE_OFF + (wm * 128 + 16 * i + efrow) * 8);
+    }
+
+    // PERSIST: request the next tile's first half-stages now; the epilogue below then only stores.  While those LDS-DMAs are
+    // in flight every compiler-visible LDS load / store would be preceded by s_waitcnt vmcnt(0) (the compiler cannot prove
+    // that the staging slices and the DMA's slots are disjoint), so the persistent epilogue stages through inline-asm
+    // ds_write / ds_read with its own lgkmcnt waits.  The bias / s loads above
+    // are retired first (an ordinary load pending beside LDS-DMAs makes the compiler wait for vmcnt(0) at its first use).
+    int v_next = v, m0_next = m0, n0_next = n0;
+    bool has_next = false;
+    if constexpr (PERSIST) {
+        v_next = v + (int)gridDim.x;
+        has_next = v_next < ntiles;
+        __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0) (bias / s / row-table loads); on BOTH paths (else the join waits)
+        if (has_next) {
+            tile_coords(v_next, m0_next, n0_next);
+            set_sources(m0_next, n0_next);
+            ISSUE_HALF_A(0, 0) ISSUE_HALF_B(HALF, 0)
+        }
+    }
+
     if constexpr (EPI == EPI_STORE_T || EPI == EPI_ACT_T || FOLD) {
         // two passes of 64 rows x 64 cols of 16-bit: LDS rows of 128 B, 16-B chunks XOR-swizzled by (row & 7)
         // ACTC: std::integral_constant<int, -1 | ACT_GELU | ACT_QUICKGELU> - the activation is fixed at compile time inside
@@ -268,10 +308,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii) {
                 const int i = 4 * pass + ii;
-                const int row = 16 * ii + frow;
+                const int row = 16 * ii + efrow;
                 float v[4][4];
                 if constexpr (FOLD) {
-                    const float2 rs = *(const float2*)(smem + 8 * SLICE + (wm * 128 + 16 * i + frow) * 8);
+                    const float2 rs = rs_all[i];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         v[j][0] = lnfold_apply(acc[i][j][0], rs.x, rs.y, s4[j].x, bias4[j].x);
@@ -293,9 +333,21 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int c = 2 * j + (fq >> 1);
-                    *(uint2*)(sl + row * 128 + ((c ^ (row & 7)) << 4) + (fq & 1) * 8) = pack4<TT>(v[j][0], v[j][1], v[j][2], v[j][3]);
+                    const uint2 pk = pack4<TT>(v[j][0], v[j][1], v[j][2], v[j][3]);
+                    char* dst = sl + row * 128 + ((c ^ (row & 7)) << 4) + (fq & 1) * 8;
+                    if constexpr (PERSIST) {
+                        // the next tile's LDS-DMAs are in flight: a compiler-visible LDS store here makes hipcc wait vmcnt(0)
+                        // for them (possible write-after-write on LDS; slots 0-1 and the slices are disjoint) -> opaque store
+                        typedef __attribute__((address_space(3))) char lds_char_t;
+                        const unsigned off = (unsigned)(uintptr_t)(lds_char_t*)dst;
+                        const unsigned long long pk64 = __builtin_bit_cast(unsigned long long, pk);
+                        asm volatile("ds_write_b64 %0, %1" ::"v"(off), "v"(pk64) : "memory");
+                    } else {
+                        *(uint2*)dst = pk;
+                    }
                 }
             }
+            if constexpr (PERSIST) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the flush below reads what was just staged
         };
         typedef std::integral_constant<int, -1> NoAct;
         typedef std::integral_constant<int, ACT_GELU> Gelu;
@@ -303,13 +355,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
         auto flush16 = [&](int pass, u16* dst) {
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
-                const int row = 8 * it + (lane >> 3), pc = lane & 7;
-                const uint4 v = *(const uint4*)(sl + row * 128 + (pc << 4));
-                const int m = mb + 64 * pass + row;
-                if (m < p.M) {
-                    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-                    __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, v), (u32x4_t*)(dst + (size_t)m * p.ldc + nb + ((pc ^ (row & 7)) << 3)));
+                const int row = 8 * it + (elane >> 3), pc = elane & 7;
+                typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+                u32x4_t v;
+                if constexpr (PERSIST) {
+                    typedef __attribute__((address_space(3))) char lds_char_t;
+                    const unsigned off = (unsigned)(uintptr_t)(lds_char_t*)(sl + row * 128 + (pc << 4));
+                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(off) : "memory");
+                } else {
+                    v = *(const u32x4_t*)(sl + row * 128 + (pc << 4));
                 }
+                const int m = mb + 64 * pass + row;
+                if (m < p.M)
+                    __builtin_nontemporal_store(v, (u32x4_t*)(dst + (size_t)m * p.ldc + nb + ((pc ^ (row & 7)) << 3)));
             }
         };
         constexpr bool ACTIVE = (EPI == EPI_ACT_T || EPI == EPI_LNFOLD_ACT_T);
@@ -335,7 +393,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
             if (beta != 0.f) {   // fetch the residual rows of this pass first: 8 coalesced 16-B loads in flight
 #pragma unroll
                 for (int it = 0; it < 8; ++it) {
-                    const int row = 4 * it + (lane >> 4), pc = lane & 15;
+                    const int row = 4 * it + (elane >> 4), pc = elane & 15;
                     const int m = mb + 32 * pass + row;
                     res[it] = m < p.M ? *(const float4*)(rsrc + (size_t)m * p.ldc + nb + ((pc ^ (row & 15)) << 2))
                                       : float4{0.f, 0.f, 0.f, 0.f};
@@ -344,7 +402,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
 #pragma unroll
             for (int ii = 0; ii < 2; ++ii) {
                 const int i = 2 * pass + ii;
-                const int row = 16 * ii + frow;
+                const int row = 16 * ii + efrow;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int c = 4 * j + fq;
@@ -355,7 +413,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
             }
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
-                const int row = 4 * it + (lane >> 4), pc = lane & 15;
+                const int row = 4 * it + (elane >> 4), pc = elane & 15;
                 float4 v = *(const float4*)(sl + row * 256 + (pc << 4));
                 const int m = mb + 32 * pass + row;
                 if (beta != 0.f) {
@@ -381,6 +439,31 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
         }
     }
     STAMP(4)
+    if constexpr (!PERSIST) break;
+    if (!has_next) break;
+    // exactly NSTORE stores behind the prefetch: a full tile without the optional pre-activation stash
+    counted = (m0 + BM <= p.M) && !(EPI == EPI_ACT_T && p.aux);
+    first = false;
+    v = v_next; m0 = m0_next; n0 = n0_next;
+  }
+#undef ADV
+#undef DMA16
+#undef ISSUE_A
+#undef ISSUE_B
+#undef ISSUE_HALF_A
+#undef ISSUE_HALF_B
+#undef READ_FRAGS
+#undef MROW
+#undef MFMA_H1
+#undef MFMA_H2
+#undef SYNC_TILE
+#undef KSTEP
+#undef MF
+#undef RDW
+#undef RDX
+#undef NOP_
+#undef SB
+#undef LD
 }
 
 // N tiles per group: minimise the bytes that miss L2.  A group's B panels (G x 256 rows x K) stay resident in an XCD's L2
@@ -410,29 +493,46 @@ template <class TT>
 hipError_t launch256h(const GemmArgs& p_in, int epi, hipStream_t s) {
     GemmArgs p = p_in;
     p.ngroup = pick_ngroup(p);
-    const int grid = ((p.M + BM - 1) / BM) * (p.N / BN);
-#define LEAF_CASE(E)                                                                                         \
-    case E: {                                                                                                \
+    const int ntiles = ((p.M + BM - 1) / BM) * (p.N / BN);
+    // persistent form for the 16-bit-output epilogues (QKV, c_fc): one workgroup per CU; LEAF_GEMM_PERSIST=0 disables (A/B)
+    static int persist_on = -1, ncu = 0;
+    if (persist_on < 0) {
+        const char* e = getenv("LEAF_GEMM_PERSIST");
+        persist_on = (e && e[0] == '0') ? 0 : 1;
+        int dev = 0;
+        hipDeviceProp_t prop;
+        ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+        ncu = ncu >= 8 ? ncu / 8 * 8 : 8;      // a multiple of the 8 XCDs keeps every workgroup's tiles on one XCD
+    }
+#define LEAF_LAUNCH(E, PS, GRID)                                                                             \
+    {                                                                                                        \
         static bool attr_done = false;                                                                       \
         if (!attr_done) {                                                                                    \
-            (void)hipFuncSetAttribute((const void*)gemm_nt256_half_kernel<TT, E>,                            \
+            (void)hipFuncSetAttribute((const void*)gemm_nt256_half_kernel<TT, E, PS>,                        \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, RING);                     \
             attr_done = true;                                                                                \
         }                                                                                                    \
-        hipLaunchKernelGGL((gemm_nt256_half_kernel<TT, E>), dim3(grid), dim3(512), RING, s, p);              \
-        break;                                                                                               \
+        hipLaunchKernelGGL((gemm_nt256_half_kernel<TT, E, PS>), dim3(GRID), dim3(512), RING, s, p);          \
     }
+#define LEAF_CASE(E)  case E: LEAF_LAUNCH(E, false, ntiles) break;
+#define LEAF_CASE_P(E)                                                                                       \
+    case E:                                                                                                  \
+        if (persist_on && ntiles > ncu) LEAF_LAUNCH(E, true, ncu)                                            \
+        else LEAF_LAUNCH(E, false, ntiles)                                                                   \
+        break;
     switch (epi) {
-        LEAF_CASE(EPI_STORE_T)
-        LEAF_CASE(EPI_ACT_T)
+        LEAF_CASE_P(EPI_STORE_T)
+        LEAF_CASE_P(EPI_ACT_T)
         LEAF_CASE(EPI_RESID_F32)
         LEAF_CASE(EPI_STORE_F32)
-        LEAF_CASE(EPI_LNFOLD_T)
-        LEAF_CASE(EPI_LNFOLD_ACT_T)
+        LEAF_CASE_P(EPI_LNFOLD_T)
+        LEAF_CASE_P(EPI_LNFOLD_ACT_T)
         LEAF_CASE(EPI_RESID_LN)
         default: return hipErrorInvalidValue;
     }
 #undef LEAF_CASE
+#undef LEAF_CASE_P
+#undef LEAF_LAUNCH
     return hipGetLastError();
 }
 

@@ -31,9 +31,10 @@ for name, epi, N, K in [("qkv", 0, 3 * d, d), ("out", 2, d, d), ("fc", 1, 4 * d,
     torch.cuda.synchronize()
     lib.leaf_debug_gemm_stamps(None)
     s = stamps.cpu().numpy().reshape(nblk, 8)[:, :5].astype(np.float64)
+    s = s[s[:, 4] > 0]            # the persistent form records the LAST tile of each of its (one per CU) workgroups
     seg = np.diff(s, axis=1)
     tot = s[:, 4] - s[:, 0]
     names = ["first DMA wait", "K loop (main)", "K tail", "epilogue"]
-    print(f"{name}: N={N} K={K} blocks={nblk} median block {np.median(tot):.0f} ticks; kernel span {(s[:,4].max()-s[:,0].min()):.0f} ticks")
+    print(f"{name}: N={N} K={K} tiles={nblk} stamped workgroups={len(s)} median tile {np.median(tot):.0f} ticks; kernel span {(s[:,4].max()-s[:,0].min()):.0f} ticks")
     for i, n in enumerate(names):
         print(f"   {n:22s} median {np.median(seg[:, i]):9.0f}  mean {seg[:, i].mean():9.0f}  ({100 * seg[:, i].sum() / tot.sum():5.1f}%)")
