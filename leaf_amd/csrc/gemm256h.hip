@@ -299,7 +299,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
         }
     }
 
-    if constexpr (EPI == EPI_STORE_T || EPI == EPI_ACT_T || FOLD) {
+    if constexpr (EPI == EPI_STORE_T || EPI == EPI_ACT_T || EPI == EPI_ACTGRAD_T || FOLD) {
         // two passes of 64 rows x 64 cols of 16-bit: LDS rows of 128 B, 16-B chunks XOR-swizzled by (row & 7)
         // ACTC: std::integral_constant<int, -1 | ACT_GELU | ACT_QUICKGELU> - the activation is fixed at compile time inside
         // the element loops (a run-time id there costs one branch per element and serialises the transcendental chains)
@@ -318,6 +318,21 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
                         v[j][1] = lnfold_apply(acc[i][j][1], rs.x, rs.y, s4[j].y, bias4[j].y);
                         v[j][2] = lnfold_apply(acc[i][j][2], rs.x, rs.y, s4[j].z, bias4[j].z);
                         v[j][3] = lnfold_apply(acc[i][j][3], rs.x, rs.y, s4[j].w, bias4[j].w);
+                    }
+                } else if constexpr (EPI == EPI_ACTGRAD_T) {
+                    // backward of the MLP activation: C16 = acc * act'(pre), pre = the forward's stashed pre-activations (aux,
+                    // 16-bit of the forward dtype, same shape as C); rows past M are clamped for the load and never stored
+                    int mr = mb + 64 * pass + row;
+                    mr = mr < p.M ? mr : p.M - 1;
+                    uint2 u[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) u[j] = *(const uint2*)((const u16*)p.aux + (size_t)mr * p.ldc + nb + 16 * j + 4 * fq);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float pre[4];
+                        if (p.aux_f16) unpack4<F16>(u[j], pre); else unpack4<BF16>(u[j], pre);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[j][e] = acc[i][j][e] * act_bwd(pre[e], p.act);
                     }
                 } else {
 #pragma unroll
@@ -525,6 +540,7 @@ hipError_t launch256h(const GemmArgs& p_in, int epi, hipStream_t s) {
         LEAF_CASE_P(EPI_ACT_T)
         LEAF_CASE(EPI_RESID_F32)
         LEAF_CASE(EPI_STORE_F32)
+        LEAF_CASE(EPI_ACTGRAD_T)
         LEAF_CASE_P(EPI_LNFOLD_T)
         LEAF_CASE_P(EPI_LNFOLD_ACT_T)
         LEAF_CASE(EPI_RESID_LN)
@@ -549,7 +565,7 @@ bool leaf_gemm256h_eligible(const GemmArgs& p, int epi) {
     const long tiles = (long)((p.M + BM - 1) / BM) * (p.N / BN);
     // the DMA sources are 32-bit byte offsets from the operand bases (saddr + voffset): both operands must span < 4 GiB
     const bool fits32 = (unsigned long long)p.M * p.lda * 2ull < (1ull << 32) && (unsigned long long)p.N * p.ldb * 2ull < (1ull << 32);
-    return p.N % BN == 0 && tiles >= g_min_tiles && p.K % BK == 0 && p.K >= 4 * BK && p.ldc % 8 == 0 && epi != EPI_ACTGRAD_T && fits32;
+    return p.N % BN == 0 && tiles >= g_min_tiles && p.K % BK == 0 && p.K >= 4 * BK && p.ldc % 8 == 0 && fits32;
 }
 
 hipError_t leaf_launch_gemm256h(const GemmArgs& p, int dtype, int epi, hipStream_t s) {
