@@ -39,7 +39,9 @@ def write_csv(path, acc, counter):
 
 
 def short(name):
-    m = re.search(r"(\w+)<(\w+), (\d+)>", name)
+    """'void (anonymous namespace)::gemm_nt256_half_kernel<F16, 7, false>(GemmArgs)' -> 'gemm_nt256_half_kernel<F16,7>' (the name
+    bench.py builds from its profiler key: kernel family, operand type, epilogue id)."""
+    m = re.search(r"(\w+)<(\w+), (\d+)(?:, \w+)*>", name)
     return f"{m.group(1)}<{m.group(2)},{m.group(3)}>" if m else name
 
 
