@@ -145,32 +145,41 @@ def allreduce_grads(model) -> float:
     return 1.0
 
 
-def bucket_plan(layout, n_params: int, layers: int):
-    """Gradient buckets in the order the backward finishes them: one per transformer block (its four GEMM weights, a
-    contiguous 12 d^2 run of the flat buffer -- 28 MB for ViT-L), blocks L-1 .. 0, then ONE last bucket list with everything
-    else (embedding tables + text_projection in front of the block weights; every bias / LayerNorm vector + ln_final behind
-    them), which is complete only after the backward's last kernel.  Returns [(event index, [(offset, numel), ...]), ...];
-    the ranges partition [0, n_params) (tests/test_dp_gloo.py)."""
-    def span(names):
+def bucket_plan(layout, n_params: int, layers: int, min_bytes: int = 64 << 20):
+    """Gradient buckets in the order the backward finishes them.  The four GEMM weights of a transformer block are one
+    contiguous 12 d^2 run of the flat buffer (28 MB for ViT-L) and consecutive blocks are adjacent, so a bucket is the run of
+    one or more consecutive blocks, grown downwards from block L-1 until it holds at least ``min_bytes`` (fewer, larger
+    collectives: ViT-L -> 3 blocks = 85 MB per bucket, bigG -> 1 block = 79 MB); its event is the LOWEST block's, the one
+    that finishes last.  ONE last bucket list takes everything else (embedding tables + text_projection in front of the block
+    weights; every bias / LayerNorm vector + ln_final behind them), complete only after the backward's last kernel.
+    Returns [(event index, [(offset, numel), ...]), ...]; the ranges partition [0, n_params) (tests/test_dp_gloo.py)."""
+    def span(l):
+        p = f"transformer.resblocks.{l}."
+        names = [p + "attn.in_proj_weight", p + "attn.out_proj.weight", p + "mlp.c_fc.weight", p + "mlp.c_proj.weight"]
         lo = min(layout[k][0] for k in names)
         hi = max(layout[k][0] + int(np.prod(layout[k][1])) for k in names)
         return lo, hi
-    plan, w_lo, w_hi = [], None, None
+    plan = []
+    w_lo, w_hi = span(0)[0], span(layers - 1)[1]
+    hi = None
     for l in reversed(range(layers)):
-        p = f"transformer.resblocks.{l}."
-        lo, hi = span([p + "attn.in_proj_weight", p + "attn.out_proj.weight", p + "mlp.c_fc.weight", p + "mlp.c_proj.weight"])
-        plan.append((l, [(lo, hi - lo)]))
-        w_lo = lo if w_lo is None else min(w_lo, lo)
-        w_hi = hi if w_hi is None else max(w_hi, hi)
+        lo, h_ = span(l)
+        if hi is None:
+            hi = h_
+        if (hi - lo) * 4 >= min_bytes or l == 0:
+            plan.append((l, [(lo, hi - lo)]))
+            hi = None
+        else:
+            assert span(l - 1)[1] == lo, "block weights are expected back to back in the flat layout"
     plan.append((layers, [(0, w_lo), (w_hi, n_params - w_hi)]))
     return plan
 
 
 class GradReducer:
     """Data-parallel gradient mean overlapped with the backward.  The backward records one
-    event per transformer block as soon as that block's gradients are final (leaf_textfare_backward_events); each block's
-    weight bucket is then all-reduced (RCCL, sum) on a side stream while the backward of the earlier blocks is still
-    running; only the last bucket (embedding tables + vectors) is exposed.  Every rank issues the same collectives in the
+    event per transformer block as soon as that block's gradients are final (leaf_textfare_backward_events); the weight
+    buckets (runs of consecutive blocks, >= 64 MB each: bucket_plan) are all-reduced (RCCL, sum) on a side stream while the
+    backward of the earlier blocks is still running; only the last bucket (embedding tables + vectors) is exposed.  Every rank issues the same collectives in the
     same order.  LEAF_DP_OVERLAP=0 (or world size 1) falls back to ONE flat all-reduce after the backward.
     The 1/world factor is folded into the AdamW kernel (``finish()`` returns it)."""
 

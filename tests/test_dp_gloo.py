@@ -89,18 +89,25 @@ def test_bucket_plan_partitions_the_gradient_buffer(name):
     cfg = MODEL_CONFIGS[name]
     layout, n = _layout_for(cfg)
     plan = bucket_plan(layout, n, cfg.layers)
-    assert [ev for ev, _ in plan] == list(reversed(range(cfg.layers))) + [cfg.layers]
-    cover = np.zeros(n, dtype=np.int8) if n < 2e8 else None
+    evs = [ev for ev, _ in plan]
+    assert evs[-1] == cfg.layers and evs[:-1] == sorted(evs[:-1], reverse=True) and evs[-2] == 0, "completion order, block 0 last"
     spans = sorted((off, off + m) for _, ranges in plan for off, m in ranges if m)
     assert spans[0][0] == 0 and spans[-1][1] == n and all(a[1] == b[0] for a, b in zip(spans, spans[1:])), "gap or overlap"
+    per_block = 12 * cfg.width ** 2
+    hi_layer = cfg.layers - 1
     for ev, ranges in plan[:-1]:
         (off, m), = ranges
-        p = f"transformer.resblocks.{ev}."
-        want = sum(int(np.prod(layout[p + k][1])) for k in ("attn.in_proj_weight", "attn.out_proj.weight", "mlp.c_fc.weight", "mlp.c_proj.weight"))
-        assert m == want == 12 * cfg.width ** 2
+        nblk = hi_layer - ev + 1                       # blocks ev .. hi_layer, the lowest one finishes last
+        assert m == nblk * per_block
+        assert m * 4 >= (64 << 20) or ev == 0, "buckets hold at least 64 MB (except the remainder at block 0)"
         for k, (o, shp) in layout.items():
             inside = off <= o < off + m
-            assert inside == (k.startswith(p) and k.endswith("weight") and "ln_" not in k), k
+            blk = int(k.split(".")[2]) if k.startswith("transformer.resblocks.") else -1
+            assert inside == (ev <= blk <= hi_layer and k.endswith("weight") and "ln_" not in k), k
+        hi_layer = ev - 1
+    assert hi_layer == -1
+    # one block per bucket when asked for
+    assert [ev for ev, _ in bucket_plan(layout, n, cfg.layers, min_bytes=1)] == list(reversed(range(cfg.layers))) + [cfg.layers]
 
 
 def _bucket_worker(rank, world, port, out):
