@@ -8,6 +8,9 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef uint16_t u16;
@@ -30,6 +33,15 @@ struct F16 {
         return (_Float16)x;                                           // v_cvt_f16_f32, RTN-even
     }
     static __device__ __forceinline__ float to_f32(elem x) { return (float)x; }
+    // two elements: v_cvt_pk_f16_f32 (RTN-even, overflow -> inf) then the saturation on the PACKED halves (v_pk_min_f16 /
+    // v_pk_max_f16: one instruction per pair instead of one v_med3_f32 per element).  Same value as from_f32 for every
+    // non-NaN input: a float in (65504, 65520) rounds to 65504 either way, anything beyond saturates either way.
+    static __device__ __forceinline__ unsigned pack2(f32x2 v) {
+        f16x2 h = {(_Float16)v.x, (_Float16)v.y};
+        h = __builtin_elementwise_min(h, (f16x2){(_Float16)65504.f, (_Float16)65504.f});
+        h = __builtin_elementwise_max(h, (f16x2){(_Float16)-65504.f, (_Float16)-65504.f});
+        return __builtin_bit_cast(unsigned, h);
+    }
 };
 struct BF16 {
     using elem = __bf16;
@@ -43,13 +55,15 @@ struct BF16 {
     }
     static __device__ __forceinline__ elem from_f32(float x) { return (__bf16)x; }  // RTN-even, NaN kept
     static __device__ __forceinline__ float to_f32(elem x) { return (float)x; }
+    static __device__ __forceinline__ unsigned pack2(f32x2 v) {
+        bf16x2 h = {(__bf16)v.x, (__bf16)v.y};
+        return __builtin_bit_cast(unsigned, h);
+    }
 };
 
 template <class TT>
 __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
-    typename TT::vec4 v;
-    v[0] = TT::from_f32(a); v[1] = TT::from_f32(b); v[2] = TT::from_f32(c); v[3] = TT::from_f32(d);
-    return __builtin_bit_cast(uint2, v);
+    return uint2{TT::pack2(f32x2{a, b}), TT::pack2(f32x2{c, d})};
 }
 // pack4 without the fp16 saturation clamp, for values whose magnitude is bounded by construction (softmax
 // probabilities; attention outputs = convex combinations of 16-bit V values): one v_med3 less per element
@@ -113,6 +127,34 @@ __device__ __forceinline__ float act_fwd(float x, int act) {
     if (act == ACT_QUICKGELU) return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-2.4554669595930157f * x));
     return 0.5f * x * (1.f + fast_erf(x * 0.70710678118654752f));
 }
+// Two elements at once on the packed-f32 VALU ops (v_pk_mul / v_pk_add / v_pk_fma_f32: two lanes per issue slot; the
+// transcendentals stay scalar).  Per element this is the SAME sequence of roundings as act_fwd above (the build uses
+// -ffp-contract=off), so a value does not depend on which form a kernel uses.
+__device__ __forceinline__ f32x2 fast_erf2(f32x2 x) {
+    const f32x2 ax = {__builtin_fabsf(x.x), __builtin_fabsf(x.y)};
+    const f32x2 d = __builtin_elementwise_fma(f32x2{0.3275911f, 0.3275911f}, ax, f32x2{1.0f, 1.0f});
+    const f32x2 t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    f32x2 p = __builtin_elementwise_fma(t, f32x2{1.061405429f, 1.061405429f}, f32x2{-1.453152027f, -1.453152027f});
+    p = __builtin_elementwise_fma(t, p, f32x2{1.421413741f, 1.421413741f});
+    p = __builtin_elementwise_fma(t, p, f32x2{-0.284496736f, -0.284496736f});
+    p = __builtin_elementwise_fma(t, p, f32x2{0.254829592f, 0.254829592f});
+    const f32x2 q = (ax * -1.4426950408889634f) * ax;
+    const f32x2 e = {__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)};
+    const f32x2 r = 1.0f - (p * t) * e;
+    return f32x2{__builtin_copysignf(r.x, x.x), __builtin_copysignf(r.y, x.y)};
+}
+template <int ACT>
+__device__ __forceinline__ f32x2 act_fwd2(f32x2 x) {
+    if constexpr (ACT < 0) return x;
+    else if constexpr (ACT == ACT_QUICKGELU) {
+        const f32x2 z = x * -2.4554669595930157f;
+        const f32x2 u = f32x2{__builtin_amdgcn_exp2f(z.x), __builtin_amdgcn_exp2f(z.y)} + 1.f;
+        return x * f32x2{__builtin_amdgcn_rcpf(u.x), __builtin_amdgcn_rcpf(u.y)};
+    } else {
+        return (x * 0.5f) * (fast_erf2(x * 0.70710678118654752f) + 1.f);
+    }
+}
+
 // compile-time selected form for the GEMM epilogues (ACT < 0: identity): with the activation id a run-time value inside
 // the per-element loop the compiler emitted one branch per ELEMENT and a serial mul-exp-add-rcp-mul chain per lane
 template <int ACT>

@@ -69,13 +69,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
     tile_coords(v, m0, n0);
 
     // ---- DMA sources: wave w moves pieces 4w..4w+3 (8 rows x 128 B) of whichever panel a half-stage carries
-    const int prow = lane >> 3;
-    const int schunk = (lane & 7) ^ prow;
     const char* __restrict__ A = (const char*)p.A;
     const char* __restrict__ B = (const char*)p.B;
     // 32-bit byte offsets from the (uniform) operand bases: saddr + voffset addressing, 5 VGPRs instead of 10
     unsigned a0, a1, a2, a3, b0;
-    auto set_sources = [&](int m0_, int n0_) {
+    // (ln = the lane id; the persistent epilogue passes its opaque copy so that nothing of this is hoisted out of the tile loop
+    // and kept -- spilled -- across the K loop)
+    auto set_sources = [&](int m0_, int n0_, int ln) {
+        const int prow = ln >> 3;
+        const int schunk = (ln & 7) ^ prow;
         auto arow = [&](int j) { int r = m0_ + wid * 32 + 8 * j + prow; return r < p.M ? r : p.M - 1; };
         a0 = (unsigned)arow(0) * (unsigned)p.lda * 2u + schunk * 16;
         a1 = (unsigned)arow(1) * (unsigned)p.lda * 2u + schunk * 16;
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
         a3 = (unsigned)arow(3) * (unsigned)p.lda * 2u + schunk * 16;
         b0 = (unsigned)(n0_ + wid * 32 + prow) * (unsigned)p.ldb * 2u + schunk * 16;
     };
-    set_sources(m0, n0);
+    set_sources(m0, n0, lane);
     const unsigned bstep = 16u * (unsigned)p.ldb;   // 8 rows, bytes
     const int piece = wid * 4096;
 #ifdef LEAF_DIAG_NODMA   // diagnostic only: no operand traffic at all (results are garbage) - isolates the MFMA + LDS-read loop
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
         __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0) (bias / s / row-table loads); on BOTH paths (else the join waits)
         if (has_next) {
             tile_coords(v_next, m0_next, n0_next);
-            set_sources(m0_next, n0_next);
+            set_sources(m0_next, n0_next, elane);
             ISSUE_HALF_A(0, 0) ISSUE_HALF_B(HALF, 0)
         }
     }
@@ -309,15 +311,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
             for (int ii = 0; ii < 4; ++ii) {
                 const int i = 4 * pass + ii;
                 const int row = 16 * ii + efrow;
-                float v[4][4];
+                // two adjacent columns per operation: packed-f32 VALU ops (v_pk_fma / v_pk_mul / v_pk_add_f32), the same
+                // roundings per element as the scalar forms of the register-direct epilogues (gemm_epilogue.h)
+                f32x2 v[4][2];
                 if constexpr (FOLD) {
                     const float2 rs = rs_all[i];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        v[j][0] = lnfold_apply(acc[i][j][0], rs.x, rs.y, s4[j].x, bias4[j].x);
-                        v[j][1] = lnfold_apply(acc[i][j][1], rs.x, rs.y, s4[j].y, bias4[j].y);
-                        v[j][2] = lnfold_apply(acc[i][j][2], rs.x, rs.y, s4[j].z, bias4[j].z);
-                        v[j][3] = lnfold_apply(acc[i][j][3], rs.x, rs.y, s4[j].w, bias4[j].w);
+                        v[j][0] = lnfold_apply2(f32x2{acc[i][j][0], acc[i][j][1]}, rs.x, rs.y, f32x2{s4[j].x, s4[j].y}, f32x2{bias4[j].x, bias4[j].y});
+                        v[j][1] = lnfold_apply2(f32x2{acc[i][j][2], acc[i][j][3]}, rs.x, rs.y, f32x2{s4[j].z, s4[j].w}, f32x2{bias4[j].z, bias4[j].w});
                     }
                 } else if constexpr (EPI == EPI_ACTGRAD_T) {
                     // backward of the MLP activation: C16 = acc * act'(pre), pre = the forward's stashed pre-activations (aux,
@@ -331,24 +333,25 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
                     for (int j = 0; j < 4; ++j) {
                         float pre[4];
                         if (p.aux_f16) unpack4<F16>(u[j], pre); else unpack4<BF16>(u[j], pre);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[j][e] = acc[i][j][e] * act_bwd(pre[e], p.act);
+                        v[j][0] = f32x2{acc[i][j][0] * act_bwd(pre[0], p.act), acc[i][j][1] * act_bwd(pre[1], p.act)};
+                        v[j][1] = f32x2{acc[i][j][2] * act_bwd(pre[2], p.act), acc[i][j][3] * act_bwd(pre[3], p.act)};
                     }
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        v[j][0] = acc[i][j][0] + bias4[j].x; v[j][1] = acc[i][j][1] + bias4[j].y;
-                        v[j][2] = acc[i][j][2] + bias4[j].z; v[j][3] = acc[i][j][3] + bias4[j].w;
+                        v[j][0] = f32x2{acc[i][j][0], acc[i][j][1]} + f32x2{bias4[j].x, bias4[j].y};
+                        v[j][1] = f32x2{acc[i][j][2], acc[i][j][3]} + f32x2{bias4[j].z, bias4[j].w};
                     }
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[j][e] = act_fwd_t<ACT>(v[j][e]);     // 16 independent chains
+                for (int j = 0; j < 4; ++j) {
+                    v[j][0] = act_fwd2<ACT>(v[j][0]);     // 8 independent pairs
+                    v[j][1] = act_fwd2<ACT>(v[j][1]);
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int c = 2 * j + (fq >> 1);
-                    const uint2 pk = pack4<TT>(v[j][0], v[j][1], v[j][2], v[j][3]);
+                    const uint2 pk = uint2{TT::pack2(v[j][0]), TT::pack2(v[j][1])};
                     char* dst = sl + row * 128 + ((c ^ (row & 7)) << 4) + (fq & 1) * 8;
                     if constexpr (PERSIST) {
                         // the next tile's LDS-DMAs are in flight: a compiler-visible LDS store here makes hipcc wait vmcnt(0)
@@ -368,21 +371,39 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
         typedef std::integral_constant<int, ACT_GELU> Gelu;
         typedef std::integral_constant<int, ACT_QUICKGELU> QuickGelu;
         auto flush16 = [&](int pass, u16* dst) {
+            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+            u32x4_t fv[8];
+            if constexpr (PERSIST) {
+                // all eight reads of the pass in flight at once (rows 8 it + lane / 8: 1 KiB apart), each store then waits for
+                // its own read only (LDS returns a wave's reads in order: lgkmcnt(7 - it))
+                typedef __attribute__((address_space(3))) char lds_char_t;
+                const unsigned off = (unsigned)(uintptr_t)(lds_char_t*)(sl + (elane >> 3) * 128 + ((elane & 7) << 4));
+                asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:1024\n\tds_read_b128 %2, %8 offset:2048\n\t"
+                             "ds_read_b128 %3, %8 offset:3072\n\tds_read_b128 %4, %8 offset:4096\n\tds_read_b128 %5, %8 offset:5120\n\t"
+                             "ds_read_b128 %6, %8 offset:6144\n\tds_read_b128 %7, %8 offset:7168"
+                             : "=&v"(fv[0]), "=&v"(fv[1]), "=&v"(fv[2]), "=&v"(fv[3]), "=&v"(fv[4]), "=&v"(fv[5]), "=&v"(fv[6]), "=&v"(fv[7])
+                             : "v"(off) : "memory");
+            }
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int row = 8 * it + (elane >> 3), pc = elane & 7;
-                typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-                u32x4_t v;
                 if constexpr (PERSIST) {
-                    typedef __attribute__((address_space(3))) char lds_char_t;
-                    const unsigned off = (unsigned)(uintptr_t)(lds_char_t*)(sl + row * 128 + (pc << 4));
-                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(off) : "memory");
+                    switch (it) {   // the wait is tied to the value it releases ("+v"): its store cannot move above it
+                        case 0: asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(fv[0]) :: "memory"); break;
+                        case 1: asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(fv[1]) :: "memory"); break;
+                        case 2: asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(fv[2]) :: "memory"); break;
+                        case 3: asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fv[3]) :: "memory"); break;
+                        case 4: asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fv[4]) :: "memory"); break;
+                        case 5: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fv[5]) :: "memory"); break;
+                        case 6: asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(fv[6]) :: "memory"); break;
+                        default: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fv[7]) :: "memory"); break;
+                    }
                 } else {
-                    v = *(const u32x4_t*)(sl + row * 128 + (pc << 4));
+                    fv[it] = *(const u32x4_t*)(sl + row * 128 + (pc << 4));
                 }
                 const int m = mb + 64 * pass + row;
                 if (m < p.M)
-                    __builtin_nontemporal_store(v, (u32x4_t*)(dst + (size_t)m * p.ldc + nb + ((pc ^ (row & 7)) << 3)));
+                    __builtin_nontemporal_store(fv[it], (u32x4_t*)(dst + (size_t)m * p.ldc + nb + ((pc ^ (row & 7)) << 3)));
             }
         };
         constexpr bool ACTIVE = (EPI == EPI_ACT_T || EPI == EPI_LNFOLD_ACT_T);

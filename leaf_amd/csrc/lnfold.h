@@ -46,6 +46,11 @@ __device__ __forceinline__ float lnfold_apply(float acc, float mean, float rstd,
     return __builtin_fmaf(rstd, __builtin_fmaf(-mean, s, acc), c);
 }
 
+// ... and for two adjacent columns of one row on v_pk_fma_f32 (the same two roundings per element)
+__device__ __forceinline__ f32x2 lnfold_apply2(f32x2 acc, float mean, float rstd, f32x2 s, f32x2 c) {
+    return __builtin_elementwise_fma(f32x2{rstd, rstd}, __builtin_elementwise_fma(f32x2{-mean, -mean}, s, acc), c);
+}
+
 // chunk-level pieces of the producer's reduction: a lane holds 4 consecutive columns
 __device__ __forceinline__ float lnfold_sum4(float a, float b, float c, float d) { return (a + b) + (c + d); }
 __device__ __forceinline__ float lnfold_dev4(float a, float b, float c, float d, float mean) {

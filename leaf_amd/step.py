@@ -71,25 +71,27 @@ class SyntheticCandidates:
         ids = torch.randint(1, self.vocab - 2, (B, rho), device=cur.device, generator=self.gen, dtype=torch.int32)
         return cur[:, None, :].repeat(1, rho, 1), ids
 
-    def _apply(self, drawn, pos_host):
-        cand, ids = drawn
-        pos = torch.from_numpy(pos_host).pin_memory().to(cand.device, non_blocking=True)
-        cand.scatter_(2, pos[:, :, None], ids[:, :, None])
-        return cand
-
     def stage1(self, cur: torch.Tensor):
         import numpy as np
         pos = 1 + (self.rng.random((self.B, self.rho)) * self.inner[:, None]).astype(np.int64)
-        return self._apply(self._draw(cur), pos), pos
+        cand, ids = self._draw(cur)
+        self.pos1_dev = torch.from_numpy(pos).pin_memory().to(cand.device, non_blocking=True)
+        cand.scatter_(2, self.pos1_dev[:, :, None], ids[:, :, None])
+        return cand, pos
 
-    def stage2_draw(self, cur: torch.Tensor):
-        return self._draw(cur)
+    def stage2_device(self, cur: torch.Tensor, best1: torch.Tensor):
+        """The stage-2 candidate ids, built ON THE DEVICE from the stage-1 arg-max (no host round trip): queued behind stage 1
+        BEFORE the host waits for the winners, so after that wait only the row plan is left to do."""
+        cand, ids = self._draw(cur)
+        p = self.pos1_dev.gather(1, best1.to(torch.int64)[:, None])          # [B, 1] winning positions
+        cand.scatter_(2, p[:, :, None].expand(self.B, self.rho, 1), ids[:, :, None])
+        return cand
 
-    def stage2(self, drawn, pos, best1_host):
+    def stage2_positions(self, pos, best1_host):
+        """Host copy of the stage-2 edit positions (the prefix lengths of the row plan)."""
         import numpy as np
         p = pos[np.arange(self.B), best1_host]
-        pos2 = np.repeat(p[:, None], self.rho, axis=1)
-        return self._apply(drawn, pos2), pos2
+        return np.repeat(p[:, None], self.rho, axis=1)
 
 
 def search_synthetic(model, anchor: torch.Tensor, base: torch.Tensor, cfg: StepConfig, seed: int,
@@ -113,8 +115,8 @@ def search_synthetic(model, anchor: torch.Tensor, base: torch.Tensor, cfg: StepC
             anchor_ready = None
         best1, _ = model.score_candidates(cand.view(B * cfg.rho, -1), anchor, cfg.rho, "l2", want_features=False,
                                           seq_lens=cand_lens, prefix_lens=pos.reshape(-1) if reuse else None, kv=kv)
-        drawn = gen.stage2_draw(cur)                                     # queued behind stage 1, before the host waits
-        cand, pos2 = gen.stage2(drawn, pos, best1.cpu().numpy())        # the search's device->host sync (B indices)
+        cand = gen.stage2_device(cur, best1)                             # queued behind stage 1, before the host waits
+        pos2 = gen.stage2_positions(pos, best1.cpu().numpy())           # the search's device->host sync (B indices)
         best2, _ = model.score_candidates(cand.view(B * cfg.rho, -1), anchor, cfg.rho, "l2", want_features=False,
                                           seq_lens=cand_lens, prefix_lens=pos2.reshape(-1) if reuse else None, kv=kv)
         cur = cand[ar, best2.to(torch.int64)]
