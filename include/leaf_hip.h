@@ -230,6 +230,14 @@ int leaf_op_attention_bwd_t(const void* qkv, int qkv_dtype, const void* dout16, 
  * (dY [rows,Nw] in g_dtype, X [rows,Kw] in x_dtype, alpha a device scalar or NULL = 1; Nw, Kw multiples of 128) */
 int leaf_op_wgrad(const void* dY, const void* X, float* dW, float* db, int rows, int Nw, int Kw, int x_dtype,
                   int g_dtype, const float* alpha_dev, leaf_stream_t s);
+/* LayerNorm backward of `rows` rows (autograd of F.layer_norm, src/open_clip/transformer.py:15-30): dx_inout[rows,d] +=
+ * d LN / d x, dx16 (optional) = its 16-bit copy (g_dtype), dg[d] += sum_r dy * xhat / S, db[d] += sum_r dy / S with
+ * gscale = {S, 1/S} on the device (the loss scale of the fp16 gradient path); dg = db = NULL: input gradient only.
+ * ws: leaf_op_layernorm_bwd_ws_bytes(rows, d) bytes of device scratch for the per-workgroup partial sums (needed with dg) */
+size_t leaf_op_layernorm_bwd_ws_bytes(int rows, int d);
+int leaf_op_layernorm_bwd(const float* dy, const float* x, const float* g, float eps, float* dx_inout, void* dx16,
+                          int g_dtype, const float* gscale, float* dg, float* db, int rows, int d, void* ws, size_t ws_bytes,
+                          leaf_stream_t s);
 /* out[M,D] = [normalize](LayerNorm(xg[M,d]; g, b) @ proj[d,D]) in fp32 on the matrix cores; xn_scratch = fp32 [M,d] */
 int leaf_op_project_rows(const float* xg, const float* g, const float* b, float eps, const float* proj,
                          float* xn_scratch, float* out, int M, int d, int D, int normalize, leaf_stream_t s);

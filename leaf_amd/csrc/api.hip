@@ -641,6 +641,21 @@ extern "C" int leaf_op_wgrad(const void* dY, const void* X, float* dW, float* db
     wa.nprob = 1; wa.rows = rows; wa.alpha = alpha_dev;
     return leaf_check(leaf_launch_wgrad_group(wa, x_dtype, g_dtype, (hipStream_t)s), "wgrad_group");
 }
+extern "C" size_t leaf_op_layernorm_bwd_ws_bytes(int rows, int d) {
+    return (size_t)leaf_ln_bwd_grid(rows, d) * 2 * d * sizeof(float);
+}
+extern "C" int leaf_op_layernorm_bwd(const float* dy, const float* x, const float* g, float eps, float* dx_inout, void* dx16,
+                                     int g_dtype, const float* gscale, float* dg, float* db, int rows, int d, void* ws,
+                                     size_t ws_bytes, leaf_stream_t s) {
+    if (!dy || !x || !g || !dx_inout || !gscale || rows < 1 || (dg == nullptr) != (db == nullptr)) { leaf_set_error("layernorm_bwd: null/invalid argument"); return 1; }
+    if (dg && (!ws || ws_bytes < leaf_op_layernorm_bwd_ws_bytes(rows, d))) { leaf_set_error("layernorm_bwd: workspace too small (need %zu bytes)", leaf_op_layernorm_bwd_ws_bytes(rows, d)); return 1; }
+    LEAF_TRY(leaf_launch_layernorm_bwd(dy, x, g, eps, dx_inout, dx16, g_dtype == LEAF_F16 ? 1 : 0, dg ? (float*)ws : nullptr, rows, d, (hipStream_t)s));
+    if (!dg) return 0;
+    LnReduceArgs ra{};
+    ra.part = (const float*)ws; ra.n = 1; ra.grid = leaf_ln_bwd_grid(rows, d); ra.d = d; ra.inv_s = gscale + 1;
+    ra.dg[0] = dg; ra.db[0] = db;
+    return leaf_check(leaf_launch_ln_param_reduce(ra, (hipStream_t)s), "ln_param_reduce");
+}
 extern "C" int leaf_op_project_rows(const float* xg, const float* g, const float* b, float eps, const float* proj,
                                     float* xn_scratch, float* out, int M, int d, int D, int normalize, leaf_stream_t s) {
     if (!leaf_project_rows_ok(d, D)) { leaf_set_error("project_rows needs D %% 128 == 0 and d %% 16 == 0"); return 1; }

@@ -54,6 +54,7 @@ struct BwdBuf {
     uint16_t* tB;     // [4d,rpad] bf16
     float* dout;      // [n,D]
     float* gscale;    // {S, 1/S}
+    float* lnpart;    // [2 layers][leaf_ln_bwd_grid][2][d] per-workgroup partial sums of the LayerNorm parameter gradients
 };
 
 BwdBuf carve_bwd(const leaf_text* h, Carver& c, int n_seq, size_t rows) {
@@ -71,6 +72,7 @@ BwdBuf carve_bwd(const leaf_text* h, Carver& c, int n_seq, size_t rows) {
     b.tB = (uint16_t*)c.take(4 * d * rpad * 2);
     b.dout = (float*)c.take((size_t)n_seq * h->cfg.embed_dim * 4);
     b.gscale = (float*)c.take(256 + (size_t)n_seq * 8);   // {S, 1/S} + per-caption loss partials
+    b.lnpart = (float*)c.take((size_t)2 * h->cfg.layers * leaf_ln_bwd_grid((int)rows, (int)d) * 2 * d * 4);
     return b;
 }
 
@@ -194,6 +196,8 @@ static int backward_impl(leaf_text_t h, const float* P, const void* w16_bwd, con
     static int grouped = -1;
     if (grouped < 0) { const char* e = getenv("LEAF_WGRAD"); grouped = (e && e[0] == '0') ? 0 : 1; }
 
+    const int ln_grid = leaf_ln_bwd_grid(rows, d);
+    const size_t ln_stride = (size_t)ln_grid * 2 * d;      // floats per LayerNorm in b.lnpart
     for (int l = L - 1; l >= 0; --l) {
         const LayerOff& o = h->layer[l];
         const float* xin = st.xin + l * rd; const float* x1 = st.x1 + l * rd;
@@ -212,8 +216,8 @@ static int backward_impl(leaf_text_t h, const float* P, const void* w16_bwd, con
         }
         if (leaf_gemm(gk, EPI_STORE_F32, b.big16, 4 * d, WT + h->w16_fc(l), 4 * d, b.dxn, d, nullptr, nullptr, rows, d,
                  4 * d, 0, s)) return 1;
-        LEAF_TRY(leaf_launch_layernorm_bwd(b.dxn, x1, P + o.ln2_w, cf.ln_eps, b.dx, b.dx16b, gk, b.gscale,
-                                           G ? G + o.ln2_w : nullptr, G ? G + o.ln2_b : nullptr, rows, d, s));
+        LEAF_TRY(leaf_launch_layernorm_bwd(b.dxn, x1, P + o.ln2_w, cf.ln_eps, b.dx, b.dx16b, gk,
+                                           G ? b.lnpart + (size_t)(2 * l + 1) * ln_stride : nullptr, rows, d, s));
         // ---- attention
         if (G && !grouped) {
             if (wgrad(b.dx16b, d, ao, fk, d, G + o.out_w)) return 1;
@@ -239,10 +243,25 @@ static int backward_impl(leaf_text_t h, const float* P, const void* w16_bwd, con
         }
         if (leaf_gemm(gk, EPI_STORE_F32, b.dqkv, 3 * d, WT + h->w16_qkv(l), 3 * d, b.dxn, d, nullptr, nullptr, rows, d,
                  3 * d, 0, s)) return 1;
-        LEAF_TRY(leaf_launch_layernorm_bwd(b.dxn, xin, P + o.ln1_w, cf.ln_eps, b.dx, b.dx16, gk, b.gscale,
-                                           G ? G + o.ln1_w : nullptr, G ? G + o.ln1_b : nullptr, rows, d, s));
+        LEAF_TRY(leaf_launch_layernorm_bwd(b.dxn, xin, P + o.ln1_w, cf.ln_eps, b.dx, b.dx16, gk,
+                                           G ? b.lnpart + (size_t)(2 * l) * ln_stride : nullptr, rows, d, s));
         // every gradient of block l is final here: the caller may start reducing this block's bucket (step.py)
         if (layer_events && layer_events[l]) LEAF_TRY(hipEventRecord((hipEvent_t)layer_events[l], s));
+    }
+    if (G) {
+        // LayerNorm parameter gradients of all blocks: one reduction of the per-workgroup partials (LN_REDUCE_MAX per launch)
+        for (int i0 = 0; i0 < 2 * L; i0 += LN_REDUCE_MAX) {
+            LnReduceArgs ra{};
+            ra.n = 2 * L - i0 < LN_REDUCE_MAX ? 2 * L - i0 : LN_REDUCE_MAX;
+            ra.part = b.lnpart + (size_t)i0 * ln_stride; ra.grid = ln_grid; ra.d = d; ra.inv_s = inv_s;
+            for (int i = 0; i < ra.n; ++i) {
+                const LayerOff& o = h->layer[(i0 + i) >> 1];
+                const bool second = (i0 + i) & 1;
+                ra.dg[i] = G + (second ? o.ln2_w : o.ln1_w);
+                ra.db[i] = G + (second ? o.ln2_b : o.ln1_b);
+            }
+            LEAF_TRY(leaf_launch_ln_param_reduce(ra, s));
+        }
     }
     if (G) LEAF_TRY(leaf_launch_embed_bwd(b.dx, b.gscale, tokens, G + h->tok_emb, G + h->pos_emb, rows, n_seq, map, d, cf.vocab_size, s));
     if (d_embed) LEAF_TRY(leaf_launch_scale_copy(b.dx, inv_s, d_embed, rd, s));   // d loss / d (token embedding), un-scaled

@@ -120,10 +120,21 @@ hipError_t leaf_launch_pool_project_bwd(const float* dout, const float* pooled, 
                                         const float* g, const float* b, float eps, const float* proj, float* dx,
                                         float* dproj, float* dg, float* db, const float* gscale, int n_seq, RowMap map,
                                         int d, int D, float* scratch /* [n_seq, d + 2] fp32 */, hipStream_t s);
-// dx_out = dx_in + LNbwd(dy, x, g);  dg += .../S, db += .../S;  dx16 = 16-bit(dx_out) of kind gkind (optional)
+// dx_out = dx_in + LNbwd(dy, x, g); dx16 = 16-bit(dx_out) of kind gkind (optional).  Parameter gradients: with `part` the launch
+// writes leaf_ln_bwd_grid(rows, d) per-workgroup partial sums part[wg][2][d] = (sum_r dy xhat | sum_r dy) over the
+// workgroup's rows (fixed order, no atomics); leaf_launch_ln_param_reduce adds them to dg / db for many LayerNorms at once.
+int leaf_ln_bwd_grid(int rows, int d);
 hipError_t leaf_launch_layernorm_bwd(const float* dy, const float* x, const float* g, float eps, float* dx_inout,
-                                     void* dx16, int gkind, const float* gscale, float* dg, float* db, int rows, int d,
-                                     hipStream_t s);
+                                     void* dx16, int gkind, float* part, int rows, int d, hipStream_t s);
+constexpr int LN_REDUCE_MAX = 64;
+struct LnReduceArgs {
+    const float* part;            // [n][grid][2][d]
+    float* dg[LN_REDUCE_MAX];     // dg[i][c] += inv_s * sum_wg part[i][wg][0][c]
+    float* db[LN_REDUCE_MAX];     // db[i][c] += inv_s * sum_wg part[i][wg][1][c]
+    const float* inv_s;           // device scalar (1 / loss scale)
+    int n, grid, d;
+};
+hipError_t leaf_launch_ln_param_reduce(const LnReduceArgs& a, hipStream_t s);
 // dbias[n] += sum_r dy[r,n] / S   (dy 16-bit of kind gkind, row stride ld)
 hipError_t leaf_launch_colsum(const void* dy16, int gkind, const float* gscale, int ld, int rows, int n, float* dbias,
                               hipStream_t s);

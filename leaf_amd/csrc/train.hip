@@ -274,38 +274,49 @@ __global__ __launch_bounds__(256) void pool_ln_wgrad_kernel(const float* __restr
     db[c] += sb;
 }
 
-// grid-stride over rows, one wave per row; per-lane column partials for dg/db reduced at the end
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                     const float* __restrict__ g, float eps, float* __restrict__ dx,
-                                                     void* __restrict__ dx16, int gkind, const float* __restrict__ gscale,
-                                                     float* __restrict__ dg, float* __restrict__ db, int rows, int d) {
+// LayerNorm backward.  One wave per row, SIXTEEN waves per workgroup (rows blockIdx * NW + wave, grid-stride): at the 3,200
+// rows of a training batch every wave owns one row, so x / dy / dx of all rows are in flight at once instead of four rows in
+// sequence per wave.  Parameter gradients: every wave accumulates (dy xhat | dy) of its rows in a private [2][d] fp32 image in
+// LDS, the workgroup sums the NW images in wave order and writes ONE partial row part[blockIdx][2][d]; a single launch at the
+// end of the backward (ln_param_reduce_kernel) adds the partials of every LayerNorm of the tower to dg / db.  No atomics:
+// the first version's 310 k same-address global atomics per launch cost 33 of its 47 us, and the result is now deterministic.
+// NCH = float4 chunks per lane = ceil(d / 256) (3 for ViT-L, 4 ViT-H, 5 bigG), NW = waves per workgroup: 16 while the row fits
+// 128 VGPRs (NCH <= 4), else 8.
+template <int NCH, int NW>
+__global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                         const float* __restrict__ g, float eps, float* __restrict__ dx,
+                                                         void* __restrict__ dx16, int gkind, float* __restrict__ part,
+                                                         int rows, int d) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int nq = d >> 2;
-    float4 pg[MAXCH], pb[MAXCH], gg[MAXCH];
+    float4* mine = (float4*)smem + (size_t)wid * 2 * nq;   // this wave's [2][d] image: dg | db terms
+    float4 gg[NCH];
 #pragma unroll
-    for (int i = 0; i < MAXCH; ++i) {
-        pg[i] = float4{0.f, 0.f, 0.f, 0.f}; pb[i] = pg[i];
-        int c = lane + 64 * i;
+    for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i;
         gg[i] = c < nq ? *(const float4*)(g + 4 * c) : float4{0.f, 0.f, 0.f, 0.f};
+        if (part && c < nq) { mine[c] = float4{0.f, 0.f, 0.f, 0.f}; mine[nq + c] = float4{0.f, 0.f, 0.f, 0.f}; }
     }
-    for (int row = blockIdx.x * 4 + wid; row < rows; row += gridDim.x * 4) {
+    for (int row = blockIdx.x * NW + wid; row < rows; row += gridDim.x * NW) {
         const float* xr = x + (size_t)row * d;
         const float* dyr = dy + (size_t)row * d;
-        float4 xv[MAXCH], dv[MAXCH];
+        float* dxr = dx + (size_t)row * d;
+        float4 xv[NCH], dv[NCH], ov[NCH];
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXCH; ++i) {
-            int c = lane + 64 * i;
+        for (int i = 0; i < NCH; ++i) {     // all three streams of the row requested up front
+            const int c = lane + 64 * i;
             if (c < nq) {
-                xv[i] = *(const float4*)(xr + 4 * c); dv[i] = *(const float4*)(dyr + 4 * c);
+                xv[i] = *(const float4*)(xr + 4 * c); dv[i] = *(const float4*)(dyr + 4 * c); ov[i] = *(const float4*)(dxr + 4 * c);
                 s += (xv[i].x + xv[i].y) + (xv[i].z + xv[i].w);
             }
         }
         const float mu = wave_sum(s) / (float)d;
         float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXCH; ++i) {
-            int c = lane + 64 * i;
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
             if (c < nq) {
                 xv[i].x -= mu; xv[i].y -= mu; xv[i].z -= mu; xv[i].w -= mu;
                 q += (xv[i].x * xv[i].x + xv[i].y * xv[i].y) + (xv[i].z * xv[i].z + xv[i].w * xv[i].w);
@@ -314,13 +325,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
         float m1 = 0.f, m2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXCH; ++i) {
-            int c = lane + 64 * i;
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
             if (c < nq) {
                 xv[i].x *= rstd; xv[i].y *= rstd; xv[i].z *= rstd; xv[i].w *= rstd;   // xhat
-                pg[i].x = fmaf(dv[i].x, xv[i].x, pg[i].x); pg[i].y = fmaf(dv[i].y, xv[i].y, pg[i].y);
-                pg[i].z = fmaf(dv[i].z, xv[i].z, pg[i].z); pg[i].w = fmaf(dv[i].w, xv[i].w, pg[i].w);
-                pb[i].x += dv[i].x; pb[i].y += dv[i].y; pb[i].z += dv[i].z; pb[i].w += dv[i].w;
+                if (part) {   // the image belongs to this wave alone: plain read-modify-write
+                    float4 pg = mine[c], pb = mine[nq + c];
+                    pg.x = fmaf(dv[i].x, xv[i].x, pg.x); pg.y = fmaf(dv[i].y, xv[i].y, pg.y);
+                    pg.z = fmaf(dv[i].z, xv[i].z, pg.z); pg.w = fmaf(dv[i].w, xv[i].w, pg.w);
+                    pb.x += dv[i].x; pb.y += dv[i].y; pb.z += dv[i].z; pb.w += dv[i].w;
+                    mine[c] = pg; mine[nq + c] = pb;
+                }
                 dv[i].x *= gg[i].x; dv[i].y *= gg[i].y; dv[i].z *= gg[i].z; dv[i].w *= gg[i].w;  // dxhat
                 m1 += (dv[i].x + dv[i].y) + (dv[i].z + dv[i].w);
                 m2 += (dv[i].x * xv[i].x + dv[i].y * xv[i].y) + (dv[i].z * xv[i].z + dv[i].w * xv[i].w);
@@ -328,12 +343,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         }
         m1 = wave_sum(m1) / (float)d;
         m2 = wave_sum(m2) / (float)d;
-        float* dxr = dx + (size_t)row * d;
 #pragma unroll
-        for (int i = 0; i < MAXCH; ++i) {
-            int c = lane + 64 * i;
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + 64 * i;
             if (c < nq) {
-                float4 o = *(float4*)(dxr + 4 * c);
+                float4 o = ov[i];
                 o.x += rstd * (dv[i].x - m1 - xv[i].x * m2); o.y += rstd * (dv[i].y - m1 - xv[i].y * m2);
                 o.z += rstd * (dv[i].z - m1 - xv[i].z * m2); o.w += rstd * (dv[i].w - m1 - xv[i].w * m2);
                 *(float4*)(dxr + 4 * c) = o;
@@ -341,24 +355,39 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             }
         }
     }
-    if (!dg) return;   // input-gradient-only backward (embedding-space PGD): no parameter gradients wanted
-    // block-level reduction of the per-wave column partials through LDS, then one atomic per column per block
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4* red = (float4*)smem;   // [4 waves][2][nq]
-#pragma unroll
-    for (int i = 0; i < MAXCH; ++i) {
-        int c = lane + 64 * i;
-        if (c < nq) { red[(wid * 2 + 0) * nq + c] = pg[i]; red[(wid * 2 + 1) * nq + c] = pb[i]; }
-    }
+    if (!part) return;   // input-gradient-only backward (embedding-space PGD): no parameter gradients wanted
     __syncthreads();
-    for (int c = threadIdx.x; c < 2 * nq; c += 256) {
-        const int which = c / nq, cc = c - which * nq;
-        float4 a = red[(0 * 2 + which) * nq + cc], b1 = red[(1 * 2 + which) * nq + cc];
-        float4 b2 = red[(2 * 2 + which) * nq + cc], b3 = red[(3 * 2 + which) * nq + cc];
-        float* dst = (which ? db : dg) + 4 * cc;
-        const float inv = gscale[1];
-        atomicAdd(dst + 0, ((a.x + b1.x) + (b2.x + b3.x)) * inv); atomicAdd(dst + 1, ((a.y + b1.y) + (b2.y + b3.y)) * inv);
-        atomicAdd(dst + 2, ((a.z + b1.z) + (b2.z + b3.z)) * inv); atomicAdd(dst + 3, ((a.w + b1.w) + (b2.w + b3.w)) * inv);
+    const float4* img = (const float4*)smem;
+    float4* dst = (float4*)(part + (size_t)blockIdx.x * 2 * d);
+    for (int c = threadIdx.x; c < 2 * nq; c += NW * 64) {
+        float4 a = img[c];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) {
+            const float4 t = img[(size_t)w * 2 * nq + c];
+            a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+        }
+        dst[c] = a;
+    }
+}
+
+// dg[i][c] += inv_s * sum_wg part[i][wg][0][c] (db likewise) for n LayerNorms in one launch: grid (n, 2d / 64), a workgroup
+// owns 64 columns, its four waves sum a quarter of the partial rows each (ascending), combined in wave order: deterministic
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(LnReduceArgs a) {
+    __shared__ float red[4][64];
+    const int i = blockIdx.x, cg = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cg;              // column of the [2][d] partial row
+    const int per = (a.grid + 3) / 4;
+    const int p0 = rg * per, p1 = p0 + per < a.grid ? p0 + per : a.grid;
+    const float* src = a.part + (size_t)i * a.grid * 2 * a.d + c;
+    float sum = 0.f;
+    if (c < 2 * a.d)
+        for (int p = p0; p < p1; ++p) sum += src[(size_t)p * 2 * a.d];
+    red[rg][cg] = sum;
+    __syncthreads();
+    if (rg == 0 && c < 2 * a.d) {
+        const float t = ((red[0][cg] + red[1][cg]) + red[2][cg]) + red[3][cg];
+        float* dst = c < a.d ? a.dg[i] + c : a.db[i] + (c - a.d);
+        *dst += t * a.inv_s[0];
     }
 }
 
@@ -679,14 +708,45 @@ hipError_t leaf_launch_pool_project_bwd(const float* dout, const float* pooled, 
     return hipGetLastError();
 }
 
+static int ln_bwd_nw(int d) { return (d / 4 + 63) / 64 <= 4 ? 16 : 8; }
+int leaf_ln_bwd_grid(int rows, int d) {
+    const int nw = ln_bwd_nw(d);
+    const int grid = (rows + nw - 1) / nw;
+    return grid > 256 ? 256 : grid < 1 ? 1 : grid;
+}
+
 hipError_t leaf_launch_layernorm_bwd(const float* dy, const float* x, const float* g, float eps, float* dx_inout,
-                                     void* dx16, int gkind, const float* gscale, float* dg, float* db, int rows, int d,
-                                     hipStream_t s) {
+                                     void* dx16, int gkind, float* part, int rows, int d, hipStream_t s) {
     if (d % 4 || d > 256 * MAXCH) return hipErrorInvalidValue;
-    int grid = (rows + 15) / 16;
-    if (grid > 256) grid = 256;
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), (size_t)8 * d * sizeof(float), s, dy, x, g, eps, dx_inout,
-                       dx16, gkind, gscale, dg, db, rows, d);
+    const int nch = (d / 4 + 63) / 64;
+    const int grid = leaf_ln_bwd_grid(rows, d);
+#define LEAF_LN_BWD(N, NW)                                                                                             \
+    {                                                                                                                  \
+        const size_t lds = part ? (size_t)NW * 2 * d * sizeof(float) : 0;                                              \
+        static bool attr = false;                                                                                      \
+        if (!attr) {                                                                                                   \
+            (void)hipFuncSetAttribute((const void*)ln_bwd_kernel<N, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                      NW * 2 * 256 * N * (int)sizeof(float));                                          \
+            attr = true;                                                                                               \
+        }                                                                                                              \
+        hipLaunchKernelGGL((ln_bwd_kernel<N, NW>), dim3(grid), dim3(NW * 64), lds, s, dy, x, g, eps, dx_inout, dx16, gkind, \
+                           part, rows, d);                                                                             \
+    }
+    switch (nch) {
+        case 1: LEAF_LN_BWD(1, 16) break;
+        case 2: LEAF_LN_BWD(2, 16) break;
+        case 3: LEAF_LN_BWD(3, 16) break;
+        case 4: LEAF_LN_BWD(4, 16) break;
+        case 5: LEAF_LN_BWD(5, 8) break;
+        default: LEAF_LN_BWD(MAXCH, 8) break;
+    }
+#undef LEAF_LN_BWD
+    return hipGetLastError();
+}
+
+hipError_t leaf_launch_ln_param_reduce(const LnReduceArgs& a, hipStream_t s) {
+    if (a.n < 1 || a.n > LN_REDUCE_MAX || a.grid < 1 || a.d % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(a.n, (2 * a.d + 63) / 64), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -7,7 +7,7 @@
 // materialising dY^T and X^T (two transposes per weight, the first implementation) the 32-row operand slabs are staged
 // row-major in LDS and read as MFMA fragments with the gfx950 transposing read ds_read_b64_tr_b16.
 //
-// Tile 128 (n) x 128 (k), 4 waves of 64 x 64, k-step = 32 rows, register-staged double buffering, one barrier per step.
+// Tile 128 (n) x 128 (k), 4 waves of 64 x 64, k-step = 32 rows, two slabs in LDS + three in flight in registers, one barrier per step.
 // The problems of a block (c_proj, c_fc, out_proj, in_proj) share one launch: blockIdx -> (problem, tile) through a
 // small table, so the 432 tiles of a ViT-L block fill the chip where the largest single weight has 144.
 // Column sums (bias gradients) are accumulated by the blocks of the first k-tile column while they stage dY and reduced
@@ -72,24 +72,27 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(WgradArgs a) {
     const u16* xp = P.X + (size_t)srow * P.ldx + k0 + sch * 8;
     const size_t ystep = (size_t)16 * P.ldy, xstep = (size_t)16 * P.ldx;
     const int lds_off = srow * (LD * 2) + sch * 16;
-    u32x4 y0, y1, x0, x1;
+    // three slabs in flight in registers (sets 0-2, slab j lives in set j % 3) on top of the two in LDS: with one slab of
+    // look-ahead every 32-row step waited a full memory round trip for 16 MFMAs per wave (1.7 k cycles per step: 107 us per
+    // ViT-L block at 3,200 rows)
+    u32x4 y0[3], y1[3], x0[3], x1[3];
     const u32x4 z4 = u32x4{0u, 0u, 0u, 0u};
-#define LOAD_SLAB(ks)                                                                                       \
+#define LOAD_SLAB(S, ks)                                                                                    \
     {                                                                                                       \
         const int r_ = (ks) * KS + srow;                                                                    \
         const size_t oy_ = (size_t)(ks) * KS * P.ldy, ox_ = (size_t)(ks) * KS * P.ldx;                      \
-        y0 = r_ < rows ? *(const u32x4*)(yp + oy_) : z4;                                                    \
-        x0 = r_ < rows ? cvt8<XT, GT>(*(const u32x4*)(xp + ox_)) : z4;                                      \
-        y1 = r_ + 16 < rows ? *(const u32x4*)(yp + oy_ + ystep) : z4;                                       \
-        x1 = r_ + 16 < rows ? cvt8<XT, GT>(*(const u32x4*)(xp + ox_ + xstep)) : z4;                         \
+        y0[S] = r_ < rows ? *(const u32x4*)(yp + oy_) : z4;                                                 \
+        x0[S] = r_ < rows ? cvt8<XT, GT>(*(const u32x4*)(xp + ox_)) : z4;                                   \
+        y1[S] = r_ + 16 < rows ? *(const u32x4*)(yp + oy_ + ystep) : z4;                                    \
+        x1[S] = r_ + 16 < rows ? cvt8<XT, GT>(*(const u32x4*)(xp + ox_ + xstep)) : z4;                      \
     }
-#define STORE_SLAB(buf)                                                                                     \
+#define STORE_SLAB(S, buf)                                                                                  \
     {                                                                                                       \
         char* yb_ = smem + (buf) * 2 * SLAB;                                                                \
-        *(u32x4*)(yb_ + lds_off) = y0;                                                                      \
-        *(u32x4*)(yb_ + lds_off + 16 * LD * 2) = y1;                                                        \
-        *(u32x4*)(yb_ + SLAB + lds_off) = x0;                                                               \
-        *(u32x4*)(yb_ + SLAB + lds_off + 16 * LD * 2) = x1;                                                 \
+        *(u32x4*)(yb_ + lds_off) = y0[S];                                                                   \
+        *(u32x4*)(yb_ + lds_off + 16 * LD * 2) = y1[S];                                                     \
+        *(u32x4*)(yb_ + SLAB + lds_off) = x0[S];                                                            \
+        *(u32x4*)(yb_ + SLAB + lds_off + 16 * LD * 2) = x1[S];                                              \
     }
     float cs[8];
 #pragma unroll
@@ -111,32 +114,39 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(WgradArgs a) {
     const int g = lane >> 4;
     const int nk = (rows + KS - 1) / KS;
 
-    LOAD_SLAB(0)
-    if (do_bias) { ADD_COLS(y0) ADD_COLS(y1) }
-    STORE_SLAB(0)
+    LOAD_SLAB(0, 0)
+    LOAD_SLAB(1, 1)       // (slabs past the last row load nothing: zero registers)
+    LOAD_SLAB(2, 2)
+    if (do_bias) { ADD_COLS(y0[0]) ADD_COLS(y1[0]) }
+    STORE_SLAB(0, 0)
     __syncthreads();
-    for (int ks = 0; ks < nk; ++ks) {
-        const int buf = ks & 1;
-        if (ks + 1 < nk) {
-            LOAD_SLAB(ks + 1)
-        }
-        const char* yb = smem + buf * 2 * SLAB;
-        const char* xb = yb + SLAB;
-        typename GT::vec8 bf[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bf[j] = __builtin_bit_cast(typename GT::vec8, tr8(xb, 8 * g, wn * 64 + 16 * j, lane));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const typename GT::vec8 af = __builtin_bit_cast(typename GT::vec8, tr8(yb, 8 * g, wm * 64 + 16 * i, lane));
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = GT::mfma(af, bf[j], acc[i][j]);
-        }
-        if (ks + 1 < nk) {
-            if (do_bias) { ADD_COLS(y0) ADD_COLS(y1) }
-            STORE_SLAB(buf ^ 1)
-        }
-        __syncthreads();
+    // one 32-row step: request slab ks + 3 into the set slab ks came from, multiply slab ks out of LDS, move slab ks + 1 from
+    // its registers into the other LDS buffer
+#define STEP(S_CUR, S_NEXT, ks)                                                                             \
+    {                                                                                                       \
+        const int buf = (ks) & 1;                                                                           \
+        LOAD_SLAB(S_CUR, (ks) + 3)                                                                          \
+        const char* yb = smem + buf * 2 * SLAB;                                                             \
+        const char* xb = yb + SLAB;                                                                         \
+        typename GT::vec8 bf[4];                                                                            \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                       \
+            bf[j] = __builtin_bit_cast(typename GT::vec8, tr8(xb, 8 * g, wn * 64 + 16 * j, lane));          \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                     \
+            const typename GT::vec8 af = __builtin_bit_cast(typename GT::vec8, tr8(yb, 8 * g, wm * 64 + 16 * i, lane)); \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = GT::mfma(af, bf[j], acc[i][j]);       \
+        }                                                                                                   \
+        if ((ks) + 1 < nk) {                                                                                \
+            if (do_bias) { ADD_COLS(y0[S_NEXT]) ADD_COLS(y1[S_NEXT]) }                                      \
+            STORE_SLAB(S_NEXT, buf ^ 1)                                                                     \
+        }                                                                                                   \
+        __syncthreads();                                                                                    \
     }
+    for (int ks = 0; ks < nk; ks += 3) {
+        STEP(0, 1, ks)
+        if (ks + 1 < nk) STEP(1, 2, ks + 1)
+        if (ks + 2 < nk) STEP(2, 0, ks + 2)
+    }
+#undef STEP
 #undef LOAD_SLAB
 #undef STORE_SLAB
 #undef ADD_COLS

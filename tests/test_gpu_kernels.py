@@ -206,6 +206,45 @@ def test_wgrad_group(env, xdt, gdt, rows, Nw, Kw):
     assert rel_l2(tb.cpu().numpy(), want_b) < 2e-6
 
 
+@pytest.mark.parametrize("with_params", [True, False])
+@pytest.mark.parametrize("rows,d", [(3219, 768), (800, 1024), (130, 1280), (7, 128), (40, 2048)])
+def test_layernorm_bwd(env, with_params, rows, d):
+    """LayerNorm backward (train.hip ln_bwd_kernel: dx += dLN/dx, 16-bit copy, dg / db += column sums / S) against float64
+    numpy; every tower width has its own instantiation (float4 chunks per lane, waves per workgroup)."""
+    lib, torch, dev = env
+    from leaf_amd import _lib
+    rng = np.random.default_rng(rows + d)
+    x = (rng.standard_normal((rows, d)) * 2 + 0.3).astype(np.float32)
+    dy = rng.standard_normal((rows, d)).astype(np.float32)
+    g = (1 + 0.1 * rng.standard_normal(d)).astype(np.float32)
+    dx0 = rng.standard_normal((rows, d)).astype(np.float32)
+    dg0, db0 = rng.standard_normal(d).astype(np.float32), rng.standard_normal(d).astype(np.float32)
+    S = 8.0
+    x64, dy64 = x.astype(np.float64), dy.astype(np.float64)
+    mu = x64.mean(-1, keepdims=True)
+    rstd = 1.0 / np.sqrt(x64.var(-1, keepdims=True) + 1e-5)
+    xhat = (x64 - mu) * rstd
+    dxhat = dy64 * g
+    want_dx = dx0 + rstd * (dxhat - dxhat.mean(-1, keepdims=True) - xhat * (dxhat * xhat).mean(-1, keepdims=True))
+    want_dg = dg0 + (dy64 * xhat).sum(0) / S
+    want_db = db0 + dy64.sum(0) / S
+    tx, tdy, tg, tdx, tdg, tdb = (torch.from_numpy(a.copy()).to(dev) for a in (x, dy, g, dx0, dg0, db0))
+    t16 = torch.zeros(rows, d, dtype=torch.float16, device=dev)
+    gs = torch.tensor([S, 1.0 / S], dtype=torch.float32, device=dev)
+    ws = torch.empty(lib.leaf_op_layernorm_bwd_ws_bytes(rows, d), dtype=torch.uint8, device=dev)
+    _lib.check(lib.leaf_op_layernorm_bwd(ptr(tdy), ptr(tx), ptr(tg), 1e-5, ptr(tdx), ptr(t16), DT["fp16"], ptr(gs),
+                                         ptr(tdg) if with_params else None, ptr(tdb) if with_params else None, rows, d,
+                                         ptr(ws), ws.numel(), stream()), "layernorm_bwd")
+    torch.cuda.synchronize()
+    got = tdx.cpu().numpy()
+    assert rel_l2(got, want_dx) < 2e-6
+    assert np.array_equal(t16.cpu().numpy(), np.clip(got, -65504, 65504).astype(np.float16))
+    if with_params:
+        assert rel_l2(tdg.cpu().numpy(), want_dg) < 5e-6 and rel_l2(tdb.cpu().numpy(), want_db) < 5e-6
+    else:
+        assert np.array_equal(tdg.cpu().numpy(), dg0) and np.array_equal(tdb.cpu().numpy(), db0)
+
+
 @pytest.mark.parametrize("normalize", [0, 1])
 @pytest.mark.parametrize("M,d,D", [(300, 768, 768), (64, 1024, 1024), (1, 1280, 1280), (130, 128, 128)])
 def test_project_rows(env, normalize, M, d, D):
