@@ -333,6 +333,7 @@ int leaf_gemm_family(const GemmArgs& p, int epi) {
 
 static void* g_stamps = nullptr;
 void leaf_gemm_set_stamps(void* p) { g_stamps = p; }
+void* leaf_gemm_get_stamps() { return g_stamps; }
 
 hipError_t leaf_launch_gemm(const GemmArgs& p_in, int dtype, int epi, hipStream_t s) {
     GemmArgs p = p_in;

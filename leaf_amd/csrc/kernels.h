@@ -152,7 +152,9 @@ struct WgradArgs {
     WgradProb p[4];
     int nprob, rows;
     const float* alpha;   // device scalar or null (1.0)
+    void* stamps;         // diagnostic builds only (-DLEAF_GEMM_STAMPS): 8 s_memtime slots per workgroup, or null
 };
+void* leaf_gemm_get_stamps();
 bool leaf_wgrad_tn_ok(int Nw, int Kw, int ldy, int ldx);
 hipError_t leaf_launch_wgrad_group(WgradArgs a, int x_dtype, int g_dtype, hipStream_t s);
 // transposed 16-bit copies of all layers' GEMM weights in one launch (train.hip)
