@@ -7,10 +7,10 @@
 // materialising dY^T and X^T (two transposes per weight, the first implementation) the 32-row operand slabs are staged
 // row-major in LDS and read as MFMA fragments with the gfx950 transposing read ds_read_b64_tr_b16.
 //
-// Tile 128 (n) x 128 (k), 4 waves of 64 x 64, k-step = 32 rows, software-pipelined over four LDS buffers, one barrier per step.
+// Tile 128 (n) x 128 (k), 4 waves of 64 x 64, k-step = 32 rows, one barrier per step.
 // Two kernels: wgrad_tn_dma_kernel (both operands of one 16-bit type, the default: slabs arrive by LDS-DMA into an
-// XOR-swizzled image) and wgrad_tn_kernel (X converted on the way: register-staged; LEAF_GRAD_DTYPE=bf16 beside an fp16
-// forward).  Measured per ViT-L block at 3,200 rows inside the step: 107 us (first version: one slab of look-ahead through
+// XOR-swizzled image, software-pipelined over four LDS buffers) and wgrad_tn_kernel (X converted on the way: register-staged,
+// double-buffered; LEAF_GRAD_DTYPE=bf16 beside an fp16 forward, or a bf16 forward beside fp16 gradients).  Measured per ViT-L block at 3,200 rows inside the step: 107 us (first version: one slab of look-ahead through
 // registers) -> 70 us; tools/wgrad_stamps.py for where a step's cycles go.
 // The problems of a block (c_proj, c_fc, out_proj, in_proj) share one launch: blockIdx -> (problem, tile) through a
 // small table, so the 432 tiles of a ViT-L block fill the chip where the largest single weight has 144.
@@ -26,8 +26,7 @@ namespace {
 constexpr int TM = 128, TN = 128, KS = 32;
 constexpr int LD = 136;                         // LDS row stride (elements): 272 B
 constexpr int SLAB = KS * LD * 2;               // 8,704 B
-constexpr int NBUF = 4;                         // LDS buffers (one dY + one X slab each)
-constexpr int LDS_BYTES = NBUF * 2 * SLAB;      // 69,632 B: two workgroups per CU
+constexpr int LDS_BYTES = 4 * SLAB;             // register-staged kernel: dY and X slabs, double-buffered: 34,816 B
 
 #ifdef LEAF_GEMM_STAMPS   // diagnostic builds: s_memtime at phase boundaries (tools/wgrad_stamps.py)
 #define WSTAMP(i)                                                                                         \
@@ -77,6 +76,11 @@ __device__ __forceinline__ u32x4 cvt8(u32x4 v) {
     }
 }
 
+// Register-staged form (operand types differ: X is converted on its way to LDS).  Compiler-managed loads, one slab of
+// look-ahead, two LDS buffers -- the first version of this kernel.  (A deeper pipeline with inline-asm loads and counted
+// waits was tried here and withdrawn: nothing ties an asynchronous load's destination registers to the later wait, so under
+// register pressure the compiler may move or re-use them while the load is in flight -- the bf16-forward / fp16-gradient
+// instantiation faulted.  The LDS-DMA form below has no such registers.)
 template <class XT, class GT>
 __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -98,49 +102,28 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(WgradArgs a) {
 
     // staging: thread -> (row = tid >> 4 [+16], 8-column chunk = tid & 15) of each 32 x 128 slab
     const int srow = tid >> 4, sch = tid & 15;
+    const u16* yp = P.dY + (size_t)srow * P.ldy + n0 + sch * 8;
+    const u16* xp = P.X + (size_t)srow * P.ldx + k0 + sch * 8;
+    const size_t ystep = (size_t)16 * P.ldy, xstep = (size_t)16 * P.ldx;
     const int lds_off = srow * (LD * 2) + sch * 16;
-    // Software pipeline, three stages deep beyond the loads: slab j is requested into register set j % NSET (NSET loads in
-    // flight), moved to LDS buffer j % NBUF during step j - 2, its MFMA fragments are read during step j - 1 (into the fragment
-    // set j % 2) and multiplied during step j.  The first version (one slab of look-ahead, stores / transposing reads / MFMAs
-    // of one slab back to back between two barriers) ran 1.3-1.7 k cycles per 32-row step for 256 cycles of MFMA per wave.
-    constexpr int NSET = 4;
-    u32x4 y0[NSET], y1[NSET], x0[NSET], x1[NSET];
+    u32x4 y0, y1, x0, x1;
     const u32x4 z4 = u32x4{0u, 0u, 0u, 0u};
-    // The loads are inline asm with COUNTED waits: with compiler-visible loads hipcc drains vmcnt(0) at the loop header (the
-    // loaded registers are loop-carried), which exposes a full memory round trip every trip instead of hiding three slabs of
-    // look-ahead.  Rows past the end are clamped for the address and zeroed when the slab is moved to LDS.
-#define LOAD_SLAB(S, ks)                                                                                    \
+#define LOAD_SLAB(ks)                                                                                       \
     {                                                                                                       \
-        const int ra_ = (ks) * KS + srow, rb_ = ra_ + 16;                                                   \
-        const size_t r0_ = ra_ < rows ? ra_ : rows - 1, r1_ = rb_ < rows ? rb_ : rows - 1;                  \
-        const u16* py0_ = P.dY + r0_ * P.ldy + n0 + sch * 8;                                                \
-        const u16* py1_ = P.dY + r1_ * P.ldy + n0 + sch * 8;                                                \
-        const u16* px0_ = P.X + r0_ * P.ldx + k0 + sch * 8;                                                 \
-        const u16* px1_ = P.X + r1_ * P.ldx + k0 + sch * 8;                                                 \
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(y0[S]) : "v"(py0_) : "memory");               \
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(x0[S]) : "v"(px0_) : "memory");               \
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(y1[S]) : "v"(py1_) : "memory");               \
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(x1[S]) : "v"(px1_) : "memory");               \
+        const int r_ = (ks) * KS + srow;                                                                    \
+        const size_t oy_ = (size_t)(ks) * KS * P.ldy, ox_ = (size_t)(ks) * KS * P.ldx;                      \
+        y0 = r_ < rows ? *(const u32x4*)(yp + oy_) : z4;                                                    \
+        x0 = r_ < rows ? cvt8<XT, GT>(*(const u32x4*)(xp + ox_)) : z4;                                      \
+        y1 = r_ + 16 < rows ? *(const u32x4*)(yp + oy_ + ystep) : z4;                                       \
+        x1 = r_ + 16 < rows ? cvt8<XT, GT>(*(const u32x4*)(xp + ox_ + xstep)) : z4;                         \
     }
-    // slab `ks` (register set S) is waited for while the 4 (NSET - 1) loads of the three younger slabs stay outstanding (vmcnt
-    // completes in order); the wait is tied to the registers it releases.  (In the prologue fewer are in flight: it over-waits.)
-#define WAIT_SLAB(S, ks)                                                                                    \
-    {                                                                                                       \
-        static_assert(NSET == 4, "the counted wait below is 4 (NSET - 1)");                                 \
-        asm volatile("s_waitcnt vmcnt(12)" : "+v"(y0[S]), "+v"(x0[S]), "+v"(y1[S]), "+v"(x1[S]) :: "memory"); \
-        const int ra_ = (ks) * KS + srow;                                                                   \
-        if (ra_ >= rows) { y0[S] = z4; x0[S] = z4; }                                                        \
-        if (ra_ + 16 >= rows) { y1[S] = z4; x1[S] = z4; }                                                   \
-        x0[S] = cvt8<XT, GT>(x0[S]);                                                                        \
-        x1[S] = cvt8<XT, GT>(x1[S]);                                                                        \
-    }
-#define STORE_SLAB(S, buf)                                                                                  \
+#define STORE_SLAB(buf)                                                                                     \
     {                                                                                                       \
         char* yb_ = smem + (buf) * 2 * SLAB;                                                                \
-        *(u32x4*)(yb_ + lds_off) = y0[S];                                                                   \
-        *(u32x4*)(yb_ + lds_off + 16 * LD * 2) = y1[S];                                                     \
-        *(u32x4*)(yb_ + SLAB + lds_off) = x0[S];                                                            \
-        *(u32x4*)(yb_ + SLAB + lds_off + 16 * LD * 2) = x1[S];                                              \
+        *(u32x4*)(yb_ + lds_off) = y0;                                                                      \
+        *(u32x4*)(yb_ + lds_off + 16 * LD * 2) = y1;                                                        \
+        *(u32x4*)(yb_ + SLAB + lds_off) = x0;                                                               \
+        *(u32x4*)(yb_ + SLAB + lds_off + 16 * LD * 2) = x1;                                                 \
     }
     float cs[8];
 #pragma unroll
@@ -162,57 +145,32 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(WgradArgs a) {
     const int g = lane >> 4;
     const int nk = (rows + KS - 1) / KS;
 
-    typename GT::vec8 af[2][4], bf[2][4];
-#define READ_FRAGS(F, buf)                                                                                  \
-    {                                                                                                       \
-        const char* yb_ = smem + (buf) * 2 * SLAB;                                                          \
-        const char* xb_ = yb_ + SLAB;                                                                       \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                       \
-            bf[F][j] = __builtin_bit_cast(typename GT::vec8, tr8(xb_, 8 * g, wn * 64 + 16 * j, lane));      \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                       \
-            af[F][i] = __builtin_bit_cast(typename GT::vec8, tr8(yb_, 8 * g, wm * 64 + 16 * i, lane));      \
-    }
-#define MOVE_SLAB(S, ks)   /* registers of slab ks -> LDS buffer ks % NBUF (+ its share of the bias column sums) */ \
-    {                                                                                                       \
-        WAIT_SLAB(S, ks)                                                                                    \
-        if ((ks) < nk) {                                                                                    \
-            if (do_bias) { ADD_COLS(y0[S]) ADD_COLS(y1[S]) }                                                \
-            STORE_SLAB(S, (ks) % NBUF)                                                                      \
-        }                                                                                                   \
-    }
-    WSTAMP(0)
-    LOAD_SLAB(0, 0)
-    LOAD_SLAB(1, 1)
-    LOAD_SLAB(2, 2)
-    LOAD_SLAB(3, 3)
-    MOVE_SLAB(0, 0)
-    LOAD_SLAB(0, 4)
-    MOVE_SLAB(1, 1)
+    LOAD_SLAB(0)
+    if (do_bias) { ADD_COLS(y0) ADD_COLS(y1) }
+    STORE_SLAB(0)
     __syncthreads();
-    READ_FRAGS(0, 0)
-    WSTAMP(1)
-    // step ks (sets / buffers / fragment sets are compile-time: the loop is unrolled by NSET = NBUF = 4): request slab ks + 5
-    // (slab ks + 4 is already in flight), move slab ks + 2 to LDS, read the fragments of slab ks + 1, multiply slab ks.  The
-    // buffer written here was last read (fragments of slab ks - 2) two steps and two barriers ago.
-#define STEP(U, ks)                                                                                         \
-    {                                                                                                       \
-        LOAD_SLAB((U + 1) % NSET, (ks) + 5)                                                                 \
-        MOVE_SLAB((U + 2) % NSET, (ks) + 2)                                                                 \
-        if ((ks) + 1 < nk) READ_FRAGS((U + 1) & 1, (U + 1) % NBUF)                                          \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                       \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = GT::mfma(af[U & 1][i], bf[U & 1][j], acc[i][j]); \
-        __syncthreads();                                                                                    \
+    for (int ks = 0; ks < nk; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < nk) {
+            LOAD_SLAB(ks + 1)
+        }
+        const char* yb = smem + buf * 2 * SLAB;
+        const char* xb = yb + SLAB;
+        typename GT::vec8 bf[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf[j] = __builtin_bit_cast(typename GT::vec8, tr8(xb, 8 * g, wn * 64 + 16 * j, lane));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const typename GT::vec8 af = __builtin_bit_cast(typename GT::vec8, tr8(yb, 8 * g, wm * 64 + 16 * i, lane));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = GT::mfma(af, bf[j], acc[i][j]);
+        }
+        if (ks + 1 < nk) {
+            if (do_bias) { ADD_COLS(y0) ADD_COLS(y1) }
+            STORE_SLAB(buf ^ 1)
+        }
+        __syncthreads();
     }
-    for (int ks = 0; ks < nk; ks += NSET) {
-        STEP(0, ks)
-        if (ks + 1 < nk) STEP(1, ks + 1)
-        if (ks + 2 < nk) STEP(2, ks + 2)
-        if (ks + 3 < nk) STEP(3, ks + 3)
-    }
-    WSTAMP(2)
-#undef READ_FRAGS
-#undef MOVE_SLAB
-#undef STEP
 #undef LOAD_SLAB
 #undef STORE_SLAB
 #undef ADD_COLS
@@ -242,7 +200,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(WgradArgs a) {
             P.db[n0 + tid] = fmaf(alpha, s, P.db[n0 + tid]);
         }
     }
-    WSTAMP(3)
 }
 
 

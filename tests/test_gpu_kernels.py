@@ -181,8 +181,8 @@ def test_attention_bwd_mfma(env, fdt, gdt, L, H, n):
     assert rel_l2(got, want) < (2e-3 if gdt == "fp16" else 1.2e-2)
 
 
-@pytest.mark.parametrize("xdt,gdt", [("fp16", "fp16"), ("fp16", "bf16")])
-@pytest.mark.parametrize("rows,Nw,Kw", [(77 * 3, 256, 128), (3200, 768, 3072), (1000, 3072, 768), (33, 128, 128)])
+@pytest.mark.parametrize("xdt,gdt", [("fp16", "fp16"), ("fp16", "bf16"), ("bf16", "fp16"), ("bf16", "bf16")])
+@pytest.mark.parametrize("rows,Nw,Kw", [(77 * 3, 256, 128), (3200, 768, 3072), (1000, 3072, 768), (33, 128, 128), (3219, 2304, 768)])
 def test_wgrad_group(env, xdt, gdt, rows, Nw, Kw):
     """dW += alpha dY^T X and db += alpha colsum(dY) (wgrad.hip) against float64 numpy on the rounded operands."""
     lib, torch, dev = env

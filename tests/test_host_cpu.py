@@ -141,3 +141,24 @@ def test_native_tokenizer_and_stage_match_python(golden_dir):
     want = pt.encode_batch(want_strings)
     assert np.array_equal(got, want)
     assert np.array_equal(lens, want.argmax(-1) + 1)
+
+
+def test_persistent_gemm_flush_asm_is_ordered(tmp_path):
+    """The persistent GEMM epilogue reads its LDS staging slices with inline-asm ds_read_b128 + counted lgkmcnt waits (a
+    compiler-visible LDS read beside in-flight LDS-DMAs would drain vmcnt(0)).  Nothing but program order ties those reads to
+    their destination registers, so the generated ISA of every persistent instantiation is checked: each destination is stored
+    only behind the wait that releases it and is never copied while in flight (tools/check_flush_asm.py)."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "gemm256h.s"
+    subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-Wno-unused-function", "-S",
+                    "--cuda-device-only", os.path.join(root, "leaf_amd", "csrc", "gemm256h.hip"), "-o", str(out)],
+                   check=True, capture_output=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_flush_asm.py"), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert r.stdout.count("flush blocks") == 8 and " flush blocks 0" not in r.stdout, r.stdout
