@@ -6,8 +6,9 @@
 // One WAVE owns one (sequence, head).  Everything stays on chip:
 //   * K fragments (<= 6 key tiles x 2 k-steps) are loaded straight from HBM into registers in MFMA
 //     fragment shape (16 B per lane); Q fragments likewise per 16-row query tile.
-//   * V is copied row-major into LDS once and consumed COLUMN-wise as the MFMA A operand through the
-//     gfx950 transposing read ds_read_b64_tr_b16 (no software transpose).
+//   * V goes row-major into LDS once, by LDS-DMA (round 2: global_load_lds into an unpadded, XOR-swizzled image; a third of
+//     the kernel's bytes no longer pass through the VGPR ingest path: -6.5 % per launch), and is consumed COLUMN-wise as
+//     the MFMA A operand through the gfx950 transposing read ds_read_b64_tr_b16 (no software transpose).
 //   * scores are computed TRANSPOSED (S^T = K Q^T, MFMA 16x16x32): a lane then holds 4 consecutive
 //     keys of ONE query per tile, so the row softmax is in-lane plus two wave shuffles (xor 16, 32).
 //   * O^T = V^T P^T runs on the k = 16 MFMA (16x16x16): its B operand wants, per lane, 4 consecutive keys of one
@@ -22,10 +23,18 @@ namespace {
 constexpr int HD = 64;          // head dim (all CLIP text towers)
 constexpr int MAXT_ALL = 6;     // 16-row tiles -> ctx <= 96; kernels are instantiated for 2..6 tiles (register count
                                 // follows the tile count: 140 VGPRs at 6 tiles, 3 waves per SIMD; fewer tiles, more resident waves)
-constexpr int V_LD = 72;        // LDS V row stride (elements): 144 B, 16-B aligned
-// per-wave LDS: the V image of `vrows` rows (a multiple of 16 covering the longest sequence of the launch, <= 96):
-// 13,824 B at 96 rows, 6,912 B at 48 - sizing it by the launch's longest sequence keeps more waves resident per CU
-__host__ __device__ constexpr int wave_lds_bytes(int vrows) { return vrows * V_LD * 2; }
+// per-wave LDS: the V image of `vrows` rows (a multiple of 16 covering the longest sequence of the launch, <= 96), rows of
+// 128 B (one head's 64 dims) WITHOUT padding: 12,288 B at 96 rows, 6,144 B at 48 - sizing it by the launch's longest sequence
+// keeps more waves resident per CU.  The rows arrive by LDS-DMA (global_load_lds: no trip through VGPRs, whose ingest rate
+// of ~12 B/clk per CU the K / Q fragment loads already use), eight rows per 1-KiB piece; the 16-byte chunk c of row r sits at
+// position c ^ vswz(r), so that the eight rows one half-wave cycle of ds_read_b64_tr_b16 touches hit eight different 32-byte
+// bank groups (even rows: groups 0-3, odd rows: 4-7, selected by (r >> 1) & 3).
+constexpr int V_ROW = 128;      // bytes per V row in LDS
+__host__ __device__ constexpr int wave_lds_bytes(int vrows) { return vrows * V_ROW; }
+__device__ __forceinline__ int vswz(int row) { return 2 * ((row >> 1) & 3); }
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
 
 
 template <bool USE_TR>
@@ -36,14 +45,17 @@ __device__ __forceinline__ s16x4 load_vt_frag(const char* vlds, int key0, int di
         // ds_read_b64_tr_b16: per 16-lane group a 4x16 block; lane 4q+p supplies row q, cols 4p..4p+3,
         // lane i receives column i of the 4 rows.
         const int q = i >> 2, p = i & 3;
+        const int row = key0 + 4 * g + q;
         typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
         return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (lds_s16x4*)(vlds + (key0 + 4 * g + q) * (V_LD * 2) + (dim0 + 4 * p) * 2));
+            (lds_s16x4*)(vlds + row * V_ROW + ((((dim0 >> 3) + (p >> 1)) ^ vswz(row)) << 4) + (p & 1) * 8));
     } else {
         s16x4 r;
-        const short* base = (const short*)vlds + (key0 + 4 * g) * V_LD + dim0 + i;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) r[j] = base[j * V_LD];
+        for (int j = 0; j < 4; ++j) {
+            const int row = key0 + 4 * g + j, col = dim0 + i;
+            r[j] = *(const short*)(vlds + row * V_ROW + (((col >> 3) ^ vswz(row)) << 4) + (col & 7) * 2);
+        }
         return r;
     }
 }
@@ -75,15 +87,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const u16* __restrict__ q
     const int qt0 = eot >= 0 ? eot >> 4 : pfx >> 4;
     const int qt1 = eot >= 0 ? eot >> 4 : nt - 1;
 
-    // ---- V rows -> LDS (row-major), rows ctx..vrows-1 zero
-    // rows beyond the sequence's own last 16-row tile are never read (key tiles kt <= qt < nt)
-    for (int idx = lane; idx < nt * 16 * 8; idx += 64) {
-        const int key = idx >> 3, ch = idx & 7;
-        uint4 v = uint4{0u, 0u, 0u, 0u};
-        if (key < ctx) v = *(const uint4*)(rowptr(key) + 2 * d + ch * 8);
-        *(uint4*)(vlds + key * (V_LD * 2) + ch * 16) = v;
-    }
-    // ---- K fragments -> registers
+    // ---- K fragments -> registers (straight from global memory; routing them through the LDS image by DMA as well measured
+    // the same: 79.0 against 79.4 us per launch)
     typename TT::vec8 kf[MAXT][2];
 #pragma unroll
     for (int kt = 0; kt < MAXT; ++kt) {
@@ -94,7 +99,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const u16* __restrict__ q
             kf[kt][1] = __builtin_bit_cast(typename TT::vec8, *(const uint4*)(kp + 32));
         }
     }
-
+    // ---- V rows -> LDS by LDS-DMA: piece pc = rows 8 pc .. 8 pc + 7, lane -> (row 8 pc + lane / 8, position lane % 8) fetches the
+    // source chunk (lane % 8) ^ vswz(row).  Rows ctx .. nt*16-1 of the last tile are zeroed FIRST (plain stores, no DMA in flight
+    // yet; P is zero there, but 0 x stale NaN would not be); lanes of rows >= ctx are masked off in the DMA.  The wait for the DMA
+    // (explicit vmcnt(0)) sits in front of the first transposing read of V, i.e. after Q K^T and the softmax of a query tile.
+    // Rows beyond the sequence's own last 16-row tile are never read (key tiles kt <= qt < nt).
+    {
+        const int vr = lane >> 3, vc = lane & 7;
+        for (int key = ctx + vr; key < nt * 16; key += 8) *(uint4*)(vlds + key * V_ROW + vc * 16) = uint4{0u, 0u, 0u, 0u};
+        for (int pc = 0; pc < 2 * nt; ++pc) {
+            const int key = 8 * pc + vr;
+            if (key < ctx)
+                __builtin_amdgcn_global_load_lds((glb_void_t*)(rowptr(key) + 2 * d + ((vc ^ vswz(key)) << 3)),
+                                                 (lds_void_t*)(vlds + pc * 8 * V_ROW), 16, 0, 0);
+        }
+    }
 #pragma unroll
     for (int qt = 0; qt < MAXT; ++qt) {
         if (qt < nt && qt >= qt0 && qt <= qt1) {
@@ -141,6 +160,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const u16* __restrict__ q
             f32x4 o[4];
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // the V image has landed: explicit, hipcc does NOT order LDS reads behind the DMA's LDS writes by itself (no vmcnt
+            // wait in the ISA when K went the same way)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int kt = 0; kt < MAXT; ++kt) {
                 if (kt <= qt) {
