@@ -215,3 +215,34 @@ def test_non_finite_gradients_skip_the_step(torch_mod):
     assert not torch_mod.equal(m.flat, p0) and m.skipped_steps() == 2 and bool(torch_mod.isfinite(m.flat).all())
     # guard off: the plain kernel (no extra pass over the gradients)
     assert m.adamw_step(lr=1e-3, guard=False) is None
+
+
+def test_deep_tower_layernorm_gradients_vs_oracle(torch_mod):
+    """A tower with more LayerNorms than one ln_param_reduce launch takes (34 blocks = 68 > 64): every LayerNorm / bias
+    gradient through the per-workgroup partial sums + batched reduction (train.hip) against the oracle's fp32 backward."""
+    from leaf_amd.model import LeafCLIPText, TextConfig
+    cfg = TextConfig(128, 2, 34, 64, quick_gelu=True)
+    ocfg = O.TextCfg(128, 2, 34, 64, quick_gelu=True)
+    w = O.init_weights(ocfg, seed=21)
+    m = LeafCLIPText(cfg, trainable=True)
+    m.load_state_dict({k: torch_mod.from_numpy(v) for k, v in w.items()}, strict=False)
+    toks = O.synthetic_tokens(6, seed=5)
+    feat_ref = O.encode_text(w, ocfg, toks)
+    rng = np.random.default_rng(3)
+    anchor = (feat_ref + rng.standard_normal(feat_ref.shape).astype(np.float32) * np.linalg.norm(feat_ref, axis=-1, keepdims=True) /
+              np.sqrt(feat_ref.shape[-1])).astype(np.float32)
+    loss_ref, _, g = O.encode_text_backward(w, ocfg, toks, anchor)
+    feat = m.forward_train(toks)
+    m.zero_grad()
+    loss = m.backward(feat, torch_mod.from_numpy(anchor).cuda())
+    torch_mod.cuda.synchronize()
+    assert abs(float(loss) - float(loss_ref)) < 3e-3 * abs(float(loss_ref))
+    worst = 0.0
+    for l in (0, 1, 16, 31, 32, 33):
+        for name in ("ln_1.weight", "ln_1.bias", "ln_2.weight", "ln_2.bias", "attn.out_proj.bias", "mlp.c_fc.weight"):
+            k = f"transformer.resblocks.{l}.{name}"
+            off, shape = m.layout[k]
+            got = m.grads[off: off + int(np.prod(shape))].view(shape).cpu().numpy()
+            worst = max(worst, rel_l2(got, g[k]))
+    print("deep tower: max grad rel-L2", worst)
+    assert worst < 8e-3        # measured 2.6e-3 (width 128: short reductions; ViT-H, 24 blocks of width 1024: 7.8e-3)
