@@ -102,6 +102,17 @@ int leaf_score_candidates_prefix(leaf_text_t h, const float* params, const void*
                                  const float* anchor, int B, int rho, int objective, int32_t* best_idx, float* best_feat, float* loss, void* ws,
                                  size_t ws_bytes, leaf_stream_t s);
 
+/* leaf_text_forward_kv and the FIRST stage's leaf_score_candidates_prefix in one pass (the clean-caption pass is a chain of ~80
+ * small launches; here its 3,200 rows ride in the candidates' launches): tokens [(B + B*rho), ctx] with the B captions FIRST,
+ * seq_lens (host) = rows to compute per sequence (captions: their length; candidates: suffix length), cu_rows = exclusive
+ * prefix sum (device, [B + B*rho + 1]), prefix (device; 0 for the captions).  `kv` receives the captions' per-layer q|k|v rows
+ * exactly as leaf_text_forward_kv writes them (later stages use leaf_score_candidates_prefix with it).  Bit-identical
+ * results.  Returns 2 when the rows do not fit one chunk (use the two separate calls then). */
+int leaf_score_candidates_prefix_fused(leaf_text_t h, const float* params, const void* w16_fwd, const int32_t* tokens,
+                                       const int32_t* seq_lens, const int32_t* cu_rows, const int32_t* prefix, int max_len,
+                                       const float* anchor, int B, int rho, int objective, int32_t* best_idx, float* best_feat,
+                                       float* loss, void* kv, size_t kv_bytes, void* ws, size_t ws_bytes, leaf_stream_t s);
+
 /* training forward (utils_AT.py:317-319) keeping activations in `stash` for the backward pass */
 int leaf_text_forward_train(leaf_text_t h, const float* params, const void* w16_fwd, const int32_t* tokens,
                             const int32_t* seq_lens, const int32_t* cu_rows, int n_seq, float* out, void* stash,

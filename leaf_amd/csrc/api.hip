@@ -297,6 +297,10 @@ struct KvPlan {
     uint16_t* kv_write = nullptr;
     const uint16_t* kv_read = nullptr;
     size_t kv_stride = 0;
+    // fused pass (leaf_score_candidates_prefix_fused): the clean captions are the FIRST kv_self_rows rows of this chunk; the
+    // candidates' attention reads their K/V from the chunk's own qkv buffer, and every layer's rows are copied to kv_copy
+    uint16_t* kv_copy = nullptr;
+    size_t kv_self_rows = 0;
 };
 
 int forward_chunk(const leaf_text* h, const float* P, const uint16_t* W, const int32_t* tokens, int cs, int rows,
@@ -349,6 +353,10 @@ int forward_chunk(const leaf_text* h, const float* P, const uint16_t* W, const i
         if (kv.kv_write) b.qkv = kv.kv_write + (size_t)l * kv.kv_stride;
         if (qkv_gemm(l, rows, ln, b.a)) return 1;
         const void* kvl = kv.kv_read ? kv.kv_read + (size_t)l * kv.kv_stride : nullptr;
+        if (kv.kv_self_rows) {
+            kvl = b.qkv;
+            LEAF_TRY(hipMemcpyAsync(kv.kv_copy + (size_t)l * kv.kv_stride, b.qkv, kv.kv_self_rows * 3 * d * 2, hipMemcpyDeviceToDevice, s));
+        }
         if (last && !out) break;          // K/V-only pass (clean captions for the cache): nothing consumes the rest
         if (last && h->last_trim && !kv.kv_write) {
             // Last block: only the pooled row (first maximum token id = EOT) of each sequence reaches the output, and every later op is
@@ -410,6 +418,9 @@ struct PrefixPlan {   // prefix reuse: see RowMap in common.h
     size_t kv_stride = 0;
     int group = 1;
     int max_len = 0;   // upper bound of prefix + suffix length over the candidates (0 = context_length)
+    int group_off = 0;          // fused pass: the first group_off sequences are the clean captions
+    uint16_t* kv_copy = nullptr;
+    size_t kv_self_rows = 0;
 };
 
 // rows below which a pass is not split across the two streams (the halves would not fill the chip anyway)
@@ -441,8 +452,9 @@ int forward_all(leaf_text* h, const float* P, const void* W, const int32_t* toke
         if (pp.max_len > 0 && pp.max_len < max_len) { leaf_set_error("max_len %d below a suffix length %d", pp.max_len, max_len); return 1; }
         max_len = pp.max_len > 0 && pp.max_len <= ctx ? pp.max_len : ctx;
     }
-    const int nsets = (h->streams >= 2 && total >= SPLIT_MIN_ROWS && n_seq >= 2) ? 2 : 1;
+    const int nsets = (h->streams >= 2 && total >= SPLIT_MIN_ROWS && n_seq >= 2 && !pp.kv_self_rows) ? 2 : 1;
     size_t nchunks = (total + budget - 1) / budget;
+    if (pp.kv_self_rows && nchunks > 1) { leaf_set_error("fused pass: the captions and their candidates must fit one chunk (%zu rows > %zu)", total, budget); return 2; }
     if (nsets == 2) nchunks = (nchunks + 1) / 2 * 2;                 // an even number of near-equal chunks
     const size_t target = (total + nchunks - 1) / nchunks;           // <= budget
     FwdBuf bufs[2];
@@ -466,10 +478,12 @@ int forward_all(leaf_text* h, const float* P, const void* W, const int32_t* toke
             rows += L;
             ++s1;
         }
-        RowMap map{cu_dev, s0, (int)row0, ctx, pp.prefix_dev, pp.base_cu_dev, pp.group};
+        RowMap map{cu_dev, s0, (int)row0, ctx, pp.prefix_dev, pp.base_cu_dev, pp.group, pp.group_off};
         KvPlan kv;
         kv.kv_read = pp.kv;
         kv.kv_stride = pp.kv_stride;
+        kv.kv_copy = pp.kv_copy;
+        kv.kv_self_rows = pp.kv_self_rows;
         if (s1 == s0) { leaf_set_error("a sequence does not fit the row budget"); return 1; }
         const int set = nsets == 2 ? (ci & 1) : 0;
         if (forward_chunk(h, P, (const uint16_t*)W, tokens, s1 - s0, (int)rows, map, out + (size_t)s0 * h->cfg.embed_dim,
@@ -581,6 +595,44 @@ extern "C" int leaf_score_candidates_prefix(leaf_text_t h, const float* params, 
     pp.group = rho;
     if (forward_all(h, params, w16_fwd, tokens, suffix_lens, cu_suffix, n_seq, feat, normalize, c, (hipStream_t)s, pp)) return 1;
     LEAF_TRY(leaf_launch_score(feat, anchor, B, rho, h->cfg.embed_dim, objective, best_idx, best_feat, loss, (hipStream_t)s));
+    return 0;
+}
+
+// The clean-caption K/V pass and the FIRST stage's scoring in one pass: sequences 0 .. B-1 are the captions (full rows, prefix 0),
+// B .. B + B rho - 1 their candidates; seq_lens (host) / cu_rows / prefix (device) cover all of them.  Returns 2 (and an error
+// text) when the rows do not fit one chunk: the caller then runs leaf_text_forward_kv + leaf_score_candidates_prefix.
+extern "C" int leaf_score_candidates_prefix_fused(leaf_text_t h, const float* params, const void* w16_fwd, const int32_t* tokens,
+                                                  const int32_t* seq_lens, const int32_t* cu_rows, const int32_t* prefix,
+                                                  int max_len, const float* anchor, int B, int rho, int objective,
+                                                  int32_t* best_idx, float* best_feat, float* loss, void* kv, size_t kv_bytes,
+                                                  void* ws, size_t ws_bytes, leaf_stream_t s) {
+    if (!h || !params || !w16_fwd || !tokens || !seq_lens || !cu_rows || !prefix || !anchor || !best_idx || !kv || !ws || B < 1 || rho < 1) {
+        leaf_set_error("null/invalid argument");
+        return 1;
+    }
+    if (objective < 0 || objective > 3) { leaf_set_error("unknown objective %d", objective); return 1; }
+    size_t base_rows = 0;
+    for (int i = 0; i < B; ++i) base_rows += seq_lens[i];
+    const size_t stride = base_rows * 3 * h->cfg.width;
+    if (stride * 2 * h->cfg.layers > kv_bytes) { leaf_set_error("kv cache too small"); return 1; }
+    Carver c(ws, ws_bytes);
+    const int n_seq = B + B * rho;
+    float* feat = (float*)c.take((size_t)n_seq * h->cfg.embed_dim * 4);
+    const int normalize = (objective == LEAF_OBJ_SIM || objective == LEAF_OBJ_DISSIM);
+    PrefixPlan pp;
+    pp.prefix_dev = prefix;
+    pp.base_cu_dev = cu_rows;          // the captions are the first sequences: their row offsets are the first B entries
+    pp.max_len = max_len;
+    pp.kv = nullptr;
+    pp.kv_stride = stride;
+    pp.group = rho;
+    pp.group_off = B;
+    pp.kv_copy = (uint16_t*)kv;
+    pp.kv_self_rows = base_rows;
+    const int rc = forward_all(h, params, w16_fwd, tokens, seq_lens, cu_rows, n_seq, feat, normalize, c, (hipStream_t)s, pp);
+    if (rc) return rc;
+    LEAF_TRY(leaf_launch_score(feat + (size_t)B * h->cfg.embed_dim, anchor, B, rho, h->cfg.embed_dim, objective, best_idx, best_feat, loss,
+                               (hipStream_t)s));
     return 0;
 }
 

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const u16* __restrict__ q
     int ctx = pfx + seq_len(map, sg);               // total length of this sequence
     ctx = ctx < vrows ? ctx : vrows;                // never past the LDS image (the host sizes vrows from the true maximum)
     const u16* own = qkv + (size_t)row_s * ld + h * HD;
-    const u16* cached = pfx ? kv_base + (size_t)map.base_cu[sg / map.group] * ld + h * HD : own;
+    const u16* cached = pfx ? kv_base + (size_t)map.base_cu[(sg - map.group_off) / map.group] * ld + h * HD : own;
     auto rowptr = [&](int pos) { return pos < pfx ? cached + (size_t)pos * ld : own + (size_t)(pos - pfx) * ld; };
     const int r16 = lane & 15, g = lane >> 4;
     const int nt = (ctx + 15) >> 4;

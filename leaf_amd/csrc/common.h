@@ -195,6 +195,8 @@ struct RowMap {
     const int32_t* prefix;   // device, per sequence, or null
     const int32_t* base_cu;  // device, packed row offsets of the clean captions inside the kv cache
     int group;               // candidates per clean caption
+    int group_off;           // sequences [0, group_off) of the pass are the clean captions themselves (fused K/V + scoring pass):
+                             // candidate s belongs to caption (s - group_off) / group
 };
 __device__ __forceinline__ int seq_row(const RowMap& m, int s) { return (m.cu ? m.cu[s] : s * m.ctx) - m.row0; }
 __device__ __forceinline__ int seq_len(const RowMap& m, int s) { return m.cu ? m.cu[s + 1] - m.cu[s] : m.ctx; }

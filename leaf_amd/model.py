@@ -363,6 +363,52 @@ class LeafCLIPText:
             _ptr(feat), _ptr(loss), _ptr(ws), ws.numel(), self._stream()), "leaf_score_candidates_prefix")
         return (idx, feat, loss) if want_loss else (idx, feat)
 
+    def score_candidates_fused(self, base_tokens, base_lens, tokens, anchor: torch.Tensor, rho: int, seq_lens, prefix_lens,
+                               objective: str = "l2", want_features: bool = False, want_loss: bool = False):
+        """``encode_text_kv(base_tokens)`` and the first stage's ``score_candidates(..., prefix_lens, kv)`` in ONE pass
+        (leaf_score_candidates_prefix_fused: the B clean captions ride in the launches of their B*rho candidates).
+        Returns (best_idx, best_feat or None, kv cache for the later stages[, loss [B, rho] when want_loss]), or None when
+        the rows do not fit one chunk (the caller then uses the two separate calls).  Bit-identical to the separate calls."""
+        if not self._packed:
+            self.pack()
+        B = anchor.shape[0]
+        blens = np.ascontiguousarray(np.asarray(base_lens).reshape(-1), dtype=np.int32)
+        full = np.asarray(seq_lens, dtype=np.int64).reshape(-1)
+        pfx = np.minimum(np.asarray(prefix_lens, dtype=np.int64).reshape(-1), full - 1)      # keep at least the EOT row
+        pfx = np.minimum(pfx, np.repeat(blens.astype(np.int64), rho))                        # rows the captions really have
+        lens = np.ascontiguousarray(np.concatenate([blens, full - pfx]), dtype=np.int32)     # rows to compute per sequence
+        cu = np.zeros(lens.size + 1, dtype=np.int32)
+        np.cumsum(lens, out=cu[1:])
+        host = np.concatenate([cu, np.zeros(B, dtype=np.int32), pfx.astype(np.int32)])
+        dev = torch.from_numpy(host).pin_memory().to(self.device, non_blocking=True)
+        cu_dev, pfx_dev = dev[:lens.size + 1], dev[lens.size + 1:]
+        bt = self._tokens(base_tokens)
+        ct = self._tokens(tokens.reshape(-1, tokens.shape[-1]))
+        if bt.shape[0] != B or ct.shape[0] != B * rho:
+            raise ValueError("captions / candidate rows do not match B, B*rho")
+        t = torch.cat([bt, ct], 0)
+        base_rows = int(cu[B])
+        need = base_rows * 3 * self.cfg.width * 2 * self.cfg.layers
+        if getattr(self, "_kv", None) is None or self._kv.numel() < need:
+            self._kv = None
+            with torch.cuda.device(self.device):
+                self._kv = torch.empty(max(need, 1), dtype=torch.uint8, device=self.device)
+        anchor = anchor.to(device=self.device, dtype=torch.float32).contiguous()
+        idx = torch.empty(B, dtype=torch.int32, device=self.device)
+        feat = torch.empty(B, self.cfg.embed_dim, dtype=torch.float32, device=self.device) if want_features else None
+        loss = torch.empty(B, rho, dtype=torch.float32, device=self.device) if want_loss else None
+        ws = self._workspace(1, B + B * rho)
+        max_len = int(max(int(full.max()), int(blens.max())))
+        rc = self._lib.leaf_score_candidates_prefix_fused(
+            self._h, _ptr(self.flat), _ptr(self.w16), _ptr(t), C.c_void_p(lens.ctypes.data), _ptr(cu_dev), _ptr(pfx_dev), max_len,
+            _ptr(anchor), B, rho, _OBJ[objective], _ptr(idx), _ptr(feat), _ptr(loss), _ptr(self._kv), self._kv.numel(),
+            _ptr(ws), ws.numel(), self._stream())
+        if rc == 2:
+            return None
+        _lib.check(rc, "leaf_score_candidates_prefix_fused")
+        cache = {"kv": self._kv, "base_cu": cu_dev[:B + 1], "base_rows": base_rows, "lens": blens, "n": B}
+        return (idx, feat, cache, loss) if want_loss else (idx, feat, cache)
+
     # ------------------------------------------------------------------ training
     def enable_training(self):
         if self.grads is None:

@@ -107,14 +107,22 @@ def search_synthetic(model, anchor: torch.Tensor, base: torch.Tensor, cfg: StepC
     cur = base
     B = base.shape[0]
     ar = torch.arange(B, device=base.device)
+    fuse = reuse and os.environ.get("LEAF_FUSE_KV", "1") != "0"
     for _ in range(cfg.k_adv):
-        kv = model.encode_text_kv(cur, seq_lens=base_lens) if reuse else None
         cand, pos = gen.stage1(cur)
         if anchor_ready is not None:
             torch.cuda.current_stream().wait_event(anchor_ready)
             anchor_ready = None
-        best1, _ = model.score_candidates(cand.view(B * cfg.rho, -1), anchor, cfg.rho, "l2", want_features=False,
-                                          seq_lens=cand_lens, prefix_lens=pos.reshape(-1) if reuse else None, kv=kv)
+        # stage 1 with the clean captions' K/V pass fused in (their rows ride in the candidates' launches); falls back to the
+        # separate pass when the rows do not fit one chunk
+        fused = model.score_candidates_fused(cur, base_lens, cand.view(B * cfg.rho, -1), anchor, cfg.rho, cand_lens,
+                                             pos.reshape(-1)) if fuse else None
+        if fused is not None:
+            best1, _, kv = fused
+        else:
+            kv = model.encode_text_kv(cur, seq_lens=base_lens) if reuse else None
+            best1, _ = model.score_candidates(cand.view(B * cfg.rho, -1), anchor, cfg.rho, "l2", want_features=False,
+                                              seq_lens=cand_lens, prefix_lens=pos.reshape(-1) if reuse else None, kv=kv)
         cand = gen.stage2_device(cur, best1)                             # queued behind stage 1, before the host waits
         pos2 = gen.stage2_positions(pos, best1.cpu().numpy())           # the search's device->host sync (B indices)
         best2, _ = model.score_candidates(cand.view(B * cfg.rho, -1), anchor, cfg.rho, "l2", want_features=False,

@@ -127,7 +127,8 @@ def test_vitl_param_grads_and_adamw_vs_oracle(torch_mod):
 
 
 def test_vitl_k5_search_every_stage_rescored_by_oracle(torch_mod):
-    """configs[2] (k=5): search_synthetic with prefix reuse on ViT-L; all 10 scoring calls are intercepted, their
+    """configs[2] (k=5): search_synthetic with prefix reuse on ViT-L; all 10 scoring calls (5 fused first stages, 5 second
+    stages) are intercepted, their
     candidates re-scored by the fp32 oracle, and each arg-max must agree whenever the oracle's top-2 gap exceeds the
     measured loss error; stage inputs must chain (stage t+1 candidates derive from stage t's winner)."""
     from leaf_amd.model import LeafCLIPText, create_model, get_config
@@ -153,9 +154,20 @@ def test_vitl_k5_search_every_stage_rescored_by_oracle(torch_mod):
         calls.append((tokens.detach().cpu().numpy().copy(), idx.cpu().numpy().copy(), loss.cpu().numpy().copy(),
                       feat.cpu().numpy().copy()))
         return idx, feat
+    real_fused = m.score_candidates_fused
+
+    def spy_fused(base_tokens, base_lens, tokens, anchor_, rho_, seq_lens, prefix_lens, objective="l2", **kw):
+        # the first stage of every edit: the clean captions' K/V pass rides in the same launches (leaf_score_candidates_prefix_fused)
+        idx, feat, kv, loss = real_fused(base_tokens, base_lens, tokens, anchor_, rho_, seq_lens, prefix_lens, objective,
+                                         want_features=True, want_loss=True)
+        calls.append((tokens.detach().cpu().numpy().copy(), idx.cpu().numpy().copy(), loss.cpu().numpy().copy(),
+                      feat.cpu().numpy().copy()))
+        return idx, feat, kv
     m.score_candidates = spy
+    m.score_candidates_fused = spy_fused
     adv = search_synthetic(m, anchor, base, StepConfig(rho=rho, k_adv=k), seed=3, base_lens=lens, prefix_reuse=True)
     m.score_candidates = real
+    m.score_candidates_fused = real_fused
     assert len(calls) == 2 * k
     L = int(lens.max())
     cur = base_np.copy()

@@ -65,3 +65,38 @@ def test_overlapped_gradient_reduction_on_rccl_single_rank(tmp_path):
     flat = run({"LEAF_BENCH_FORCE_DIST": "1", "LEAF_DP_OVERLAP": "0"}, True)
     assert plain["n_ranks_seen"] == 1 and overlap["n_ranks_seen"] == 1
     assert plain["loss"] == overlap["loss"] == flat["loss"], (plain["loss"], overlap["loss"], flat["loss"])
+
+
+@pytest.mark.parametrize("name,B,rho", [("tiny-test-quickgelu", 8, 10), ("ViT-L-14-quickgelu", 6, 7)])
+def test_fused_caption_pass_is_bit_identical(name, B, rho):
+    """The clean captions' K/V pass fused into the first stage's scoring pass (leaf_score_candidates_prefix_fused) against the
+    two separate calls: same arg-max, same winning features, the same bytes in the K/V cache (GEMM rows do not depend on the
+    launch they are computed in), and the later stage scores identically from either cache."""
+    import torch
+    from leaf_amd.model import create_model
+    from leaf_amd.step import SyntheticCandidates
+    m = create_model(name, seed=5)
+    base = torch.from_numpy(O.synthetic_tokens(B, seed=9).astype(np.int32)).cuda()
+    lens = (base.argmax(-1) + 1).cpu().numpy().astype(np.int32)
+    anchor = m.encode_text(base, seq_lens=lens) + 0.05
+    gen = SyntheticCandidates(base, lens, rho, m.cfg.vocab_size, 3)
+    cand, pos = gen.stage1(base)
+    cand_lens = np.repeat(lens, rho)
+    kv_a = m.encode_text_kv(base, seq_lens=lens)
+    need = kv_a["base_rows"] * 3 * m.cfg.width * 2 * m.cfg.layers
+    kv_bytes_a = kv_a["kv"][:need].clone()
+    i_a, f_a = m.score_candidates(cand.view(B * rho, -1), anchor, rho, "l2", seq_lens=cand_lens, prefix_lens=pos.reshape(-1), kv=kv_a)
+    i_a, f_a = i_a.clone(), f_a.clone()
+    kv_a["kv"].zero_()
+    fused = m.score_candidates_fused(base, lens, cand.view(B * rho, -1), anchor, rho, cand_lens, pos.reshape(-1), want_features=True)
+    assert fused is not None
+    i_b, f_b, kv_b = fused
+    assert torch.equal(i_a, i_b) and torch.equal(f_a, f_b)
+    assert torch.equal(kv_bytes_a, kv_b["kv"][:need])
+    assert kv_b["base_rows"] == kv_a["base_rows"] and torch.equal(kv_a["base_cu"].cpu(), kv_b["base_cu"].cpu())
+    # a later stage from the fused pass's cache
+    cand2 = gen.stage2_device(base, i_b)
+    pos2 = gen.stage2_positions(pos, i_b.cpu().numpy())
+    i2_b, f2_b = m.score_candidates(cand2.view(B * rho, -1), anchor, rho, "l2", seq_lens=cand_lens, prefix_lens=pos2.reshape(-1), kv=kv_b)
+    i2_d, f2_d = m.score_candidates(cand2.view(B * rho, -1), anchor, rho, "l2", seq_lens=cand_lens)   # no prefix reuse at all
+    assert torch.equal(i2_b, i2_d) and torch.equal(f2_b, f2_d)
