@@ -158,6 +158,13 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count()
+    # --backend gloo without --dry: REHEARSAL of the multi-rank step with real GPU work and gloo as the transport (RCCL wants one
+    # device per rank); ranks then share the devices there are (local rank % device count).  Never a metric: the line says so.
+    rehearsal = args.backend == "gloo"
+    if local >= ndev and not rehearsal:
+        raise SystemExit(f"rank {rank}: local rank {local} but only {ndev} GPU(s) visible (use --backend gloo to rehearse on fewer)")
+    local = local % max(ndev, 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or os.environ.get("LEAF_BENCH_FORCE_DIST") == "1"   # the latter rehearses the RCCL path on 1 GPU
@@ -168,7 +175,10 @@ def main():
             del os.environ["NCCL_DEBUG"]
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     n_ranks_seen = dist.get_world_size() if use_dist else 1
 
     cfg = get_config(args.model)
@@ -274,6 +284,8 @@ def main():
         out = {
             "metric": "adversarial text samples/sec", "value": value, "unit": "samples/s",
             "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps, "warmup": args.warmup,
+            **({"rehearsal": f"gloo transport, {world} rank(s) on {ndev} device(s): functional rehearsal of the multi-rank step, "
+                             "NOT the metric (RCCL, one device per rank, is)"} if rehearsal else {}),
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype + " MFMA operands, f32 accumulate", "data": "synthetic",
             "config": {"workload": (f"CLIP {args.model} text encoder, LEAF step k={args.k_adv} rho={args.rho}, "

@@ -114,3 +114,22 @@ def test_two_ranks_overlapped_equals_flat_and_the_concatenated_batch(tmp_path, n
         assert torch.equal(a0["grads"][off:off + numel], b0["grads"][off:off + numel])
     print("2 ranks vs concatenated batch: worst per-tensor grad rel-L2", worst)
     assert worst < 1e-5
+
+
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    """`bench.py --gpus 2 --backend gloo`: the launcher, the barrier-bracketed timing with the max over ranks, n_ranks_seen and
+    the full step (search with per-rank seeds, bucketed reduction beside the backward, AdamW) with two ranks sharing this box's
+    GPU.  A functional rehearsal of the driver's N > 1 command; the line says it is not the metric."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LEAF_BENCH_FORCE_DIST", "LEAF_DP_OVERLAP")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--model", "tiny-test-quickgelu",
+                        "--batch", "16", "--rho", "8", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-dense-leg"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, p.stdout[-2000:]
+    d = json.loads(line[0])
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and "rehearsal" in d
+    assert d["value"] > 0 and np.isfinite(d["loss"])
+    assert abs(d["value"] - 2 * 16 * 4 / (d["ms_per_step"] * 4e-3)) < 1e-6 * d["value"]      # whole-job samples / max-over-ranks time
