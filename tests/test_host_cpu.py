@@ -162,3 +162,30 @@ def test_persistent_gemm_flush_asm_is_ordered(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_flush_asm.py"), str(out)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
     assert r.stdout.count("flush blocks") == 8 and " flush blocks 0" not in r.stdout, r.stdout
+
+
+def test_wgrad_dma_asm_owns_m0(tmp_path):
+    """wgrad_tn_dma_kernel issues its LDS-DMA as inline asm (s_mov_b32 m0 + global_load_lds_dwordx4 in ONE statement, M0 cannot
+    be declared as clobbered: 'reserved register').  Check in the generated ISA that every DMA is immediately preceded by its own
+    M0 write and that nothing else in those kernels reads or writes M0."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "wgrad.s"
+    subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-Wno-unused-function", "-S",
+                    "--cuda-device-only", os.path.join(root, "leaf_amd", "csrc", "wgrad.hip"), "-o", str(out)],
+                   check=True, capture_output=True, timeout=600)
+    lines = out.read_text().split("\n")
+    starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN\w*wgrad_tn_dma_kernel\w*:", l)]
+    assert len(starts) == 2
+    for s0 in starts:
+        end = next(i for i in range(s0, len(lines)) if lines[i].strip().startswith("s_endpgm"))
+        body = [l.strip() for l in lines[s0:end] if l.strip() and not l.strip().startswith((";", "."))]
+        dma = [i for i, l in enumerate(body) if l.startswith("global_load_lds")]
+        assert len(dma) >= 16
+        for i in dma:
+            assert body[i - 1].startswith("s_mov_b32 m0"), body[i - 1]
+        assert sum("m0" in l for l in body) == len(dma)
