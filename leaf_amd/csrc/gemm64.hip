@@ -56,20 +56,21 @@ __global__ __launch_bounds__(256, 2) void gemm_nt64_ring_kernel(GemmArgs p) {
     const unsigned bstep = 16u * (unsigned)p.ldb;   // 8 rows, bytes
     const int apiece = wid * (1024 * MI), bpiece = A_BYTES + wid * 4096;
 #define DMA16(src, dst) __builtin_amdgcn_global_load_lds((glb_void_t*)(src), (lds_void_t*)(dst), 16, 0, 0)
-    // all MI + 4 pieces of K stage `kt` into ring slot `slot`
-#define ISSUE_STAGE(slot, kt)                                                                                \
+    // the MI + 4 pieces of K stage `kt` into ring slot `slot`, in four groups (G = 0..3: two B pieces | A pieces 0-1 | the other two
+    // B pieces | A pieces 2-3 where the tile has them)
+#define ISSUE_GROUP(slot, kt, G)                                                                             \
     {                                                                                                        \
         char* st_ = smem + (slot) * STAGE;                                                                   \
         const size_t ko_ = (size_t)(kt) * (BK * 2);                                                          \
-        DMA16(A + ko_ + a0, st_ + apiece);                                                                   \
-        DMA16(A + ko_ + a1, st_ + apiece + 1024);                                                            \
-        if constexpr (MI > 2) DMA16(A + ko_ + a2, st_ + apiece + 2048);                                      \
-        if constexpr (MI > 3) DMA16(A + ko_ + a3, st_ + apiece + 3072);                                      \
-        DMA16(B + ko_ + b0, st_ + bpiece);                                                                   \
-        DMA16(B + ko_ + bstep + b0, st_ + bpiece + 1024);                                                    \
-        DMA16(B + ko_ + 2 * (size_t)bstep + b0, st_ + bpiece + 2048);                                        \
-        DMA16(B + ko_ + 3 * (size_t)bstep + b0, st_ + bpiece + 3072);                                        \
+        if ((G) == 0) { DMA16(B + ko_ + b0, st_ + bpiece); DMA16(B + ko_ + bstep + b0, st_ + bpiece + 1024); } \
+        if ((G) == 1) { DMA16(A + ko_ + a0, st_ + apiece); DMA16(A + ko_ + a1, st_ + apiece + 1024); }       \
+        if ((G) == 2) { DMA16(B + ko_ + 2 * (size_t)bstep + b0, st_ + bpiece + 2048); DMA16(B + ko_ + 3 * (size_t)bstep + b0, st_ + bpiece + 3072); } \
+        if ((G) == 3) {                                                                                      \
+            if constexpr (MI > 2) DMA16(A + ko_ + a2, st_ + apiece + 2048);                                  \
+            if constexpr (MI > 3) DMA16(A + ko_ + a3, st_ + apiece + 3072);                                  \
+        }                                                                                                    \
     }
+#define ISSUE_STAGE(slot, kt) { ISSUE_GROUP(slot, kt, 0) ISSUE_GROUP(slot, kt, 1) ISSUE_GROUP(slot, kt, 2) ISSUE_GROUP(slot, kt, 3) }
 
     f32x4 acc[MI][4];
 #pragma unroll
@@ -86,20 +87,37 @@ __global__ __launch_bounds__(256, 2) void gemm_nt64_ring_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) wo[ks][j] = A_BYTES + lds_off_h(wn * 64 + j * 16 + frow, ks * 4 + fkc);
     }
-#define COMPUTE(slot)                                                                             \
+    // One 64-deep stage = two 32-deep k-steps.  The fragments of k-step 1 are read while the MFMAs of k-step 0 run, and the
+    // DMA pieces of the stage requested this turn (IS0..IS3: MI + 4 pieces in four groups) are issued between the MFMA rows:
+    // with one workgroup per CU (MI = 3 | 4) there is one wave per SIMD and every LDS read / DMA issue in front of the MFMAs is
+    // exposed (tools/wgrad_stamps.py measured the same structure in the weight-gradient kernel: nothing overlaps inside one
+    // wave unless it is interleaved by hand).  Same k order, same MFMA per accumulator as before: bit-identical results.
+#define RD_STEP(xa_, wb_, ks_)                                                                    \
+    {                                                                                             \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                             \
+            wb_[j] = *(const typename TT::vec8*)(st_ + wo[ks_][j]);                               \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i)                                            \
+            xa_[i] = *(const typename TT::vec8*)(st_ + xo[ks_][i]);                               \
+    }
+#define MROW64(xa_, wb_, i_) _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i_][j] = TT::mfma(wb_[j], xa_[i_], acc[i_][j]);
+#define SB64 __builtin_amdgcn_sched_barrier(0);
+#define COMPUTE(slot, IS0, IS1, IS2, IS3)                                                         \
     {                                                                                             \
         const char* st_ = smem + (slot) * STAGE;                                                  \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                        \
-            typename TT::vec8 xa[MI], wb[4];                                                      \
-            _Pragma("unroll") for (int i = 0; i < MI; ++i)                                        \
-                xa[i] = *(const typename TT::vec8*)(st_ + xo[ks][i]);                             \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                         \
-                wb[j] = *(const typename TT::vec8*)(st_ + wo[ks][j]);                             \
-            _Pragma("unroll") for (int i = 0; i < MI; ++i)                                        \
-                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                     \
-                    acc[i][j] = TT::mfma(wb[j], xa[i], acc[i][j]);                                \
-        }                                                                                         \
+        typename TT::vec8 xa0[MI], wb0[4], xa1[MI], wb1[4];                                       \
+        RD_STEP(xa0, wb0, 0)                                                                      \
+        SB64 IS0 SB64                                                                             \
+        RD_STEP(xa1, wb1, 1)                                                                      \
+        SB64 MROW64(xa0, wb0, 0) SB64 IS1                                                         \
+        SB64 MROW64(xa0, wb0, 1) SB64 IS2                                                         \
+        if constexpr (MI > 2) { SB64 MROW64(xa0, wb0, 2) }                                        \
+        if constexpr (MI > 3) { SB64 MROW64(xa0, wb0, 3) }                                        \
+        SB64 IS3 SB64                                                                             \
+        MROW64(xa1, wb1, 0) MROW64(xa1, wb1, 1)                                                   \
+        if constexpr (MI > 2) { MROW64(xa1, wb1, 2) }                                             \
+        if constexpr (MI > 3) { MROW64(xa1, wb1, 3) }                                             \
     }
+#define NOP64
     // publish: own DMAs of the stage retired (counted: MI + 4 per stage, `ahead` younger stages may stay in flight),
     // own LDS reads retired (their slot is recycled by the request issued right after the barrier), then the barrier
 #define SYNC_AHEAD(ahead)                                                                         \
@@ -114,9 +132,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt64_ring_kernel(GemmArgs p) {
     int slot = 0, nslot = NS - 1;   // slot of stage t, slot that stage t + NS - 1 goes to
     for (int t = 0; t < nt - (NS - 1); ++t) {
         SYNC_AHEAD(NS - 2)
-        ISSUE_STAGE(nslot, t + NS - 1)
-        __builtin_amdgcn_sched_barrier(0);
-        COMPUTE(slot)
+        COMPUTE(slot, ISSUE_GROUP(nslot, t + NS - 1, 0), ISSUE_GROUP(nslot, t + NS - 1, 1), ISSUE_GROUP(nslot, t + NS - 1, 2),
+                ISSUE_GROUP(nslot, t + NS - 1, 3))
         slot = slot == NS - 1 ? 0 : slot + 1;
         nslot = nslot == NS - 1 ? 0 : nslot + 1;
     }
@@ -124,14 +141,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nt64_ring_kernel(GemmArgs p) {
 #define TAIL(k)                                                                                   \
     if constexpr (NS - 2 - (k) >= 0) {                                                            \
         SYNC_AHEAD(NS - 2 - (k))                                                                  \
-        COMPUTE(slot)                                                                             \
+        COMPUTE(slot, NOP64, NOP64, NOP64, NOP64)                                                 \
         slot = slot == NS - 1 ? 0 : slot + 1;                                                     \
     }
     TAIL(0) TAIL(1) TAIL(2) TAIL(3) TAIL(4)
 #undef TAIL
 #undef DMA16
 #undef ISSUE_STAGE
+#undef ISSUE_GROUP
 #undef COMPUTE
+#undef RD_STEP
+#undef MROW64
+#undef SB64
+#undef NOP64
 #undef SYNC_AHEAD
 
     // ---- epilogue: lane holds C[m][n..n+3], m = .. + (lane & 15), n = .. + 4 * (lane >> 4)
