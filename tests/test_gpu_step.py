@@ -100,3 +100,21 @@ def test_fused_caption_pass_is_bit_identical(name, B, rho):
     i2_b, f2_b = m.score_candidates(cand2.view(B * rho, -1), anchor, rho, "l2", seq_lens=cand_lens, prefix_lens=pos2.reshape(-1), kv=kv_b)
     i2_d, f2_d = m.score_candidates(cand2.view(B * rho, -1), anchor, rho, "l2", seq_lens=cand_lens)   # no prefix reuse at all
     assert torch.equal(i2_b, i2_d) and torch.equal(f2_b, f2_d)
+
+
+def test_search_with_and_without_the_fused_caption_pass_agree(monkeypatch):
+    """search_synthetic, k = 2, ViT-L: the adversarial ids with the caption pass fused into every first stage equal those with
+    the separate leaf_text_forward_kv pass (LEAF_FUSE_KV=0) and those without any prefix reuse."""
+    import torch
+    from leaf_amd.model import create_model
+    from leaf_amd.step import StepConfig, search_synthetic
+    m = create_model("ViT-L-14-quickgelu", seed=2)
+    base = torch.from_numpy(O.synthetic_tokens(6, seed=13).astype(np.int32)).cuda()
+    lens = (base.argmax(-1) + 1).cpu().numpy().astype(np.int32)
+    anchor = m.encode_text(base, seq_lens=lens) + 0.03
+    sc = StepConfig(rho=9, k_adv=2)
+    fused = search_synthetic(m, anchor, base, sc, seed=4, base_lens=lens)
+    monkeypatch.setenv("LEAF_FUSE_KV", "0")
+    separate = search_synthetic(m, anchor, base, sc, seed=4, base_lens=lens)
+    plain = search_synthetic(m, anchor, base, sc, seed=4, base_lens=lens, prefix_reuse=False)
+    assert torch.equal(fused, separate) and torch.equal(fused, plain)
