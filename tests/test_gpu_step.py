@@ -118,3 +118,23 @@ def test_search_with_and_without_the_fused_caption_pass_agree(monkeypatch):
     separate = search_synthetic(m, anchor, base, sc, seed=4, base_lens=lens)
     plain = search_synthetic(m, anchor, base, sc, seed=4, base_lens=lens, prefix_reuse=False)
     assert torch.equal(fused, separate) and torch.equal(fused, plain)
+
+
+def test_fused_caption_pass_falls_back_when_the_rows_do_not_fit_one_chunk():
+    """With a row budget smaller than captions + candidates the fused entry point declines (returns None, error text set by the
+    C ABI) and search_synthetic runs the separate caption pass: same adversarial ids as without any prefix reuse."""
+    import torch
+    from leaf_amd.model import create_model
+    from leaf_amd.step import StepConfig, SyntheticCandidates, search_synthetic
+    m = create_model("tiny-test-quickgelu", seed=6)
+    base = torch.from_numpy(O.synthetic_tokens(8, seed=2).astype(np.int32)).cuda()
+    lens = (base.argmax(-1) + 1).cpu().numpy().astype(np.int32)
+    anchor = m.encode_text(base, seq_lens=lens) + 0.02
+    sc = StepConfig(rho=10, k_adv=1)
+    want = search_synthetic(m, anchor, base, sc, seed=9, base_lens=lens, prefix_reuse=False)
+    m.set_option("chunk", 8)            # 8 x 77 rows per pass: the 8 captions alone fit, captions + 80 candidates do not
+    gen = SyntheticCandidates(base, lens, 10, m.cfg.vocab_size, 9)
+    cand, pos = gen.stage1(base)
+    assert m.score_candidates_fused(base, lens, cand.view(80, -1), anchor, 10, np.repeat(lens, 10), pos.reshape(-1)) is None
+    got = search_synthetic(m, anchor, base, sc, seed=9, base_lens=lens)
+    assert torch.equal(got, want)
