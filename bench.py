@@ -18,7 +18,9 @@ Prints ONE JSON line on rank 0: the task contract's fields, plus
   dense         samples/s of the same step with every exact work-skipping switched off (a few steps, after the timed region);
   step_exec_frac    executed GEMM FLOP/s of the whole step / dense 16-bit MFMA peak  (the honest step-level fraction);
   dense_equiv_frac  samples/s x dense algorithmic FLOPs per sample / peak (SURVEY.md 8d's prescription; exceeds the
-                    executed fraction by the factor exact work skipping removes).
+                    executed fraction by the factor exact work skipping removes);
+  ms_per_step_first_tenth / _last_tenth   the step is data dependent (the rows the second stage computes follow the search's
+                    winners, which move as the model trains on the synthetic batch): both ends of the timed region.
 """
 import argparse
 import ctypes as C
@@ -77,6 +79,20 @@ def free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
+
+
+def step_trend(marks):
+    """ms per step over the first and the last tenth of the timed steps (events on the step's stream).  The exact work skipping
+    makes the step DATA dependent: as the model trains on the synthetic batch the search's winners move and with them the rows
+    the second stage has to compute (lr = 0 keeps the time flat), so a 20-step run and a 200-step run average differently."""
+    n = len(marks)
+    if n < 20:
+        return {}
+    k = max(n // 10, 2)
+    first = marks[0].elapsed_time(marks[k]) / k
+    last = marks[n - 1 - k].elapsed_time(marks[n - 1]) / k
+    return {"ms_per_step_first_tenth": first, "ms_per_step_last_tenth": last,
+            "step_time_note": "data dependent (exact work skipping follows the search's winners as the model trains); value = all timed steps"}
 
 
 def self_launch(args, argv):
@@ -211,12 +227,18 @@ def main():
 
     step_id = [0]
 
-    def run_steps(n, lens_arg, prefix):
+    step_marks = []     # one event per timed step (current stream, no synchronisation): the step time is DATA dependent
+
+    def run_steps(n, lens_arg, prefix, mark=False):
         loss = None
         for _ in range(n):
             loss = train_step_tokens(model, frozen, base, sc, seed=step_id[0], base_lens=lens_arg, prefix_reuse=prefix,
                                      base_ready=base_ready, micro_index=step_id[0] % args.accum_freq)
             step_id[0] += 1
+            if mark:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                step_marks.append(e)
         return loss
 
     run_steps(args.warmup, base_lens, not args.no_prefix_reuse)
@@ -225,7 +247,7 @@ def main():
     if rank == 0:
         lib.leaf_prof_begin()
     t0 = time.perf_counter()
-    loss = run_steps(args.steps, base_lens, not args.no_prefix_reuse)
+    loss = run_steps(args.steps, base_lens, not args.no_prefix_reuse, mark=True)
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -310,6 +332,7 @@ def main():
                 "shapes": shapes[:12],
             },
             "step_exec_frac": gemm_total_fl / dt / (PEAK_TFLOPS_16BIT * 1e12),
+            **step_trend(step_marks),
             "dense_equiv_frac": value * flops_per_sample / (world * PEAK_TFLOPS_16BIT * 1e12),
             "algorithmic_tflop_per_sample": flops_per_sample / 1e12,
             "exact_work_skipping": "none (dense, 77 rows per sequence)" if args.dense else
