@@ -5,8 +5,9 @@ The map restates what the reference's converters do tensor by tensor
 of ``in_proj_*``; ``text_projection.weight`` (HF, nn.Linear) is ``text_projection`` (OpenCLIP, applied as
 ``x @ P``) transposed; ``fc1/fc2`` are ``c_fc/c_proj``; ``layer_norm1/2`` are ``ln_1/ln_2``.
 The training checkpoint dict layout is the reference's (train_AT_text_only.py:516-525): ``optimizer`` is a
-``torch.optim.AdamW.state_dict()`` with the reference's two parameter groups in its ``named_parameters`` order
-(:326-341), so ``--resume`` of either code base loads the other's ``epoch_latest.pt`` (:351-372).
+``torch.optim.AdamW.state_dict()`` with the reference's two parameter groups in its ``named_parameters`` order (:326-341) --
+over the WHOLE CLIP, image tower included, because the reference freezes ``model.visual`` only after it has built the optimizer
+(:489-490); text-only groups with ``--lock-image`` or when the run started from a checkpoint without an image tower.
 """
 from __future__ import annotations
 
@@ -99,32 +100,55 @@ def non_text_tensors(sd) -> Dict[str, torch.Tensor]:
 
 
 # ----------------------------------------------------------------------------- reference AdamW state_dict layout
-def reference_param_groups(layers: int):
-    """Names of the reference's two AdamW groups in ITS order (train_AT_text_only.py:323-341 over CLIP.named_parameters() with the
-    image tower frozen, :489-490): group 0 = excluded from weight decay (p.ndim < 2 or 'bn' / 'ln' / 'bias' / 'logit_scale' in the
-    name), group 1 = the rest.  Module registration order of open_clip's CLIP: positional_embedding, text_projection, logit_scale,
-    (visual.*), transformer.resblocks.*, token_embedding, ln_final.  Pinned by tests/golden/ckpt_structure.json."""
-    order = ["positional_embedding", "text_projection", "logit_scale"]
+_BUFFER_SUFFIXES = ("running_mean", "running_var", "num_batches_tracked", "attn_mask")
+
+
+def _exclude(name: str, ndim: int) -> bool:
+    """The reference's ``exclude`` lambda (train_AT_text_only.py:326): no weight decay for gains, biases, logit_scale."""
+    return ndim < 2 or "bn" in name or "ln" in name or "bias" in name or "logit_scale" in name
+
+
+def non_text_parameters(extra) -> list:
+    """(name, ndim) of the carried-through non-text tensors that are PARAMETERS of the reference's CLIP, in checkpoint order:
+    buffers (BatchNorm statistics of the ResNet towers, a persistent attn_mask of old checkpoints) are not in
+    ``named_parameters()`` and so not in the optimizer."""
+    return [(k, int(v.ndim)) for k, v in (extra or {}).items() if not k.endswith(_BUFFER_SUFFIXES)]
+
+
+def reference_param_groups(layers: int, extra=None):
+    """Names of the reference's two AdamW groups in ITS order: train_AT_text_only.py:326-341 runs over
+    ``model.named_parameters()`` of the full CLIP while the image tower still requires grad -- it is frozen only at :489-490 --
+    so unless ``--lock-image`` was given (:286-290, before the optimizer) the groups hold every ``visual.*`` parameter too.
+    Group 0 = excluded from weight decay (p.ndim < 2 or 'bn' / 'ln' / 'bias' / 'logit_scale' in the name), group 1 = the rest.
+
+    ``extra``: the non-text tensors of the start checkpoint (``LeafCLIPText.extra_state``: ``visual.*``, ``logit_bias``) in their
+    checkpoint order, or None / {} for the TEXT-ONLY layout (``--lock-image``, or a start from an HF / text-only checkpoint, where
+    there is no image tower to name).  ``named_parameters()`` order of open_clip's CLIP: its own parameters
+    (positional_embedding, text_projection, logit_scale[, logit_bias]), then the children in registration order: visual.*,
+    transformer.*, token_embedding, ln_final.  Pinned by tests/golden/ckpt_structure.json (both cases; generated by executing the
+    reference's statements in the reference's order, tests/golden/make_golden_ckpt.py)."""
+    order = [("positional_embedding", 2), ("text_projection", 2), ("logit_scale", 0)]
+    order += non_text_parameters(extra)
     for i in range(layers):
         p = f"transformer.resblocks.{i}."
-        order += [p + n for n in ("ln_1.weight", "ln_1.bias", "attn.in_proj_weight", "attn.in_proj_bias", "attn.out_proj.weight",
-                                  "attn.out_proj.bias", "ln_2.weight", "ln_2.bias", "mlp.c_fc.weight", "mlp.c_fc.bias",
-                                  "mlp.c_proj.weight", "mlp.c_proj.bias")]
-    order += ["token_embedding.weight", "ln_final.weight", "ln_final.bias"]
-    one_d = lambda n: n in ("logit_scale",) or n.endswith((".bias", "ln_1.weight", "ln_2.weight", "ln_final.weight"))
-    excl = lambda n: one_d(n) or "bn" in n or "ln" in n or "bias" in n or "logit_scale" in n
-    return [n for n in order if excl(n)], [n for n in order if not excl(n)]
+        order += [(p + n, 1 if n.endswith("bias") or n.startswith("ln_") else 2) for n in
+                  ("ln_1.weight", "ln_1.bias", "attn.in_proj_weight", "attn.in_proj_bias", "attn.out_proj.weight",
+                   "attn.out_proj.bias", "ln_2.weight", "ln_2.bias", "mlp.c_fc.weight", "mlp.c_fc.bias",
+                   "mlp.c_proj.weight", "mlp.c_proj.bias")]
+    order += [("token_embedding.weight", 2), ("ln_final.weight", 1), ("ln_final.bias", 1)]
+    return [n for n, d in order if _exclude(n, d)], [n for n, d in order if not _exclude(n, d)]
 
 
 _GROUP_DEFAULTS = dict(amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
                        decoupled_weight_decay=True)
 
 
-def optimizer_state_to_torch(layout, layers, exp_avg, exp_avg_sq, step, lr, betas, eps, weight_decay, lrs=None):
+def optimizer_state_to_torch(layout, layers, exp_avg, exp_avg_sq, step, lr, betas, eps, weight_decay, lrs=None, extra=None):
     """Flat fp32 moments (engine layout: name -> (offset, shape)) -> torch.optim.AdamW.state_dict() as the reference's optimizer
-    would write it: param ids number group 0 then group 1; ``logit_scale`` (id 0) never receives a gradient, so -- exactly as in
-    the reference -- it has no state entry; every other parameter carries the common ``step`` as a 0-d fp32 tensor."""
-    g0, g1 = reference_param_groups(layers)
+    writes it (train_AT_text_only.py:516-525): param ids number group 0 then group 1 over the groups of ``reference_param_groups``
+    (``extra`` as there); parameters that never receive a gradient on this path -- ``logit_scale`` and every ``visual.*`` id --
+    have no state entry, exactly as in the reference; every text parameter carries the common ``step`` as a 0-d fp32 tensor."""
+    g0, g1 = reference_param_groups(layers, extra)
     names = g0 + g1
     state = {}
     for pid, n in enumerate(names):
@@ -143,14 +167,34 @@ def optimizer_state_to_torch(layout, layers, exp_avg, exp_avg_sq, step, lr, beta
     return {"state": state, "param_groups": groups}
 
 
-def optimizer_state_from_torch(osd, layout, layers, exp_avg, exp_avg_sq) -> int:
-    """Inverse of ``optimizer_state_to_torch`` (also reads a checkpoint the REFERENCE wrote): copies every parameter's moments
-    into the flat buffers, returns the step count.  Raises when the groups do not have the reference's sizes."""
-    g0, g1 = reference_param_groups(layers)
+def optimizer_state_layout(osd, layers, extra=None) -> str:
+    """Which of the two layouts a torch AdamW state_dict has: 'full' (groups over the whole CLIP: what the reference writes
+    without --lock-image; needs the non-text names, ``extra``) or 'text-only' (--lock-image, or written from a text-only start).
+    Raises when it has neither."""
+    pg = osd["param_groups"]
+    sizes = [len(g["params"]) for g in pg]
+    t0, t1 = reference_param_groups(layers)
+    if sizes == [len(t0), len(t1)]:
+        return "text-only"
+    if extra:
+        f0, f1 = reference_param_groups(layers, extra)
+        if sizes == [len(f0), len(f1)]:
+            return "full"
+        hint = f"or {len(f0)} + {len(f1)} with the {len(non_text_parameters(extra))} non-text parameters of this checkpoint"
+    else:
+        hint = "and the checkpoint's state_dict names no image tower to account for more"
+    raise ValueError(f"optimizer state has groups of {sizes} parameters: the reference's two groups hold {len(t0)} + {len(t1)} text "
+                     f"parameters, {hint}")
+
+
+def optimizer_state_from_torch(osd, layout, layers, exp_avg, exp_avg_sq, extra=None) -> int:
+    """Inverse of ``optimizer_state_to_torch``; also reads what the REFERENCE wrote (``extra`` = the non-text tensors of the SAME
+    checkpoint's state_dict, which name the ``visual.*`` ids between the text ids).  Copies every text parameter's moments into
+    the flat buffers and returns the step count; state of non-text ids (there is none on this path) is ignored."""
+    layout_kind = optimizer_state_layout(osd, layers, extra)
+    g0, g1 = reference_param_groups(layers, extra if layout_kind == "full" else None)
     names = g0 + g1
     pg = osd["param_groups"]
-    if len(pg) != 2 or len(pg[0]["params"]) != len(g0) or len(pg[1]["params"]) != len(g1):
-        raise ValueError(f"optimizer state does not have the reference's two groups ({len(g0)} + {len(g1)} parameters)")
     ids = list(pg[0]["params"]) + list(pg[1]["params"])
     step = 0
     exp_avg.zero_()
@@ -162,7 +206,7 @@ def optimizer_state_from_torch(osd, layout, layers, exp_avg, exp_avg_sq) -> int:
         off, shape = layout[n]
         numel = int(np.prod(shape))
         if tuple(st["exp_avg"].shape) != tuple(shape):
-            raise ValueError(f"optimizer state of {n}: shape {tuple(st['exp_avg'].shape)} != {tuple(shape)}")
+            raise ValueError(f"optimizer state of {n} (id {pid}): shape {tuple(st['exp_avg'].shape)} != {tuple(shape)}")
         exp_avg[off:off + numel].copy_(st["exp_avg"].reshape(-1))
         exp_avg_sq[off:off + numel].copy_(st["exp_avg_sq"].reshape(-1))
         step = max(step, int(float(st["step"])))

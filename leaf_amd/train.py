@@ -88,7 +88,10 @@ class LeafAdamW:
     first with weight_decay 0, the rest with ``--wd``) so schedulers and loggers that poke ``param_groups[0]['lr']``
     work unchanged."""
 
-    def __init__(self, model, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, model, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, lock_image=False):
+        # lock_image: --lock-image froze the image tower BEFORE the reference built its optimizer (train_AT_text_only.py:286-290),
+        # so that run's optimizer state has text-only groups; otherwise the groups span the whole CLIP (checkpoint.reference_param_groups)
+        self.lock_image = bool(lock_image)
         self.model = model.enable_training()
         nd = model.n_decay
         excl = [k for k, (off, _) in model.layout.items() if off >= nd]
@@ -112,17 +115,26 @@ class LeafAdamW:
     def state_dict(self):
         """torch.optim.AdamW.state_dict() of the reference's optimizer (two groups in its parameter order, per-parameter
         step / exp_avg / exp_avg_sq views of the flat moments): what --resume of the reference loads (train_AT_text_only.py:366)."""
-        from .checkpoint import optimizer_state_to_torch
+        from .checkpoint import non_text_parameters, optimizer_state_to_torch
         m, g = self.model, self.param_groups[1]
+        extra = None if self.lock_image else m.extra_state
+        n_vis = len(non_text_parameters(extra))
+        logging.info("optimizer state_dict: " + (f"the reference's groups over the whole CLIP ({n_vis} carried-through non-text parameters "
+                                                 "hold ids without state)" if n_vis else
+                                                 "TEXT-ONLY groups (" + ("--lock-image" if self.lock_image else "the start checkpoint "
+                                                 "names no image tower") + "): the reference resumes it only with --lock-image"))
         return optimizer_state_to_torch(m.layout, m.cfg.layers, m.exp_avg, m.exp_avg_sq, m.opt_step, g["lr"], g["betas"], g["eps"],
-                                        g["weight_decay"], lrs=(self.param_groups[0]["lr"], g["lr"]))
+                                        g["weight_decay"], lrs=(self.param_groups[0]["lr"], g["lr"]), extra=extra)
 
     def load_state_dict(self, sd):
         """Accepts the torch AdamW layout (written here or by the reference) and the flat layout of round-1 checkpoints."""
         m = self.model
         if "state" in sd and "param_groups" in sd:
-            from .checkpoint import optimizer_state_from_torch
-            m.opt_step = optimizer_state_from_torch(sd, m.layout, m.cfg.layers, m.exp_avg, m.exp_avg_sq)
+            from .checkpoint import optimizer_state_from_torch, optimizer_state_layout
+            # m.extra_state = the non-text tensors of the checkpoint just loaded: they name the visual.* ids of a full-CLIP layout
+            kind = optimizer_state_layout(sd, m.cfg.layers, m.extra_state)
+            logging.info(f"optimizer state_dict read in the {kind} layout")
+            m.opt_step = optimizer_state_from_torch(sd, m.layout, m.cfg.layers, m.exp_avg, m.exp_avg_sq, extra=m.extra_state)
             saved = sd["param_groups"]
         elif "exp_avg" in sd:
             m.opt_step = int(sd["step"])

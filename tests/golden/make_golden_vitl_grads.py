@@ -5,13 +5,11 @@ by the REFERENCE's CLIP + torch.autograd on CPU in fp32 (utils_AT.py:317-337).  
 text-tower tensor, the gradient's L2 norm and a fixed strided sample of its elements, plus the loss and features -- small
 enough to commit, wide enough to catch a wrong tensor, a wrong scale or a transposed weight gradient.
 
-Also writes ckpt_structure.json: the reference's AdamW grouping (train_AT_text_only.py:326-341) and
-``optimizer.state_dict()`` / ``model.state_dict()`` structure for the tiny CLIP (key order, shapes, group membership) --
-what ``--resume`` (train_AT_text_only.py:351-372) expects to find in epoch_latest.pt.
+(The optimizer / checkpoint structure fixture, ckpt_structure.json, moved to make_golden_ckpt.py in round 3: it is produced by
+executing the reference's own statements in the reference's order.  No optimizer is built here.)
 
 Runs only in the build container.   python tests/golden/make_golden_vitl_grads.py
 """
-import json
 import os
 import sys
 
@@ -68,50 +66,6 @@ def main():
         np.savez_compressed(os.path.join(HERE, f"vitl_grads_{tag}.npz"), **out)
         print(mname, "loss", loss.item(), "tensors", sum(1 for k in out if k.startswith("n:")))
         del model
-
-    # ---- checkpoint / optimizer structure of the reference (tiny CLIP, same grouping lambda)
-    model = CLIP(**MG.TINY, quick_gelu=True).float().train()
-    for p_ in model.visual.parameters():   # train_AT_text_only.py:489-490
-        p_.requires_grad = False
-    exclude = lambda n, p: p.ndim < 2 or "bn" in n or "ln" in n or "bias" in n or 'logit_scale' in n
-    named = list(model.named_parameters())
-    gain_or_bias = [(n, p) for n, p in named if exclude(n, p) and p.requires_grad]
-    rest = [(n, p) for n, p in named if not exclude(n, p) and p.requires_grad]
-    opt = torch.optim.AdamW([{"params": [p for _, p in gain_or_bias], "weight_decay": 0.},
-                             {"params": [p for _, p in rest], "weight_decay": 1e-4}], lr=1e-5, betas=(0.9, 0.999), eps=1e-8)
-    toks = torch.from_numpy(MG_tokens())
-    f = model.encode_text(toks)
-    (f ** 2).sum().backward()
-    opt.step()
-    osd = opt.state_dict()
-    struct = {
-        "state_dict_keys": [[k, list(v.shape), str(v.dtype)] for k, v in model.state_dict().items()],
-        "group_names": [[n for n, _ in gain_or_bias], [n for n, _ in rest]],
-        "param_groups": [{k: (v if k != "params" else list(v)) for k, v in g.items()} for g in osd["param_groups"]],
-        "state_entry_keys": sorted(next(iter(osd["state"].values())).keys()),
-        "state_ids": sorted(osd["state"].keys()),
-        "step_dtype": str(next(iter(osd["state"].values()))["step"].dtype),
-        "step_shape": list(next(iter(osd["state"].values()))["step"].shape),
-        "no_grad_names": [n for n, p in named if p.requires_grad and p.grad is None],
-    }
-
-    def jsonable(o):
-        if isinstance(o, dict):
-            return {k: jsonable(v) for k, v in o.items()}
-        if isinstance(o, (list, tuple)):
-            return [jsonable(v) for v in o]
-        if isinstance(o, (bool, int, float, str)) or o is None:
-            return o
-        return str(o)
-    with open(os.path.join(HERE, "ckpt_structure.json"), "w") as fjs:
-        json.dump(jsonable(struct), fjs)
-    print("ckpt_structure.json:", len(struct["state_dict_keys"]), "state_dict keys;", len(struct["state_ids"]), "optimizer states;",
-          "params without grad:", struct["no_grad_names"])
-
-
-def MG_tokens():
-    from oracle import text_oracle as O
-    return O.synthetic_tokens(4, seed=2).astype(np.int64)
 
 
 if __name__ == "__main__":

@@ -36,60 +36,134 @@ def _layout(cfg: TextConfig):
     return out, n, nd
 
 
-def test_adamw_groups_match_the_reference_fixture(golden_dir):
+def _fixture(golden_dir):
     with open(os.path.join(golden_dir, "ckpt_structure.json")) as f:
-        s = json.load(f)
-    g0, g1 = CK.reference_param_groups(2)
-    assert [g0, g1] == s["group_names"]
+        return json.load(f)
+
+
+def _extra_from_fixture(s):
+    """The non-text tensors a run started from the reference's (tiny) CLIP checkpoint carries through, in checkpoint order."""
+    text = ("token_embedding.", "positional_embedding", "transformer.", "ln_final.", "text_projection", "logit_scale")
+    return {k: torch.zeros(shape) for k, shape, _ in s["state_dict_keys"] if not k.startswith(text)}
+
+
+def test_fixture_generator_ran_the_reference_steps_in_the_reference_order(golden_dir):
+    """round 2's generator froze model.visual BEFORE building the optimizer and so pinned a layout the
+    reference never writes.  The generator now executes the reference's own statements and records where they stand in the
+    reference and what the model looked like when the optimizer was built; a re-ordered generator fails here."""
+    s = _fixture(golden_dir)
+    d, l = s["cases"]["default"], s["cases"]["lock_image"]
+    for c in (d, l):
+        ln = c["reference_lines"]
+        assert ln["lock_image"] < ln["optimizer"] < ln["freeze_visual"] < ln["checkpoint_dict"]
+        assert c["checkpoint_keys"] == ["epoch", "name", "optimizer", "state_dict"]
+    assert d["visual_trainable_when_optimizer_was_built"] is True and l["visual_trainable_when_optimizer_was_built"] is False
+    vis = [n for g in d["group_names"] for n in g if n.startswith("visual.")]
+    assert len(vis) == sum(1 for n, _ in s["named_parameters"] if n.startswith("visual.")) > 0
+    assert not any(n.startswith("visual.") for g in l["group_names"] for n in g)
+    # no state for what never receives a gradient on this path: logit_scale and the whole image tower
+    assert set(d["no_state_names"]) == {"logit_scale", *vis} and l["no_state_names"] == ["logit_scale"]
+    # the gradient fixture's generator builds no optimizer at all any more
+    src = open(os.path.join(golden_dir, "make_golden_vitl_grads.py")).read()
+    assert "optim." not in src and "AdamW" not in src
+
+
+@pytest.mark.parametrize("case", ["default", "lock_image"])
+def test_adamw_groups_match_the_reference_fixture(golden_dir, case):
+    s = _fixture(golden_dir)
+    c = s["cases"][case]
+    extra = _extra_from_fixture(s) if case == "default" else None
+    g0, g1 = CK.reference_param_groups(2, extra)
+    assert [g0, g1] == c["group_names"]
     cfg = MODEL_CONFIGS["tiny-test-quickgelu"]
     layout, n, nd = _layout(cfg)
-    # the engine's decay split must be the reference's: group 1 == the tensors below n_decay
-    assert sorted(k for k, (off, _) in layout.items() if off < nd) == sorted(g1)
+    # the engine's decay split must be the reference's: the text tensors of group 1 == the tensors below n_decay
+    assert sorted(k for k, (off, _) in layout.items() if off < nd) == sorted(k for k in g1 if k in layout)
     m, v = torch.arange(n, dtype=torch.float32) * 1e-3, torch.arange(n, dtype=torch.float32) * 1e-6 + 1.0
-    osd = CK.optimizer_state_to_torch(layout, cfg.layers, m, v, 7, 1e-5, (0.9, 0.999), 1e-8, 1e-4)
-    assert sorted(osd["state"].keys()) == s["state_ids"], "logit_scale (id 0) has no state, every other parameter has"
-    first = osd["state"][1]
-    assert sorted(first.keys()) == s["state_entry_keys"]
-    assert str(first["step"].dtype) == s["step_dtype"] and list(first["step"].shape) == s["step_shape"] and float(first["step"]) == 7.0
-    for got, want in zip(osd["param_groups"], s["param_groups"]):
+    osd = CK.optimizer_state_to_torch(layout, cfg.layers, m, v, 1, 1e-5, (0.9, 0.999), 1e-8, 1e-4, extra=extra)
+    assert sorted(osd["state"].keys()) == c["state_ids"], "the ids WITH state are exactly the reference's (text parameters)"
+    names = g0 + g1
+    assert [names[i] for i in sorted(osd["state"])] == c["state_names"]
+    first = osd["state"][c["state_ids"][0]]
+    assert sorted(first.keys()) == c["state_entry_keys"]
+    assert str(first["step"].dtype) == c["step_dtype"] and list(first["step"].shape) == c["step_shape"] and float(first["step"]) == c["step_value"]
+    for got, want in zip(osd["param_groups"], c["param_groups"]):
         assert got["params"] == want["params"] and set(want) <= set(got)
         assert got["weight_decay"] == want["weight_decay"] and list(got["betas"]) == want["betas"] and got["eps"] == want["eps"]
-    # shapes per id = the reference's state_dict shapes
     shapes = {k: v_ for k, v_, _ in s["state_dict_keys"]}
-    for pid, name in enumerate(g0 + g1):
+    for pid, name in enumerate(names):
         if pid in osd["state"]:
             assert list(osd["state"][pid]["exp_avg"].shape) == shapes[name], name
     # round trip into fresh flat buffers
     m2, v2 = torch.zeros(n), torch.zeros(n)
-    assert CK.optimizer_state_from_torch(osd, layout, cfg.layers, m2, v2) == 7
+    assert CK.optimizer_state_layout(osd, cfg.layers, extra) == ("full" if extra else "text-only")
+    assert CK.optimizer_state_from_torch(osd, layout, cfg.layers, m2, v2, extra=extra) == 1
     assert torch.equal(m, m2) and torch.equal(v, v2)
 
 
-def test_written_optimizer_state_loads_into_torch_adamw():
-    """What the reference does on --resume: optimizer.load_state_dict(checkpoint['optimizer']) on an AdamW built with its two
-    groups (train_AT_text_only.py:333-341,366) -- torch checks group sizes and casts the state to the parameters."""
-    cfg = MODEL_CONFIGS["tiny-test"]
+def _reference_ordered_adamw(s, lock_image):
+    """torch.optim.AdamW built the way the reference builds it (train_AT_text_only.py:326-341) over parameters with the
+    fixture's names / shapes in named_parameters order: over ALL of them unless --lock-image froze the image tower first."""
+    shapes = {k: sh for k, sh, _ in s["state_dict_keys"]}
+    named = [(n, torch.nn.Parameter(torch.zeros(shapes[n]))) for n, _ in s["named_parameters"]]
+    if lock_image:
+        for n, p_ in named:
+            if n.startswith("visual."):
+                p_.requires_grad = False
+    exclude = lambda n, p_: p_.ndim < 2 or "bn" in n or "ln" in n or "bias" in n or "logit_scale" in n
+    gb = [p_ for n, p_ in named if exclude(n, p_) and p_.requires_grad]
+    rest = [p_ for n, p_ in named if not exclude(n, p_) and p_.requires_grad]
+    opt = torch.optim.AdamW([{"params": gb, "weight_decay": 0.0}, {"params": rest, "weight_decay": 0.2}], lr=1e-3)
+    return dict(named), opt
+
+
+@pytest.mark.parametrize("lock_image", [False, True])
+def test_optimizer_state_interchange_with_a_reference_ordered_adamw(golden_dir, lock_image):
+    """Both directions of --resume (train_AT_text_only.py:364-366, 516-525): the reference's optimizer.load_state_dict() takes
+    what we write (torch checks the group sizes and copies the state by id), and we read what torch's AdamW -- i.e. the
+    reference -- writes, image-tower ids included; ids and shapes are checked per parameter."""
+    s = _fixture(golden_dir)
+    cfg = MODEL_CONFIGS["tiny-test-quickgelu"]
     layout, n, _ = _layout(cfg)
-    g0, g1 = CK.reference_param_groups(cfg.layers)
-    shape = lambda k: layout[k][1] if k in layout else ()
-    params = {k: torch.nn.Parameter(torch.zeros(shape(k))) for k in g0 + g1}
-    opt = torch.optim.AdamW([{"params": [params[k] for k in g0], "weight_decay": 0.0},
-                             {"params": [params[k] for k in g1], "weight_decay": 0.2}], lr=1e-3)
+    extra = None if lock_image else _extra_from_fixture(s)
+    params, opt = _reference_ordered_adamw(s, lock_image)
     rng = torch.Generator().manual_seed(0)
     m, v = torch.randn(n, generator=rng), torch.rand(n, generator=rng)
-    opt.load_state_dict(CK.optimizer_state_to_torch(layout, cfg.layers, m, v, 5, 3e-4, (0.9, 0.98), 1e-6, 0.2))
-    st = opt.state[params["transformer.resblocks.1.mlp.c_fc.weight"]]
-    off, shp = layout["transformer.resblocks.1.mlp.c_fc.weight"]
-    assert float(st["step"]) == 5 and torch.equal(st["exp_avg"], m[off:off + shp[0] * shp[1]].view(shp))
+    ours = CK.optimizer_state_to_torch(layout, cfg.layers, m, v, 5, 3e-4, (0.9, 0.98), 1e-6, 0.2, extra=extra)
+    opt.load_state_dict(ours)                        # raises on any group-size mismatch
+    for name, (off, shp) in layout.items():
+        st = opt.state[params[name]]
+        numel = int(np.prod(shp))
+        assert float(st["step"]) == 5 and torch.equal(st["exp_avg"], m[off:off + numel].view(shp)), name
+        assert torch.equal(st["exp_avg_sq"], v[off:off + numel].view(shp)), name
     assert params["logit_scale"] not in opt.state
+    assert not any(k.startswith("visual.") and p_ in opt.state for k, p_ in params.items())
     assert opt.param_groups[1]["lr"] == 3e-4 and opt.param_groups[1]["weight_decay"] == 0.2 and opt.param_groups[0]["weight_decay"] == 0.0
-    # and the other direction: a state_dict written by torch's AdamW (= by the reference) fills the flat buffers
-    for p_ in params.values():
-        p_.grad = torch.ones_like(p_) if p_.ndim else None
+    # the other direction: one more step of the text parameters in torch, then read torch's state_dict back
+    for name, p_ in params.items():
+        p_.grad = torch.ones_like(p_) if name in layout else None
     opt.step()
+    written = opt.state_dict()
+    assert [len(g["params"]) for g in written["param_groups"]] == [len(g) for g in s["cases"]["lock_image" if lock_image else "default"]["group_names"]]
     m2, v2 = torch.zeros(n), torch.zeros(n)
-    assert CK.optimizer_state_from_torch(opt.state_dict(), layout, cfg.layers, m2, v2) == 6
-    assert torch.allclose(m2[off:off + 4], 0.9 * m[off:off + 4] + 0.1)
+    assert CK.optimizer_state_from_torch(written, layout, cfg.layers, m2, v2, extra=extra) == 6
+    for name, (off, shp) in layout.items():      # (the flat buffers have alignment gaps between tensors)
+        sl = slice(off, off + int(np.prod(shp)))
+        assert torch.allclose(m2[sl], 0.9 * m[sl] + 0.1, atol=1e-6) and torch.allclose(v2[sl], 0.98 * v[sl] + 0.02, atol=1e-6), name
+
+
+def test_optimizer_state_with_unknown_groups_is_refused(golden_dir):
+    """A full-CLIP optimizer state cannot be mapped without the image tower's parameter names: loud, never a silent mis-assignment."""
+    s = _fixture(golden_dir)
+    cfg = MODEL_CONFIGS["tiny-test-quickgelu"]
+    layout, n, _ = _layout(cfg)
+    full = CK.optimizer_state_to_torch(layout, cfg.layers, torch.zeros(n), torch.ones(n), 1, 1e-5, (0.9, 0.999), 1e-8, 1e-4,
+                                       extra=_extra_from_fixture(s))
+    with pytest.raises(ValueError, match="names no image tower"):
+        CK.optimizer_state_from_torch(full, layout, cfg.layers, torch.zeros(n), torch.zeros(n), extra=None)
+    # BatchNorm buffers of a ResNet image tower are not parameters: they take no id
+    extra = {"visual.bn1.weight": torch.zeros(4), "visual.bn1.running_mean": torch.zeros(4), "visual.bn1.num_batches_tracked": torch.zeros(())}
+    assert CK.non_text_parameters(extra) == [("visual.bn1.weight", 1)]
 
 
 @pytest.mark.parametrize("name,with_proj", [("tiny-test-quickgelu", True), ("tiny-test", True), ("tiny-test", False)])

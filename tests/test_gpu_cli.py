@@ -68,6 +68,38 @@ def test_full_clip_checkpoint_is_carried_through(tmp_path, monkeypatch):
     assert torch.equal(ck["state_dict"]["visual.proj"], full["visual.proj"])
     assert not torch.equal(ck["state_dict"]["text_projection"], full["text_projection"])
     assert os.path.exists(tmp_path / "hf_out" / "model.safetensors") and os.path.exists(tmp_path / "hf_out" / "config.json")
+    # the optimizer state has the reference's groups over the WHOLE CLIP (it builds AdamW before it freezes model.visual,
+    # train_AT_text_only.py:326-341 vs :489-490): an AdamW built that way over this state_dict's parameters loads it
+    from leaf_amd.checkpoint import reference_param_groups
+    extra = {k: v for k, v in full.items() if k.startswith("visual.")}
+    g0, g1 = reference_param_groups(2, extra)
+    assert "visual.ln_post.bias" in g0 and "visual.conv1.weight" in g1 and "visual.proj" in g1
+    osd = ck["optimizer"]
+    assert [len(g["params"]) for g in osd["param_groups"]] == [len(g0), len(g1)]
+    names = g0 + g1
+    assert not any(names[i].startswith("visual.") or names[i] == "logit_scale" for i in osd["state"])
+    params = {k: torch.nn.Parameter(torch.zeros(ck["state_dict"][k].shape)) for k in names}
+    ref_opt = torch.optim.AdamW([{"params": [params[k] for k in g0], "weight_decay": 0.0},
+                                 {"params": [params[k] for k in g1], "weight_decay": 1e-4}], lr=1e-4)
+    ref_opt.load_state_dict(osd)
+    assert float(ref_opt.state[params["token_embedding.weight"]]["step"]) == 1
+    # ... and our own --resume reads it back (the visual.* names come from the same checkpoint's state_dict)
+    args2 = [a for a in args if a not in ("--export-hf", str(tmp_path / "hf_out"))]
+    args2[args2.index("runf")] = "runf2"
+    args2[args2.index("--epochs") + 1] = "2"
+    assert cli.main(args2 + ["--resume", "latest"]) == 0
+    ck2 = torch.load(tmp_path / "results" / "f_text_only_k1_rho4_seed4" / "epoch_latest.pt", map_location="cpu", weights_only=False)
+    assert ck2["epoch"] == 2 and [len(g["params"]) for g in ck2["optimizer"]["param_groups"]] == [len(g0), len(g1)]
+    assert float(next(iter(ck2["optimizer"]["state"].values()))["step"]) == 2
+    # --lock-image freezes the tower BEFORE the reference builds its optimizer (:286-290): text-only groups
+    args3 = list(args2)
+    args3[args3.index("runf2")] = "runf3"
+    args3[args3.index("f_")] = "l_"
+    args3[args3.index("--epochs") + 1] = "1"
+    assert cli.main(args3 + ["--lock-image"]) == 0
+    ck3 = torch.load(tmp_path / "results" / "l_text_only_k1_rho4_seed4" / "epoch_latest.pt", map_location="cpu", weights_only=False)
+    t0, t1 = reference_param_groups(2)
+    assert [len(g["params"]) for g in ck3["optimizer"]["param_groups"]] == [len(t0), len(t1)] and set(full) == set(ck3["state_dict"])
 
 
 def test_hf_key_roundtrip_gives_same_embeddings():

@@ -100,7 +100,8 @@ def main(argv):
         with open(os.path.join(log_base, "params.txt"), "w") as f:
             for k in sorted(vars(args)):
                 f.write(f"{k}: {getattr(args, k)}\n")
-    optimizer = LeafAdamW(model, lr=args.lr, betas=(args.beta1, args.beta2), eps=args.eps, weight_decay=args.wd)
+    optimizer = LeafAdamW(model, lr=args.lr, betas=(args.beta1, args.beta2), eps=args.eps, weight_decay=args.wd,
+                          lock_image=args.lock_image)
     start_epoch = 0
     if args.resume:
         start_epoch = load_checkpoint(args.resume, model, optimizer)
