@@ -172,7 +172,7 @@ int leaf_gemm(int dtype, int epi, const void* A, int lda, const void* B, int ldb
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.aux = aux;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.act = act; g.aux_f16 = aux_f16; g.beta = beta; g.stamps = nullptr; g.alpha = alpha; g.ngroup = 0;
-    g.ln_s = nullptr; g.rowstat = nullptr; g.stat_out = nullptr; g.x16 = nullptr; g.stat_ld = 0; g.ldx16 = 0; g.ln_eps = 0.f;
+    g.ln_s = nullptr; g.rowstat = nullptr; g.stat_out = nullptr; g.x16 = nullptr; g.stat_ld = 0; g.ldx16 = 0; g.ln_eps = 0.f; g.stagger = 0;
     if (epi == EPI_LNFOLD_T || epi == EPI_LNFOLD_ACT_T || epi == EPI_RESID_LN) {
         const bool fold = epi != EPI_RESID_LN;
         if (!ln || (fold && (!ln->ln_s || !ln->rowstat || !bias)) || (!fold && (!ln->x16 || !ln->stat_out || N % 64 || ln->stat_ld < M))) {

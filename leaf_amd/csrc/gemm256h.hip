@@ -131,7 +131,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
     acc[i][0] = TT::mfma(P##w0, xi, acc[i][0]); acc[i][1] = TT::mfma(P##w1, xi, acc[i][1]);                   \
     acc[i][2] = TT::mfma(P##w2, xi, acc[i][2]); acc[i][3] = TT::mfma(P##w3, xi, acc[i][3]);
 #define MFMA_H1(P) MROW(P, 0, P##x0) MROW(P, 1, P##x1) MROW(P, 2, P##x2) MROW(P, 3, P##x3)
-#define MFMA_H2(P) MROW(P, 4, P##x4) MROW(P, 5, P##x5) MROW(P, 6, P##x6) MROW(P, 7, P##x7)
+#define MFMA_H2(P) MROW(P, 4, XSEL_4(P)) MROW(P, 5, XSEL_5(P)) MROW(P, 6, XSEL_6(P)) MROW(P, 7, XSEL_7(P))
 #define SB __builtin_amdgcn_sched_barrier(0);
 #ifdef LEAF_DIAG_NOBAR    // diagnostic only: no per-tile workgroup barrier
 #define DIAG_BARRIER
@@ -148,9 +148,30 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
     // k-step's MFMAs, the last four (rows 4-7 of CUR, not needed before the next k-step) under CUR's own first half -
     // instead of twelve back-to-back ds_read_b128 that stall the wave's in-order MFMA issue (diagnostic builds: the
     // bunched reads cost 10 % of a tile).  The four DMA pieces of a half-stage are spread in between (IS = issue macro).
-#define MF(P, i, j) acc[i][j] = TT::mfma(P##w##j, P##x##i, acc[i][j]);
-#define RDW(P, n) P##w##n = LD(sb_ + (n) * 2048);
+#ifdef LEAF_DIAG_READ23   // diagnostic only (wrong results): activation-fragment rows 4-7 reuse the registers of rows 0-3, i.e. 8 instead
+                          // of 12 ds_read_b128 per k-step = the LDS read bytes per MFMA of a 128 x 128 per-wave tile (256 B), on random data
+#define XSEL_0(P) P##x0
+#define XSEL_1(P) P##x1
+#define XSEL_2(P) P##x2
+#define XSEL_3(P) P##x3
+#define XSEL_4(P) P##x0
+#define XSEL_5(P) P##x1
+#define XSEL_6(P) P##x2
+#define XSEL_7(P) P##x3
+#define RDX(P, n) if ((n) < 4) { P##x##n = LD(sa_ + (n) * 2048); }
+#else
+#define XSEL_0(P) P##x0
+#define XSEL_1(P) P##x1
+#define XSEL_2(P) P##x2
+#define XSEL_3(P) P##x3
+#define XSEL_4(P) P##x4
+#define XSEL_5(P) P##x5
+#define XSEL_6(P) P##x6
+#define XSEL_7(P) P##x7
 #define RDX(P, n) P##x##n = LD(sa_ + (n) * 2048);
+#endif
+#define MF(P, i, j) acc[i][j] = TT::mfma(P##w##j, XSEL_##i(P), acc[i][j]);
+#define RDW(P, n) P##w##n = LD(sb_ + (n) * 2048);
 #ifdef LEAF_GEMM_BUNCHED_READS   // the previous schedule, kept for A/B builds
 #define KSTEP(PREV, CUR, sa, sb, fo, IS0, IS1, IS2, IS3)                                                     \
     READ_FRAGS(CUR, sa, sb, fo)                                                                              \
@@ -170,10 +191,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
         SB IS1                                                                                               \
         SB MF(PREV, 6, 0) SB RDX(CUR, 2) SB MF(PREV, 6, 1) MF(PREV, 6, 2) SB RDX(CUR, 3) SB MF(PREV, 6, 3)    \
         SB IS2                                                                                               \
-        SB MROW(PREV, 7, PREV##x7) SB IS3                                                                    \
+        SB MROW(PREV, 7, XSEL_7(PREV)) SB IS3                                                              \
         SB MF(CUR, 0, 0) SB RDX(CUR, 4) SB MF(CUR, 0, 1) MF(CUR, 0, 2) SB RDX(CUR, 5) SB MF(CUR, 0, 3)        \
         SB MF(CUR, 1, 0) SB RDX(CUR, 6) SB MF(CUR, 1, 1) MF(CUR, 1, 2) SB RDX(CUR, 7) SB MF(CUR, 1, 3)        \
-        SB MROW(CUR, 2, CUR##x2) MROW(CUR, 3, CUR##x3) SB                                                    \
+        SB MROW(CUR, 2, XSEL_2(CUR)) MROW(CUR, 3, XSEL_3(CUR)) SB                                                    \
     }
 #endif
 #define NOP_
@@ -497,6 +518,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
 #undef MF
 #undef RDW
 #undef RDX
+#undef XSEL_0
+#undef XSEL_1
+#undef XSEL_2
+#undef XSEL_3
+#undef XSEL_4
+#undef XSEL_5
+#undef XSEL_6
+#undef XSEL_7
 #undef NOP_
 #undef SB
 #undef LD

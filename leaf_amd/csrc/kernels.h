@@ -43,16 +43,21 @@ struct GemmArgs {
     void* x16;                // [M, N] 16-bit copy of the fp32 output, row stride ldx16
     int stat_ld, ldx16;
     float ln_eps;
+    int stagger;  // gemm128pp.hip: start delay (x 2,048 cycles) of the second workgroup of each CU in the first round
 };
 
 hipError_t leaf_launch_gemm(const GemmArgs& p, int dtype, int epi, hipStream_t s);
 void leaf_gemm_set_stamps(void* p);
-int leaf_gemm_family(const GemmArgs& p, int epi);   // 0 = gemm_nt_kernel, 1 = gemm_nt256_kernel (gemm.hip), 4 = half-stage ring, 6 = gemm64
+int leaf_gemm_family(const GemmArgs& p, int epi);   // 0 = gemm_nt_kernel, 1 = gemm_nt256_kernel (gemm.hip), 4 = half-stage ring, 6 = gemm64, 7 = ping-pong
 // 256 x 256 tile, 64-deep half-stage LDS-DMA ring with full-line pieces (gemm256h.hip): the kernel of every launch with >= 128 tiles
 bool leaf_gemm256h_eligible(const GemmArgs& p, int epi);
 void leaf_gemm256h_set_min_tiles(int n);
 int leaf_gemm256h_pick_ngroup(const GemmArgs& p);   // N tiles per L2-sized group (0 = one group)
 hipError_t leaf_launch_gemm256h(const GemmArgs& p, int dtype, int epi, hipStream_t s);
+// 128 x 256 tiles, 4 waves, two workgroups per CU out of phase (gemm128pp.hip)
+bool leaf_gemm128pp_eligible(const GemmArgs& p, int epi);
+void leaf_gemm128pp_set_min_tiles(int n);
+hipError_t leaf_launch_gemm128pp(const GemmArgs& p, int dtype, int epi, hipStream_t s);
 // 64 x 128 tiles on a 3-slot LDS-DMA ring for small launches (gemm64.hip)
 bool leaf_gemm64_eligible(const GemmArgs& p);
 hipError_t leaf_launch_gemm64(const GemmArgs& p, int dtype, int epi, hipStream_t s);
