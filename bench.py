@@ -105,6 +105,22 @@ def self_launch(args, argv):
     return subprocess.call(cmd, env=env)
 
 
+def per_rank_summary(gathered):
+    """Per-rank diagnostics of a multi-rank run (rank order): what the first scaling run needs in order to say WHY it is 0.8 or
+    0.95.  ``ms_per_step`` is each rank's own step time (its stream's events; the ranks meet at every gradient reduction, so they
+    agree closely), ``exposed_collective_ms_per_step`` the time its stream waited inside the reduction -- small on the rank whose
+    data-dependent search took longest, large on the ranks that waited for it -- and ``scored_rows_per_step`` the rows its search
+    computed (exact work skipping makes that differ by rank)."""
+    import statistics
+    cols = list(zip(*[[float(x) for x in g.tolist()] for g in gathered]))
+    names = ("ms_per_step", "exposed_collective_ms_per_step", "scored_rows_per_step")
+    out = {n: list(c) for n, c in zip(names, cols)}
+    out.update({n + "_min_median_max": [min(c), statistics.median(c), max(c)] for n, c in zip(names, cols)})
+    ms, ex = cols[0], cols[1]
+    out["compute_ms_per_step"] = [m - e for m, e in zip(ms, ex)]        # step time without the wait: the slowest rank sets the pace
+    return out
+
+
 def dry_run(args):
     """Launcher / rendezvous rehearsal without a GPU (tests/test_bench_launch.py): gloo process group, one all-reduce,
     the same one-JSON-line contract with n_ranks_seen."""
@@ -118,14 +134,19 @@ def dry_run(args):
         dist.init_process_group(args.backend, rank=rank, world_size=world)
     t = torch.tensor([float(rank + 1)])
     seen = 1
+    mine = torch.tensor([10.0 + rank, 0.5 * rank, 1000.0 * (rank + 1)], dtype=torch.float64)   # stand-ins for the per-rank diagnostics
+    gathered = [mine]
     if world > 1:
         dist.all_reduce(t)
         seen = dist.get_world_size()
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
         dist.barrier()
     if rank == 0:
         print(json.dumps({"metric": "adversarial text samples/sec", "value": 0.0, "unit": "samples/s", "n_gpus": args.gpus,
                           "n_ranks_seen": seen, "dry": True, "backend": args.backend, "allreduce_sum": float(t.item()),
-                          "steps": args.steps, "warmup": args.warmup}), flush=True)
+                          "steps": args.steps, "warmup": args.warmup, "host_threads_per_rank": args.host_threads,
+                          "per_rank": per_rank_summary(gathered)}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
@@ -147,6 +168,8 @@ def main():
     ap.add_argument("--no-prefix-reuse", action="store_true", help="recompute every kept row of every candidate")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    ap.add_argument("--host-threads", type=int, default=0,
+                    help="host threads per rank (torch CPU ops, the native tokenizer: LEAF_HOST_THREADS); default = usable cores // ranks on this node")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--dry", action="store_true", help="rendezvous rehearsal only (no GPU work); with --backend gloo runs on CPU")
     ap.add_argument("--attack", default="leaf", choices=["leaf", "pgd"],
@@ -162,6 +185,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # host threads: N ranks on one node share its cores (a default of min(32, cores) per rank would start 8 x 32 threads)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    args.host_threads = args.host_threads or max(1, usable // max(local_world, 1))
+    os.environ["LEAF_HOST_THREADS"] = str(args.host_threads)
     if args.dry:
         return dry_run(args)
 
@@ -243,6 +271,11 @@ def main():
 
     run_steps(args.warmup, base_lens, not args.no_prefix_reuse)
     lib = _lib.lib()
+    from leaf_amd.step import get_reducer
+    reducer = get_reducer(model)
+    reducer.timing = use_dist
+    reducer.exposed_ms()          # drop the warm-up's pairs
+    rows0 = model.rows_scored
     barrier()
     if rank == 0:
         lib.leaf_prof_begin()
@@ -251,8 +284,15 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    gathered = None
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        # per-rank diagnostics: own step time (events on this rank's stream), exposed reduction wait, rows its search computed
+        own_ms = step_marks[0].elapsed_time(step_marks[-1]) / max(len(step_marks) - 1, 1) if len(step_marks) > 1 else dt / args.steps * 1e3
+        mine = torch.tensor([own_ms, reducer.exposed_ms() / args.steps, (model.rows_scored - rows0) / args.steps],
+                            dtype=torch.float64, device="cpu" if rehearsal else dev)
+        gathered = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(gathered, mine)
     dt = float(tmax.item())
 
     if rank == 0:
@@ -306,6 +346,8 @@ def main():
         out = {
             "metric": "adversarial text samples/sec", "value": value, "unit": "samples/s",
             "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps, "warmup": args.warmup,
+            "host_threads_per_rank": args.host_threads,
+            **({"per_rank": per_rank_summary(gathered)} if gathered is not None else {}),
             **({"rehearsal": f"gloo transport, {world} rank(s) on {ndev} device(s): functional rehearsal of the multi-rank step, "
                              "NOT the metric (RCCL, one device per rank, is)"} if rehearsal else {}),
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",

@@ -161,12 +161,39 @@ int leaf_textfare_backward_events(leaf_text_t h, const float* params, const void
 int leaf_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, size_t n_decay,
                     float lr, float beta1, float beta2, float eps, float wd, int step, float grad_scale,
                     leaf_stream_t s);
+/* GRADIENT SCALER (the reference trains under fp16 autocast with torch.cuda.amp.GradScaler: train_AT_text_only.py:347,
+ * utils_AT.py:79-83,339-362).  The fp16 gradient path multiplies the loss gradient by a power of two S chosen on the device
+ * each step (max|d loss / d feat| * S in [8, 16)) and its 16-bit conversions SATURATE at +-65504 instead of producing inf, so
+ * an overflow would clip silently.  With a scaler state attached (leaf_text_set_grad_scaler) the backward checks every 16-bit
+ * gradient tensor of every block for saturated / non-finite values; a hit poisons gradient element 0 with NaN (the padding row
+ * of the token-embedding table: untouched otherwise), so the guarded optimizer step below -- after the data-parallel all-reduce,
+ * hence on every rank alike -- skips the step, and halves S for the following steps (state[LEAF_SC_BACKOFF] -= 1); after
+ * state[LEAF_SC_INTERVAL] (default 2000, GradScaler's growth_interval) applied steps in a row the back-off is taken back by
+ * one halving.  The state is the head of the clip_ws buffer of leaf_adamw_step_clip: device fp32 [LEAF_SC_WORDS + 2048],
+ * zeroed once by the caller. */
+enum {
+    LEAF_SC_COEF = 0,      /* clip coefficient applied by the last guarded step, -1 = that step was skipped */
+    LEAF_SC_NORM = 1,      /* total gradient norm seen by the last guarded step */
+    LEAF_SC_SKIPPED = 2,   /* optimizer steps skipped so far (non-finite norm: overflow, saturation, NaN) */
+    LEAF_SC_BACKOFF = 3,   /* <= 0: log2 of the persistent factor on the per-step loss scale */
+    LEAF_SC_GOOD = 4,      /* applied steps since the scale last changed */
+    LEAF_SC_SAT_FLAG = 5,  /* a 16-bit gradient tensor saturated during the current optimizer step */
+    LEAF_SC_SAT_STEPS = 6, /* skipped steps that had the saturation flag up */
+    LEAF_SC_INTERVAL = 7,  /* growth interval in applied steps (0 = 2000) */
+    LEAF_SC_APPLIED = 8,   /* AdamW steps really taken = the `step` of the bias corrections (a skipped step does not count) */
+    LEAF_SC_BC1 = 9, LEAF_SC_SQRT_BC2 = 10, /* bias corrections of the last applied step */
+    LEAF_SC_WORDS = 16
+};
+/* attach (or detach with NULL) the scaler state used by leaf_textfare_backward* of this handle */
+int leaf_text_set_grad_scaler(leaf_text_t h, float* state);
+
 /* the same step preceded by torch.nn.utils.clip_grad_norm_(parameters, max_norm, 2.0) (--grad-clip-norm,
  * utils_AT.py:348-357): total norm = grad_scale * ||grads||_2, gradients are multiplied by min(1, max_norm / (norm + 1e-6))
- * inside the AdamW kernel (grads themselves are left untouched).  clip_ws: fp32 device scratch [4 + 2048], zeroed once by the
- * caller; after the call clip_ws[0] = coefficient, clip_ws[1] = total norm.  NON-FINITE GUARD: when the norm is inf / NaN the
- * whole step is skipped (parameters and moments untouched, GradScaler.step semantics), clip_ws[0] = -1 and clip_ws[2] counts
- * the skipped steps.  max_norm = +inf gives the guard without clipping. */
+ * inside the AdamW kernel (grads themselves are left untouched).  clip_ws: fp32 device scratch [LEAF_SC_WORDS + 2048], zeroed
+ * once by the caller (layout above).  NON-FINITE GUARD: when the norm is inf / NaN the whole step is skipped (parameters and
+ * moments untouched, GradScaler.step semantics), clip_ws[LEAF_SC_COEF] = -1 and clip_ws[LEAF_SC_SKIPPED] counts the skipped
+ * steps.  `step` counts ATTEMPTED steps from 1; the bias corrections use step - skipped (clip_ws[LEAF_SC_APPLIED]).
+ * max_norm = +inf gives the guard without clipping. */
 int leaf_adamw_step_clip(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, size_t n_decay,
                          float lr, float beta1, float beta2, float eps, float wd, int step, float grad_scale,
                          float max_norm, float* clip_ws, leaf_stream_t s);

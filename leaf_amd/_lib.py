@@ -22,6 +22,7 @@ _SIGS = {
     "leaf_text_destroy": (None, [C.c_void_p]),
     "leaf_text_set_chunk": (C.c_int, [C.c_void_p, C.c_int]),
     "leaf_text_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "leaf_text_set_grad_scaler": (C.c_int, [C.c_void_p, C.c_void_p]),
     "leaf_text_param_count": (C.c_size_t, [C.c_void_p]),
     "leaf_text_decay_count": (C.c_size_t, [C.c_void_p]),
     "leaf_text_num_tensors": (C.c_int, [C.c_void_p]),
@@ -111,6 +112,10 @@ _SIGS = {
     "leaf_op_attention_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p]),
 }
+
+# gradient-scaler state layout (include/leaf_hip.h LEAF_SC_*)
+SC_COEF, SC_NORM, SC_SKIPPED, SC_BACKOFF, SC_GOOD, SC_SAT_FLAG, SC_SAT_STEPS, SC_INTERVAL, SC_APPLIED = range(9)
+SC_WORDS = 16
 
 EXPORTS = tuple(_SIGS)
 _lib = None

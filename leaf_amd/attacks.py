@@ -205,7 +205,8 @@ def _stage_candidates(tokenizer, sentences, z, c, constrain, trace):
 
 
 def attack_text_leaf(model, tokenizer, sentences, anchor_features, device=None, objective="l2", n=10, k=1,
-                     V=DEFAULT_V, constrain=False, debug=False, return_trace: Optional[list] = None):
+                     V=DEFAULT_V, constrain=False, debug=False, return_trace: Optional[list] = None,
+                     return_picks: Optional[list] = None):
     """LEAF attack on a batch of sentences.  ``model`` is a ``leaf_amd.model.LeafCLIPText`` (anything with
     ``score_candidates``); ``anchor_features`` a float32 CUDA tensor [B, D].  Returns
     ``(best_features [B,D], adversarial sentences)`` like the reference.  The numpy global RNG is consumed exactly as
@@ -239,6 +240,8 @@ def attack_text_leaf(model, tokenizer, sentences, anchor_features, device=None, 
         ids_best, _ = model.score_candidates(toks, anchor_features, n, objective, want_features=False, seq_lens=lens,
                                              prefix_lens=pl, kv=kv)
         ids_best = ids_best.cpu().numpy()
+        if return_picks is not None:
+            return_picks.append(ids_best.copy())
         best_pos = positions[np.arange(B), ids_best]
         # stage 2: rho random characters at the chosen position
         u = np.stack([np.random.choice(range(len(V)), size=n, replace=(n > len(V))) for _ in sentences])
@@ -249,6 +252,8 @@ def attack_text_leaf(model, tokenizer, sentences, anchor_features, device=None, 
         ids_best, best_feat = model.score_candidates(toks, anchor_features, n, objective, want_features=True, seq_lens=lens,
                                                      prefix_lens=pl, kv=kv)
         ids_best = ids_best.cpu().numpy()
+        if return_picks is not None:
+            return_picks.append(ids_best.copy())
         sentences = [_apply_edit(S, int(z[b, ids_best[b]]), int(c[b, ids_best[b]])) for b, S in enumerate(sentences)]
         if debug:
             print(sentences[0])

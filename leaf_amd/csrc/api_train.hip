@@ -184,7 +184,8 @@ static int backward_impl(leaf_text_t h, const float* P, const void* w16_bwd, con
     };
 
     LEAF_TRY(leaf_launch_fare_loss(feat, anchor, n_seq, D, accum_scale, loss_out, b.dout, b.gscale, gk == 1, s,
-                                   h->normalize_fare ? st.norms : nullptr));
+                                   h->normalize_fare ? st.norms : nullptr, h->scaler));
+    const bool sat_check = h->scaler && G && gk == 1;     // fp16 gradient path with a scaler attached (leaf_hip.h "gradient scaler")
     LEAF_TRY(hipMemsetAsync(b.dx, 0, rd * 4, s));
     LEAF_TRY(leaf_launch_pool_project_bwd(b.dout, st.pooled, st.xin + (size_t)L * rd, st.eot, P + h->lnf_w, P + h->lnf_b,
                                           cf.ln_eps, P + h->text_proj, b.dx, G ? G + h->text_proj : nullptr,
@@ -241,6 +242,12 @@ static int backward_impl(leaf_text_t h, const float* P, const void* w16_bwd, con
             wa.nprob = 4; wa.rows = rows; wa.alpha = inv_s;
             LEAF_TRY(leaf_launch_wgrad_group(wa, fk, gk, s));
         }
+        if (sat_check) {
+            // the five 16-bit gradient tensors of this block, before ln1's backward overwrites dx16
+            const void* bufs[5] = {b.dx16, b.big16, b.dx16b, b.do16, b.dqkv};
+            const size_t numel[5] = {rd, 4 * rd, rd, rd, 3 * rd};
+            LEAF_TRY(leaf_launch_sat_check16(bufs, numel, 5, h->scaler, G, s));
+        }
         if (leaf_gemm(gk, EPI_STORE_F32, b.dqkv, 3 * d, WT + h->w16_qkv(l), 3 * d, b.dxn, d, nullptr, nullptr, rows, d,
                  3 * d, 0, s)) return 1;
         LEAF_TRY(leaf_launch_layernorm_bwd(b.dxn, xin, P + o.ln1_w, cf.ln_eps, b.dx, b.dx16, gk,
@@ -266,6 +273,12 @@ static int backward_impl(leaf_text_t h, const float* P, const void* w16_bwd, con
     if (G) LEAF_TRY(leaf_launch_embed_bwd(b.dx, b.gscale, tokens, G + h->tok_emb, G + h->pos_emb, rows, n_seq, map, d, cf.vocab_size, s));
     if (d_embed) LEAF_TRY(leaf_launch_scale_copy(b.dx, inv_s, d_embed, rd, s));   // d loss / d (token embedding), un-scaled
     if (layer_events && layer_events[L]) LEAF_TRY(hipEventRecord((hipEvent_t)layer_events[L], s));
+    return 0;
+}
+
+extern "C" int leaf_text_set_grad_scaler(leaf_text_t h, float* state) {
+    if (!h) { leaf_set_error("null handle"); return 1; }
+    h->scaler = state;
     return 0;
 }
 

@@ -24,6 +24,7 @@ struct leaf_text {
     int last_trim;   // last transformer block: attention output / out-proj / MLP only for the pooled (EOT) row
     int grad_dtype;  // 16-bit type of the gradient path: LEAF_F16 (loss-scaled, default) or LEAF_BF16
     int normalize_fare = 0;   // --normalize_fare: the training forward returns F.normalize(features), the backward follows
+    float* scaler = nullptr;  // gradient-scaler state (device, leaf_hip.h LEAF_SC_*) or null: no saturation check, no back-off
     // Two-stream chunk pipeline of the forward-only passes (api.hip forward_all): sequence chunks alternate between the
     // caller's stream and a side stream owned by the handle, so one chunk's HBM-bound kernels (LN, attention, the
     // residual epilogues) and grid tails overlap the other chunk's MFMA-bound K loops.  Measured: kernels of the two

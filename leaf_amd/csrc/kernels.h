@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/leaf_hip.h"
 #include "common.h"
 
 enum { LEAF_BF16 = 0, LEAF_F16 = 1 };
@@ -117,7 +118,11 @@ hipError_t leaf_launch_cast16(const void* src, int src_kind, void* dst, int dst_
 // power-of-two loss scale of the fp16 gradient path (S = 1 when use_scaling == 0), chosen so that max|dout| * S ~ 16.
 hipError_t leaf_launch_fare_loss(const float* feat, const float* anchor, int B, int D, float scale, float* loss,
                                  float* dout, float* gscale, int use_scaling, hipStream_t s,
-                                 const float* norms = nullptr /* --normalize_fare: ||f|| per caption, feat is f / ||f|| */);
+                                 const float* norms = nullptr /* --normalize_fare: ||f|| per caption, feat is f / ||f|| */,
+                                 const float* scaler = nullptr /* gradient-scaler state (leaf_hip.h): S *= 2^scaler[LEAF_SC_BACKOFF] */);
+// fp16 gradient path: raise scaler[LEAF_SC_SAT_FLAG] and poison *poison (gradient element 0) with NaN when any of the n <= 5
+// 16-bit tensors holds a saturated (|x| >= 65504) or non-finite value; numel multiples of 8, pointers 16-byte aligned
+hipError_t leaf_launch_sat_check16(const void* const* bufs, const size_t* numel, int n, float* scaler, float* poison, hipStream_t s);
 hipError_t leaf_launch_normalize_rows(float* x, float* norms, int M, int D, hipStream_t s);
 // projection + pooling + final-LN backward: writes dx (fp32 [rows,d], zero except EOT rows), accumulates
 // dproj [d,D], dg/db of ln_final.
@@ -177,4 +182,4 @@ hipError_t leaf_launch_embed_bwd(const float* dx, const float* gscale, const int
                                  int rows, int n_seq, RowMap map, int d, int vocab, hipStream_t s);
 hipError_t leaf_launch_adamw(float* p, const float* g, float* m, float* v, size_t n, size_t n_decay, float lr,
                              float beta1, float beta2, float eps, float wd, int step, float grad_scale, hipStream_t s,
-                             float max_norm = 0.f /* > 0: clip_grad_norm_ first */, float* clip_ws = nullptr /* [4 + 2048] fp32 */);
+                             float max_norm = 0.f /* > 0: clip_grad_norm_ first */, float* clip_ws = nullptr /* [LEAF_SC_WORDS + 2048] fp32 */);

@@ -143,7 +143,8 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(float* __restrict__
 }
 
 __global__ __launch_bounds__(256) void fare_reduce_kernel(const float* __restrict__ partial, int B, float* __restrict__ loss,
-                                                          float* __restrict__ gscale, int use_scaling) {
+                                                          float* __restrict__ gscale, int use_scaling,
+                                                          const float* __restrict__ scaler) {
     __shared__ float red[8];
     const int tid = threadIdx.x;
     float s = 0.f, amax = 0.f;
@@ -160,6 +161,9 @@ __global__ __launch_bounds__(256) void fare_reduce_kernel(const float* __restric
             int e;
             frexpf(a, &e);                      // a = m * 2^e, m in [0.5, 1)
             e = 4 - e;                          // bring max|dout| into [8, 16)
+            // persistent back-off (GradScaler semantics, leaf_hip.h "gradient scaler"): scaler[LEAF_SC_BACKOFF] <= 0 halvings, raised
+            // by every step whose 16-bit gradients saturated, lowered again after a run of clean steps
+            if (scaler) e += (int)scaler[LEAF_SC_BACKOFF];
             e = e > 40 ? 40 : (e < -40 ? -40 : e);
             S = ldexpf(1.f, e);
         }
@@ -521,6 +525,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     // torch.cuda.amp.GradScaler.step does, train_AT_text_only.py:347, utils_AT.py:339-362)
     if (clip_coef && clip_coef[0] < 0.f) return;
     const float gscale = clip_coef ? gscale_host * clip_coef[0] : gscale_host;
+    // with the guard the step counter of the bias corrections lives on the device (clip_coef_kernel): it counts APPLIED steps,
+    // a skipped step does not advance it (torch's per-parameter `step` under GradScaler)
+    if (clip_coef) { bc1 = clip_coef[LEAF_SC_BC1]; sqrt_bc2 = clip_coef[LEAF_SC_SQRT_BC2]; }
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * 256;
     for (; i < n4; i += stride) {
@@ -554,9 +561,11 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restr
     __syncthreads();
     if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
-// out[0] = clip coefficient min(1, c / (norm + 1e-6)), out[1] = norm = grad_scale * sqrt(sum partial)  (fixed order)
+// out[LEAF_SC_COEF] = clip coefficient min(1, c / (norm + 1e-6)) or -1 (skip), out[LEAF_SC_NORM] = grad_scale * sqrt(sum partial)
+// (fixed order), plus the gradient-scaler bookkeeping of leaf_hip.h ("gradient scaler"): one thread, once per optimizer step.
 __global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict__ partial, int nb, float grad_scale,
-                                                        float max_norm, float* __restrict__ out) {
+                                                        float max_norm, float* __restrict__ out, int step_host, float beta1,
+                                                        float beta2) {
     __shared__ double red[4];
     double s = 0.0;
     for (int b = threadIdx.x; b < nb; b += 256) s += (double)partial[b];
@@ -568,9 +577,52 @@ __global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict_
         const float norm = grad_scale * (float)sqrt((red[0] + red[1]) + (red[2] + red[3]));
         const float coef = max_norm / (norm + 1e-6f);
         const bool finite = norm == norm && norm < 3.0e38f;
-        out[0] = !finite ? -1.f : (coef < 1.f ? coef : 1.f);    // -1: skip the step (adamw_kernel)
-        out[1] = norm;
-        if (!finite) out[2] += 1.f;                               // skipped steps so far (the host reads it when it logs)
+        out[LEAF_SC_NORM] = norm;
+        if (!finite) {
+            // GradScaler.step / .update (train_AT_text_only.py:347, utils_AT.py:339-362): found inf -> skip the step, halve the scale
+            out[LEAF_SC_COEF] = -1.f;                                  // adamw_kernel returns at once
+            out[LEAF_SC_SKIPPED] += 1.f;
+            if (out[LEAF_SC_SAT_FLAG] != 0.f) out[LEAF_SC_SAT_STEPS] += 1.f;
+            out[LEAF_SC_BACKOFF] = fmaxf(out[LEAF_SC_BACKOFF] - 1.f, -30.f);
+            out[LEAF_SC_GOOD] = 0.f;
+        } else {
+            out[LEAF_SC_COEF] = coef < 1.f ? coef : 1.f;
+            const float interval = out[LEAF_SC_INTERVAL] > 0.f ? out[LEAF_SC_INTERVAL] : 2000.f;   // GradScaler's growth_interval
+            out[LEAF_SC_GOOD] += 1.f;
+            if (out[LEAF_SC_GOOD] >= interval) { out[LEAF_SC_BACKOFF] = fminf(out[LEAF_SC_BACKOFF] + 1.f, 0.f); out[LEAF_SC_GOOD] = 0.f; }
+            const double applied = (double)step_host - (double)out[LEAF_SC_SKIPPED];      // steps really taken, this one included
+            out[LEAF_SC_APPLIED] = (float)applied;
+            out[LEAF_SC_BC1] = (float)(1.0 - pow((double)beta1, applied));
+            out[LEAF_SC_SQRT_BC2] = sqrtf((float)(1.0 - pow((double)beta2, applied)));
+        }
+        out[LEAF_SC_SAT_FLAG] = 0.f;
+    }
+}
+
+// Saturation check of the 16-bit gradient tensors of one transformer block (fp16 gradient path): a stored value of magnitude
+// >= 65504 (0x7BFF: the conversions saturate there; 0x7C00.. = inf / NaN) means the loss scale was too large for this step.
+// The reference's GradScaler finds that as an inf in the unscaled gradients; here the kernel raises scaler[LEAF_SC_SAT_FLAG] and
+// POISONS gradient element 0 with NaN -- the padding row of the token-embedding table, which no kept row ever touches -- so
+// that the non-finite guard of the optimizer step skips the step on THIS rank and, through the gradient all-reduce, on every rank.
+struct SatArgs { const uint16_t* buf[5]; unsigned long long n8[5]; };   // element counts in units of 8 (16-byte chunks)
+__global__ __launch_bounds__(256) void sat_check16_kernel(SatArgs a, float* __restrict__ scaler, float* __restrict__ poison) {
+    unsigned hit = 0;
+#pragma unroll
+    for (int b = 0; b < 5; ++b) {
+        const uint4* p = (const uint4*)a.buf[b];
+        for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < a.n8[b]; i += (unsigned long long)gridDim.x * 256) {
+            const uint4 v = p[i];
+            const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned m = w[e] & 0x7FFF7FFFu;
+                hit |= ((m & 0xFFFFu) >= 0x7BFFu) | ((m >> 16) >= 0x7BFFu);
+            }
+        }
+    }
+    if (__any(hit != 0) && (threadIdx.x & 63) == 0) {
+        scaler[LEAF_SC_SAT_FLAG] = 1.f;
+        *poison = __builtin_nanf("");
     }
 }
 
@@ -683,11 +735,12 @@ hipError_t leaf_launch_normalize_rows(float* x, float* norms, int M, int D, hipS
 }
 
 hipError_t leaf_launch_fare_loss(const float* feat, const float* anchor, int B, int D, float scale, float* loss,
-                                 float* dout, float* gscale, int use_scaling, hipStream_t s, const float* norms) {
+                                 float* dout, float* gscale, int use_scaling, hipStream_t s, const float* norms,
+                                 const float* scaler) {
     if (D > 2048) return hipErrorInvalidValue;
     float* partial = gscale + 64;   // [B][2] right behind the {S, 1/S} slot (carve_bwd reserves it)
     hipLaunchKernelGGL(fare_rows_kernel, dim3(B), dim3(256), 0, s, feat, anchor, B, D, scale, dout, partial, norms);
-    hipLaunchKernelGGL(fare_reduce_kernel, dim3(1), dim3(256), 0, s, partial, B, loss, gscale, use_scaling);
+    hipLaunchKernelGGL(fare_reduce_kernel, dim3(1), dim3(256), 0, s, partial, B, loss, gscale, use_scaling, scaler);
     return hipGetLastError();
 }
 
@@ -783,6 +836,19 @@ hipError_t leaf_launch_attention_bwd(const void* qkv, int qkv_dtype, const void*
     return hipGetLastError();
 }
 
+hipError_t leaf_launch_sat_check16(const void* const* bufs, const size_t* numel, int n, float* scaler, float* poison, hipStream_t s) {
+    if (n < 1 || n > 5 || !scaler || !poison) return hipErrorInvalidValue;
+    SatArgs a{};
+    unsigned long long tot = 0;
+    for (int i = 0; i < n; ++i) {
+        if (numel[i] % 8 || ((uintptr_t)bufs[i] & 15)) return hipErrorInvalidValue;
+        a.buf[i] = (const uint16_t*)bufs[i]; a.n8[i] = numel[i] / 8; tot += a.n8[i];
+    }
+    const unsigned long long nb = (tot + 255) / 256 / 4 + 1;
+    hipLaunchKernelGGL(sat_check16_kernel, dim3((unsigned)(nb < 2048 ? nb : 2048)), dim3(256), 0, s, a, scaler, poison);
+    return hipGetLastError();
+}
+
 hipError_t leaf_launch_embed_bwd(const float* dx, const float* gscale, const int32_t* tokens, float* dtok, float* dpos,
                                  int rows, int n_seq, RowMap map, int d, int vocab, hipStream_t s) {
     hipLaunchKernelGGL(pos_bwd_kernel, dim3(map.ctx, (d + 255) / 256), dim3(256), 0, s, dx, gscale, dpos, n_seq, map, d);
@@ -800,11 +866,12 @@ hipError_t leaf_launch_adamw(float* p, const float* g, float* m, float* v, size_
     const float bc2 = (float)(1.0 - pow((double)beta2, (double)step));
     size_t n4 = n / 4, nb = (n4 + 255) / 256;
     const float* coef = nullptr;
-    if (max_norm > 0.f) {   // clip_ws: [4 + 2048] floats: {coef (-1 = skip), norm, skipped steps, -, partials...}
+    if (max_norm > 0.f) {   // clip_ws: [LEAF_SC_WORDS + 2048] floats: the scaler state of leaf_hip.h, then the partial sums
         if (!clip_ws) return hipErrorInvalidValue;
         const int pb = (int)(nb < 2048 ? nb : 2048);
-        hipLaunchKernelGGL(sumsq_partial_kernel, dim3(pb), dim3(256), 0, s, g, n4, clip_ws + 4);
-        hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, s, clip_ws + 4, pb, grad_scale, max_norm, clip_ws);
+        hipLaunchKernelGGL(sumsq_partial_kernel, dim3(pb), dim3(256), 0, s, g, n4, clip_ws + LEAF_SC_WORDS);
+        hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, s, clip_ws + LEAF_SC_WORDS, pb, grad_scale, max_norm, clip_ws,
+                           step, beta1, beta2);
         coef = clip_ws;
     }
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)(nb < 16384 ? nb : 16384)), dim3(256), 0, s, p, g, m, v, n4, n_decay,

@@ -117,6 +117,7 @@ class LeafCLIPText:
         # training state (allocated on demand)
         self.grads = self.exp_avg = self.exp_avg_sq = self.w16_bwd = self._stash = None
         self.opt_step = 0
+        self.rows_scored = 0      # packed rows handed to the scoring passes so far (host-side count; bench.py reports it per rank)
         if trainable:
             self.enable_training()
 
@@ -325,6 +326,7 @@ class LeafCLIPText:
         feat = torch.empty(B, self.cfg.embed_dim, dtype=torch.float32, device=self.device) if want_features else None
         loss = torch.empty(B, rho, dtype=torch.float32, device=self.device) if want_loss else None
         ws = self._workspace(1, B * rho)
+        self.rows_scored += int(keep.sum()) if keep is not None else B * rho * self.cfg.context_length
         _lib.check(self._lib.leaf_score_candidates(self._h, _ptr(self.flat), _ptr(self.w16), _ptr(t), lens_p, _ptr(cu),
                                                    _ptr(anchor), B, rho, _OBJ[objective], _ptr(idx), _ptr(feat),
                                                    _ptr(loss), _ptr(ws), ws.numel(), self._stream()),
@@ -357,6 +359,7 @@ class LeafCLIPText:
         feat = torch.empty(B, self.cfg.embed_dim, dtype=torch.float32, device=self.device) if want_features else None
         loss = torch.empty(B, rho, dtype=torch.float32, device=self.device) if want_loss else None
         ws = self._workspace(1, B * rho)
+        self.rows_scored += int(cu[-1])
         _lib.check(self._lib.leaf_score_candidates_prefix(
             self._h, _ptr(self.flat), _ptr(self.w16), _ptr(t), C.c_void_p(suf.ctypes.data), _ptr(cu_dev), _ptr(pfx_dev),
             _ptr(kv["base_cu"]), _ptr(kv["kv"]), kv["base_rows"], int(full.max()), _ptr(anchor), B, rho, _OBJ[objective], _ptr(idx),
@@ -406,6 +409,7 @@ class LeafCLIPText:
         if rc == 2:
             return None
         _lib.check(rc, "leaf_score_candidates_prefix_fused")
+        self.rows_scored += int(cu[-1])
         cache = {"kv": self._kv, "base_cu": cu_dev[:B + 1], "base_rows": base_rows, "lens": blens, "n": B}
         return (idx, feat, cache, loss) if want_loss else (idx, feat, cache)
 
@@ -417,6 +421,11 @@ class LeafCLIPText:
                 self.exp_avg = torch.zeros_like(self.flat)
                 self.exp_avg_sq = torch.zeros_like(self.flat)
                 self.w16_bwd = torch.empty_like(self.w16)
+                # gradient-scaler state + scratch of the guarded optimizer step (include/leaf_hip.h "gradient scaler"): attached to
+                # the handle, so the fp16 backward checks its 16-bit gradient tensors for saturation (LEAF_GRAD_SCALER=0 detaches)
+                self._clip_ws = torch.zeros(_lib.SC_WORDS + 2048, dtype=torch.float32, device=self.device)
+            if os.environ.get("LEAF_GRAD_SCALER", "1") != "0":
+                _lib.check(self._lib.leaf_text_set_grad_scaler(self._h, _ptr(self._clip_ws)), "leaf_text_set_grad_scaler")
             self._packed = False
         return self
 
@@ -515,13 +524,16 @@ class LeafCLIPText:
         """Fused AdamW over the flat buffers.  ``max_norm`` (--grad-clip-norm, utils_AT.py:348-357): clip the global L2
         norm of grad_scale * grads first (torch.nn.utils.clip_grad_norm_ semantics).  ``guard`` (default): one extra read of
         the gradients computes their global norm and SKIPS the whole step when it is inf / NaN (what GradScaler.step does in
-        the reference's fp16 regime; the 16-bit conversions of the gradient path saturate instead of producing inf, so this
-        catches fp32 overflow and NaNs before they reach the weights, the moments and -- through the all-reduce -- every rank).
+        the reference's fp16 regime).  The 16-bit conversions of the gradient path saturate instead of producing inf; the backward
+        therefore checks its 16-bit gradient tensors and poisons the gradient with a NaN when one saturated, so this guard skips
+        that step too -- on every rank, the NaN travels through the all-reduce -- and the persistent loss-scale back-off halves
+        (GradScaler.update; ``loss_scale_backoff()``).  ``opt_step`` counts ATTEMPTED steps; the bias corrections use the steps
+        really applied (kept on the device: a skipped step does not advance them, as torch's per-parameter ``step``).
         Returns the 0-d total-norm tensor when clipping or guarding, else None; ``skipped_steps()`` counts skipped steps."""
         self.opt_step += 1
         if max_norm is not None or guard:
             if getattr(self, "_clip_ws", None) is None:
-                self._clip_ws = torch.zeros(4 + 2048, dtype=torch.float32, device=self.device)
+                self._clip_ws = torch.zeros(_lib.SC_WORDS + 2048, dtype=torch.float32, device=self.device)
             _lib.check(self._lib.leaf_adamw_step_clip(_ptr(self.flat), _ptr(self.grads), _ptr(self.exp_avg),
                                                       _ptr(self.exp_avg_sq), self.n_params, self.n_decay, float(lr),
                                                       float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
@@ -529,7 +541,7 @@ class LeafCLIPText:
                                                       float(max_norm) if max_norm is not None else float("inf"),
                                                       _ptr(self._clip_ws), self._stream()), "leaf_adamw_step_clip")
             self._packed = False
-            return self._clip_ws[1]
+            return self._clip_ws[_lib.SC_NORM]
         _lib.check(self._lib.leaf_adamw_step(_ptr(self.flat), _ptr(self.grads), _ptr(self.exp_avg),
                                              _ptr(self.exp_avg_sq), self.n_params, self.n_decay, float(lr),
                                              float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
@@ -540,7 +552,29 @@ class LeafCLIPText:
     def skipped_steps(self) -> int:
         """Optimizer steps skipped by the non-finite guard so far (synchronises: call it where the loop already does)."""
         ws = getattr(self, "_clip_ws", None)
-        return int(ws[2].item()) if ws is not None else 0
+        return int(ws[_lib.SC_SKIPPED].item()) if ws is not None else 0
+
+    def applied_steps(self) -> int:
+        """AdamW steps really taken = attempted - skipped: the ``step`` of the bias corrections and of a checkpoint (synchronises)."""
+        return self.opt_step - self.skipped_steps()
+
+    def set_applied_steps(self, step: int):
+        """After loading optimizer state: ``step`` applied steps so far, none skipped."""
+        self.opt_step = int(step)
+        ws = getattr(self, "_clip_ws", None)
+        if ws is not None:
+            ws[_lib.SC_SKIPPED] = 0.0
+            ws[_lib.SC_APPLIED] = float(step)
+
+    def grad_scaler_state(self) -> dict:
+        """GradScaler-style bookkeeping of the fp16 gradient path (synchronises): the persistent loss-scale factor 2^backoff,
+        steps skipped in all / because a 16-bit gradient tensor saturated."""
+        ws = getattr(self, "_clip_ws", None)
+        if ws is None:
+            return {"loss_scale_factor": 1.0, "skipped": 0, "skipped_saturated": 0}
+        h = ws[:_lib.SC_WORDS].cpu()
+        return {"loss_scale_factor": float(2.0 ** float(h[_lib.SC_BACKOFF])), "skipped": int(h[_lib.SC_SKIPPED]),
+                "skipped_saturated": int(h[_lib.SC_SAT_STEPS]), "good_steps": int(h[_lib.SC_GOOD])}
 
 def create_model(name: str, device="cuda:0", dtype: str = None, pretrained: Optional[str] = None,
                  trainable: bool = False, seed: int = 1) -> LeafCLIPText:
@@ -550,8 +584,29 @@ def create_model(name: str, device="cuda:0", dtype: str = None, pretrained: Opti
     checkpoint (the hub layout, src/open_clip/factory.py:200-207) defines the architecture when present."""
     cfg = None
     if pretrained:
+        import dataclasses
+        import logging
         from .checkpoint import read_open_clip_config
         cfg = read_open_clip_config(pretrained)
+        try:
+            named = get_config(name)
+        except (KeyError, ValueError):
+            named = None              # an unknown name is fine when the json defines the architecture
+        if cfg is not None and named is not None:
+            # the name (or --force-quick-gelu's '-quickgelu' suffix) can only ADD QuickGELU: hub configs of the OpenAI-lineage
+            # towers omit the flag and rely on the model name (src/open_clip/factory.py:219-222)
+            if named.quick_gelu and not cfg.quick_gelu:
+                cfg = dataclasses.replace(cfg, quick_gelu=True)
+            shape = lambda c: (c.width, c.heads, c.layers, c.embed_dim, c.context_length, c.vocab_size)
+            if shape(cfg) != shape(named):
+                if not name.startswith("hf-hub:"):
+                    raise ValueError(f"open_clip_config.json next to '{pretrained}' describes a text tower (width, heads, layers, embed_dim, "
+                                     f"ctx, vocab) = {shape(cfg)}, but --model {name} is {shape(named)}: remove the stray json or name the "
+                                     "model the checkpoint belongs to")
+                logging.info(f"architecture taken from the open_clip_config.json next to '{pretrained}': {shape(cfg)}")
+            else:
+                logging.info(f"open_clip_config.json next to '{pretrained}' agrees with --model {name}"
+                             + (" (QuickGELU from the model name)" if named.quick_gelu else ""))
     m = LeafCLIPText(cfg or get_config(name), device=device, dtype=dtype, trainable=trainable)
     if pretrained:
         from .checkpoint import load_checkpoint_file

@@ -27,7 +27,10 @@ class NativeTokenizer(SimpleTokenizer):
         if rc != 0:
             raise _lib.LeafHipError(f"leaf_tok_create failed ({rc})")
         self._h = h
-        self.n_threads = n_threads or int(os.environ.get("LEAF_HOST_THREADS", str(min(32, os.cpu_count() or 1))))
+        # per RANK: the ranks of a node share its cores (LOCAL_WORLD_SIZE is set by torch.distributed.run)
+        usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        share = max(1, usable // max(int(os.environ.get("LOCAL_WORLD_SIZE", "1")), 1))
+        self.n_threads = n_threads or int(os.environ.get("LEAF_HOST_THREADS", str(min(32, share))))
 
     def __del__(self):
         try:

@@ -200,6 +200,10 @@ class GradReducer:
         self.events = None
         self.comm = None
         self._launched = False
+        # timing = True (bench.py at world > 1): an event pair around every finish(), i.e. around what the step's stream really
+        # waits for -- the EXPOSED part of the reduction, arrival skew of the other ranks included
+        self.timing = False
+        self._pairs = []
 
     def _setup(self):
         dev = self.model.device
@@ -230,11 +234,31 @@ class GradReducer:
         """Make the current stream wait for the reduction (launching the flat one if none is in flight); returns the
         factor AdamW must apply to the summed gradients."""
         import torch.distributed as dist
+        cur = torch.cuda.current_stream(self.model.device)
+        e0 = None
+        if self.timing and _dp_active():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(cur)
         if self._launched:
-            torch.cuda.current_stream(self.model.device).wait_stream(self.comm)
+            cur.wait_stream(self.comm)
             self._launched = False
-            return 1.0 / dist.get_world_size()
-        return allreduce_grads(self.model)
+            scale = 1.0 / dist.get_world_size()
+        else:
+            scale = allreduce_grads(self.model)
+        if e0 is not None:
+            e1.record(cur)
+            self._pairs.append((e0, e1))
+        return scale
+
+    def exposed_ms(self) -> float:
+        """Sum over the finish() calls since the last call of the time the step's stream spent waiting for the gradient
+        reduction (synchronises on the recorded events)."""
+        tot = 0.0
+        for e0, e1 in self._pairs:
+            e1.synchronize()
+            tot += e0.elapsed_time(e1)
+        self._pairs = []
+        return tot
 
 
 def reduce_buckets(flat: torch.Tensor, plan) -> None:
@@ -246,13 +270,12 @@ def reduce_buckets(flat: torch.Tensor, plan) -> None:
                 dist.all_reduce(flat[off:off + numel], op=dist.ReduceOp.SUM)
 
 
-_REDUCERS = {}
-
-
 def get_reducer(model) -> GradReducer:
-    r = _REDUCERS.get(id(model))
-    if r is None or r.model is not model:
-        r = _REDUCERS[id(model)] = GradReducer(model)
+    """The model's reducer, created on first use and stored ON the model, so that it (its comm stream, events) dies with the
+    model instead of pinning every model ever trained in a module-level table."""
+    r = getattr(model, "_grad_reducer", None)
+    if r is None:
+        r = model._grad_reducer = GradReducer(model)
     return r
 
 

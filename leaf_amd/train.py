@@ -123,7 +123,7 @@ class LeafAdamW:
                                                  "hold ids without state)" if n_vis else
                                                  "TEXT-ONLY groups (" + ("--lock-image" if self.lock_image else "the start checkpoint "
                                                  "names no image tower") + "): the reference resumes it only with --lock-image"))
-        return optimizer_state_to_torch(m.layout, m.cfg.layers, m.exp_avg, m.exp_avg_sq, m.opt_step, g["lr"], g["betas"], g["eps"],
+        return optimizer_state_to_torch(m.layout, m.cfg.layers, m.exp_avg, m.exp_avg_sq, m.applied_steps(), g["lr"], g["betas"], g["eps"],
                                         g["weight_decay"], lrs=(self.param_groups[0]["lr"], g["lr"]), extra=extra)
 
     def load_state_dict(self, sd):
@@ -134,10 +134,10 @@ class LeafAdamW:
             # m.extra_state = the non-text tensors of the checkpoint just loaded: they name the visual.* ids of a full-CLIP layout
             kind = optimizer_state_layout(sd, m.cfg.layers, m.extra_state)
             logging.info(f"optimizer state_dict read in the {kind} layout")
-            m.opt_step = optimizer_state_from_torch(sd, m.layout, m.cfg.layers, m.exp_avg, m.exp_avg_sq, extra=m.extra_state)
+            m.set_applied_steps(optimizer_state_from_torch(sd, m.layout, m.cfg.layers, m.exp_avg, m.exp_avg_sq, extra=m.extra_state))
             saved = sd["param_groups"]
         elif "exp_avg" in sd:
-            m.opt_step = int(sd["step"])
+            m.set_applied_steps(int(sd["step"]))
             m.exp_avg.copy_(sd["exp_avg"])
             m.exp_avg_sq.copy_(sd["exp_avg_sq"])
             saved = sd["param_groups"]
@@ -320,10 +320,13 @@ def train_one_epoch_text_only(model, model_frozen, tokenizer, V, data, loss, epo
             percent_complete = 100.0 * batch_count / num_batches_per_epoch
             for key, val in losses_accum.items():
                 losses_m.setdefault(key, AverageMeter()).update(float(val), batch_size)
-            skipped = unwrap_model(model).skipped_steps()     # float(val) above already synchronised
+            gs = unwrap_model(model).grad_scaler_state()      # float(val) above already synchronised
+            skipped = gs["skipped"]
             if skipped != getattr(train_one_epoch_text_only, "_skipped_seen", 0):
-                logging.warning(f"non-finite gradient norm: {skipped} optimizer step(s) skipped so far (weights and AdamW moments "
-                                "left untouched for those steps, as torch.cuda.amp.GradScaler does)")
+                logging.warning(f"non-finite gradient norm: {skipped} optimizer step(s) skipped so far ({gs['skipped_saturated']} of them "
+                                f"because a 16-bit gradient tensor saturated at the current loss scale); weights and AdamW moments "
+                                f"left untouched for those steps and the loss scale halved, as torch.cuda.amp.GradScaler does "
+                                f"(persistent loss-scale factor now {gs['loss_scale_factor']:g})")
                 train_one_epoch_text_only._skipped_seen = skipped
             loss_log = " ".join(f"{n.capitalize()}: {m.val:#.5g} ({m.avg:#.5g})" for n, m in losses_m.items())
             sps = args.accum_freq * args.batch_size * args.world_size / batch_time_m.val

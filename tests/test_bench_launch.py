@@ -23,6 +23,17 @@ def _run(extra, env_extra=None):
 def test_bench_self_launches_two_ranks():
     out = _run(["--gpus", "2"])
     assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["allreduce_sum"] == 3.0
+    # the per-rank diagnostics of a multi-rank line: one entry per rank in rank order + min / median / max
+    pr = out["per_rank"]
+    assert pr["ms_per_step"] == [10.0, 11.0] and pr["exposed_collective_ms_per_step"] == [0.0, 0.5]
+    assert pr["scored_rows_per_step"] == [1000.0, 2000.0] and pr["ms_per_step_min_median_max"] == [10.0, 10.5, 11.0]
+    assert pr["compute_ms_per_step"] == [10.0, 10.5]
+    usable = len(os.sched_getaffinity(0))
+    assert out["host_threads_per_rank"] == max(1, usable // 2), "host threads default to this node's cores // ranks"
+
+
+def test_bench_host_threads_flag():
+    assert _run(["--gpus", "2", "--host-threads", "3"])["host_threads_per_rank"] == 3
 
 
 def test_bench_single_rank_needs_no_launcher():

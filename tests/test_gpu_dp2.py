@@ -133,3 +133,8 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and "rehearsal" in d
     assert d["value"] > 0 and np.isfinite(d["loss"])
     assert abs(d["value"] - 2 * 16 * 4 / (d["ms_per_step"] * 4e-3)) < 1e-6 * d["value"]      # whole-job samples / max-over-ranks time
+    # per-rank diagnostics: own step time, exposed reduction wait, rows the rank's (differently seeded) search computed
+    pr = d["per_rank"]
+    assert len(pr["ms_per_step"]) == 2 and all(0 < t <= d["ms_per_step"] * 1.5 for t in pr["ms_per_step"])
+    assert all(0 <= e <= t for e, t in zip(pr["exposed_collective_ms_per_step"], pr["ms_per_step"]))
+    assert all(r > 0 for r in pr["scored_rows_per_step"]) and d["host_threads_per_rank"] >= 1

@@ -136,24 +136,33 @@ def test_attack_text_replays_reference_trace(torch_mod, golden_dir, native):
     for key, t in trace.items():
         z = np.load(os.path.join(golden_dir, f"attack_{key}.npz"))
         anchor = torch_mod.from_numpy(z["anchor"]).cuda()
-        got_trace = []
+        got_trace, picks = [], []
         np.random.seed(t["seed"])
         feats, adv = attacks.attack_text_leaf(m, tok, list(t["sentences"]), anchor, objective="l2", n=t["rho"],
                                               k=t["k"], V=attacks.DEFAULT_V, constrain=t["constrain"],
-                                              return_trace=got_trace)
+                                              return_trace=got_trace, return_picks=picks)
         assert got_trace[0] == t["stage_candidates"][0], "stage-1 candidates differ: RNG / mutation drift"
         # later stages depend on fp-level arg-max decisions; with identical decisions they are identical
         if adv == t["adv"]:
             assert got_trace == t["stage_candidates"]
             assert rel_l2(feats.cpu().numpy(), z["feats"]) < TOL_GLOBAL
-        else:  # a near-tie flipped: the engine's pick must be as good as the reference's within fp16 noise
+        else:
+            # a near-tie flipped somewhere.  The margin rule, for any k: up to the first stage whose candidates differ from the
+            # reference's, both runs scored the SAME candidates, so the flip is the pick of the stage before it -- and there the
+            # engine's choice must be as good as the best candidate under the fp32 oracle, within fp16 noise, for every caption
+            # (after that stage the two runs edit different sentences and are no longer comparable)
             cfg = O.TextCfg(128, 2, 2, 64, quick_gelu=True)
             w = O.init_weights(cfg, seed=12)
-            f_ref = O.encode_text(w, cfg, tok.encode_batch(t["adv"]))
-            f_got = O.encode_text(w, cfg, tok.encode_batch(adv))
-            l_ref = ((f_ref - z["anchor"]) ** 2).sum(-1)
-            l_got = ((f_got - z["anchor"]) ** 2).sum(-1)
-            assert t["k"] > 1 or np.all(l_got >= l_ref * (1 - 5e-3)), (adv, t["adv"])
+            ref = t["stage_candidates"]
+            assert len(got_trace) == len(ref) == len(picks) == 2 * t["k"]
+            s_div = next((i for i in range(len(ref)) if got_trace[i] != ref[i]), len(ref))
+            assert s_div >= 1, "stage-1 candidates are drawn before any decision"
+            B, n = len(t["sentences"]), t["rho"]
+            cands = got_trace[s_div - 1]
+            f = O.encode_text(w, cfg, tok.encode_batch(cands)).reshape(B, n, -1)
+            loss_o = ((f - z["anchor"][:, None, :]) ** 2).sum(-1)
+            pick = loss_o[np.arange(B), picks[s_div - 1]]
+            assert np.all(pick >= loss_o.max(-1) * (1 - 5e-3)), (key, s_div, pick, loss_o.max(-1))
     attacks.set_dictionary(None)
 
 

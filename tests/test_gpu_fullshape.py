@@ -189,9 +189,8 @@ def test_vitl_k5_search_every_stage_rescored_by_oracle(torch_mod):
         if t % 2 == 1:
             cur = cand[np.arange(B), idx]
     assert np.array_equal(adv.cpu().numpy(), cur), "the search must return the last stage's winners"
-    # the l2 objective is maximised greedily: the winner's distance to the anchor never decreases over the k edits
-    d = [c[2][np.arange(B), c[1]] for c in calls[1::2]]
-    assert all((d[i + 1] >= d[i] * (1 - 1e-2)).all() for i in range(k - 1)) or True
+    # (no monotonicity claim over the k edits: an edit's candidates need not contain the unedited sentence, so the greedy
+    # winner's distance to the anchor may drop from one edit to the next -- in the reference as here)
 
 
 def test_vith_accum4_equals_one_4x_batch(torch_mod):

@@ -217,6 +217,58 @@ def test_non_finite_gradients_skip_the_step(torch_mod):
     assert m.adamw_step(lr=1e-3, guard=False) is None
 
 
+def test_fp16_gradient_saturation_skips_the_step_and_halves_the_loss_scale(torch_mod):
+    """GradScaler semantics for the fp16 gradient path (train_AT_text_only.py:347, utils_AT.py:339-362; VERDICT r2 missing-6): the
+    16-bit conversions saturate at 65504 instead of producing inf, so an overflow must be FOUND -- the backward checks its 16-bit
+    gradient tensors, poisons the gradient, the guarded step skips (weights, moments and the bias-correction step untouched) and
+    the persistent loss-scale factor halves; once the gradients fit, steps apply again, and after `growth interval` clean steps
+    the factor grows back.  The planted model has a c_proj whose weights are 3e4 x larger than usual behind a c_fc that is 1e-3 x smaller, so
+    its d(hidden) = dY W_proj^T overflows fp16 at the usual scale although every forward activation is O(1)."""
+    from leaf_amd import _lib
+    from leaf_amd.model import LeafCLIPText, get_config
+    cfg = O.TextCfg(128, 2, 2, 64, quick_gelu=True)
+    w = O.init_weights(cfg, seed=12)
+    k = "transformer.resblocks.1.mlp."
+    w[k + "c_proj.weight"] = (w[k + "c_proj.weight"] * 3e4).astype(np.float32)
+    w[k + "c_fc.weight"] = (w[k + "c_fc.weight"] * 1e-3).astype(np.float32)
+    w[k + "c_fc.bias"] = (w[k + "c_fc.bias"] * 1e-3).astype(np.float32)
+    m = LeafCLIPText(get_config("tiny-test-quickgelu"), trainable=True)
+    m.load_state_dict({n: torch_mod.from_numpy(v) for n, v in w.items()}, strict=False)
+    toks = O.synthetic_tokens(6, seed=4)
+    feat_ref = O.encode_text(w, cfg, toks)
+    anchor_np = (feat_ref + 0.3).astype(np.float32)
+    anchor = torch_mod.from_numpy(anchor_np).cuda()
+    _, _, g_ref = O.encode_text_backward(w, cfg, toks, anchor_np)
+    p0 = m.flat.clone()
+    m._clip_ws[_lib.SC_INTERVAL] = 2.0          # grow back after two clean steps (GradScaler's growth_interval, default 2000)
+    history = []
+    for it in range(12):
+        f = m.forward_train(toks)
+        m.zero_grad()
+        m.backward(f, anchor)
+        grads = m.grads.clone()
+        norm = m.adamw_step(lr=0.0)              # lr 0: the weights stay put, the step bookkeeping runs
+        st = m.grad_scaler_state()
+        history.append((bool(torch_mod.isfinite(norm)), st["loss_scale_factor"], st["skipped"], st["skipped_saturated"]))
+        if history[-1][0] and len([h for h in history if h[0]]) == 1:
+            # first applied step: the gradient at the backed-off scale matches the oracle's fp32 backward
+            for name in ("transformer.resblocks.1.mlp.c_proj.weight", "transformer.resblocks.0.attn.in_proj_weight", "token_embedding.weight"):
+                off, shape = m.layout[name]
+                got = grads[off: off + int(np.prod(shape))].view(shape).cpu().numpy()
+                assert rel_l2(got, g_ref[name]) < 2e-2, name
+            assert m.applied_steps() == 1 and m.opt_step == it + 1
+    print("scaler history (applied, factor, skipped, skipped_saturated):", history)
+    assert torch_mod.equal(m.flat, p0)
+    assert not history[0][0] and history[0][1] == 0.5 and history[0][3] == 1, "the first step saturates: skipped, scale halved"
+    n_skip0 = next(i for i, h in enumerate(history) if h[0])          # leading skipped steps
+    assert 1 <= n_skip0 <= 8 and all(history[i][1] == 0.5 ** (i + 1) for i in range(n_skip0))
+    assert history[n_skip0][1] == 0.5 ** n_skip0 and history[n_skip0 + 1][0], "two clean steps at the backed-off scale"
+    # ... after which the factor doubles and the very next step overflows again, is skipped and halves it back
+    assert history[n_skip0 + 1][1] == 0.5 ** (n_skip0 - 1) and not history[n_skip0 + 2][0] and history[n_skip0 + 2][1] == 0.5 ** n_skip0
+    assert history[-1][2] == history[-1][3], "every skipped step of this run was a saturation"
+    assert m.applied_steps() == sum(1 for h in history if h[0]) and m.opt_step == 12
+
+
 def test_deep_tower_layernorm_gradients_vs_oracle(torch_mod):
     """A tower with more LayerNorms than one ln_param_reduce launch takes (34 blocks = 68 > 64): every LayerNorm / bias
     gradient through the per-workgroup partial sums + batched reduction (train.hip) against the oracle's fp32 backward."""

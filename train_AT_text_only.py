@@ -120,6 +120,12 @@ def main(argv):
         from leaf_amd.checkpoint import load_checkpoint_file
         frozen.load_state_dict(load_checkpoint_file(args.pretrained))
     else:
+        if args.resume and is_master(args):
+            # the reference re-creates model_frozen from the hub weights on every start (train_AT_text_only.py:439-465); without
+            # --pretrained there is nothing to restore the anchor from but the resumed, already adversarially trained weights
+            logging.warning("--resume WITHOUT --pretrained: the frozen TextFARE anchor is a copy of the RESUMED weights, not of the "
+                            "weights the run started from -- the objective differs from the interrupted run's; pass the original "
+                            "--pretrained checkpoint to continue it unchanged")
         frozen.copy_from(model)
     frozen.pack()
     model.pack()
