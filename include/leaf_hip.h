@@ -217,14 +217,21 @@ int leaf_tok_mutate_encode(leaf_tok_t tk, const char* const* sentences, const in
 /* --constrain (utils_attacks.py:110-143,321-325,360-364): valid[b * rho + r] = 1 iff candidate generate_sentence(S_b, z, c,
  * alternative = -1) holds STRICTLY FEWER distinct dictionary words than S_b.  The word set is built once (leaf_dict_create:
  * '\n'-separated words); only the whitespace-delimited window around the edit is re-tokenised.  tokenizer_kind 0 = the regex
- * tokenizer [A-Za-z0-9]+|[^\sA-Za-z0-9] (exact for all ASCII), 1 = nltk.word_tokenize (exact for letters / digits /
- * whitespace without the Treebank contraction words; everything else gets fallback = 1 and is decided by the caller). */
+ * tokenizer [A-Za-z0-9]+|[^\sA-Za-z0-9] (exact for all ASCII), 1 = nltk.word_tokenize: NLTKWordTokenizer's substitution pipeline
+ * (nltk/tokenize/destructive.py, third-party: requirements.txt:14) restated window-locally, exact for ASCII text whose tokens
+ * cannot depend on the Punkt sentence model -- a sentence / candidate in which a lone '.' ends a whitespace-delimited chunk
+ * before the end of the text gets fallback = 1 and is decided by the caller with the real nltk. */
 typedef struct leaf_dict* leaf_dict_t;
 int leaf_dict_create(const char* words, size_t len, leaf_dict_t* out);
 void leaf_dict_destroy(leaf_dict_t d);
 int64_t leaf_dict_size(leaf_dict_t d);
 int leaf_tok_constrain(leaf_dict_t d, int tokenizer_kind, const char* const* sentences, const int32_t* sent_len, int B,
                        const int32_t* z, const int32_t* c, int rho, uint8_t* valid, uint8_t* fallback, int n_threads);
+/* test / debug hook: the word tokens of `text` under tokenizer_kind (0 = the regex stand-in of leaf_amd/attacks.py, 1 =
+ * nltk.word_tokenize restated: nltk/tokenize/destructive.py's substitution pipeline), '\n'-joined into out[0, cap).
+ * Returns 0; 2 when the text is declined (kind 1: non-ASCII, or a lone '.' ends a chunk inside the text, where the result would
+ * depend on nltk's trained Punkt sentence splitter); 1 on bad arguments. */
+int leaf_tok_word_tokens(int tokenizer_kind, const char* text, int len, char* out, int cap, int* out_len);
 
 /* ---- per-launch GEMM timing (bench.py roofline): between begin/end every GEMM launch is bracketed by HIP events on
  * its stream; end() sums duration / algorithmic FLOPs / algorithmic bytes / launches per key = kernel_family*16 + operand_dtype*8 + epilogue id

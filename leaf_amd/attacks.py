@@ -92,10 +92,20 @@ class Dictionary:
 
     @classmethod
     def from_nltk(cls):
-        import nltk  # noqa: F401  (absent in the build image; present where the reference runs)
+        """The reference's dictionary: nltk's ``words`` corpus + ``word_tokenize`` (utils_attacks.py:7-9,125-139).  The native
+        constraint restates word_tokenize's Treebank step (leaf_amd/treebank.py, host_text.cpp); it is switched on only after the
+        restatement has reproduced the INSTALLED nltk on a fixed battery of strings -- a different nltk generation falls back to
+        calling nltk itself for every candidate."""
+        import logging
+        import nltk  # noqa: F401  (absent from the build image's system interpreter; present where the reference runs)
         from nltk.corpus import words
         from nltk.tokenize import word_tokenize
-        return cls(words.words(), word_tokenize, kind="nltk")
+        from .treebank import self_check
+        ok = self_check(word_tokenize)
+        if not ok:
+            logging.warning(f"nltk {getattr(nltk, '__version__', '?')}: word_tokenize differs from the restated Treebank pipeline on the "
+                            "self-check strings -- --constrain is decided with nltk itself for every candidate (slow host path)")
+        return cls(words.words(), word_tokenize, kind="nltk" if ok else None)
 
     def native_handle(self):
         """leaf_dict_t of this word set (built once), or None when the tokenizer has no native restatement."""
@@ -120,9 +130,17 @@ class Dictionary:
             pass
 
     @classmethod
-    def from_file(cls, path: str):
+    def from_file(cls, path: str, tokenizer: str = "regex"):
+        """A word-list file (one word per line).  ``tokenizer='treebank'``: tokenise like nltk.word_tokenize WITHOUT nltk: the
+        restated Treebank pipeline; a text whose tokens would depend on nltk's trained Punkt sentence model (a lone '.' ending a
+        chunk inside the text) is tokenised as ONE sentence -- ``word_tokenize(text, preserve_line=True)`` -- since there is no
+        Punkt here (install nltk and use ``from_nltk`` for the reference's exact behaviour on such texts)."""
         with open(path) as f:
-            return cls([w.strip() for w in f if w.strip()])
+            ws = [w.strip() for w in f if w.strip()]
+        if tokenizer == "treebank":
+            from .treebank import treebank_tokenize
+            return cls(ws, treebank_tokenize, kind="nltk")
+        return cls(ws)
 
     def count(self, sentence: str) -> int:
         return len(self.words.intersection(self.tokenize(sentence.lower())))
@@ -179,9 +197,12 @@ def _stage_candidates(tokenizer, sentences, z, c, constrain, trace):
         # compares distinct dictionary-word counts (leaf_tok_constrain); what it declines is decided here in Python
         D = get_dictionary()
         valid, fb = tokenizer.constrain_mask(D, sentences, z, c)
+        lo = {}                                           # dictionary words of a sentence: counted once, not once per candidate
         for i in np.nonzero(fb.reshape(-1))[0]:
             b, r = divmod(int(i), rho)
-            valid[b, r] = D.count(_apply_edit(sentences[b], int(z[b, r]), int(c[b, r]))) < D.count(sentences[b])
+            if b not in lo:
+                lo[b] = D.count(sentences[b])
+            valid[b, r] = D.count(_apply_edit(sentences[b], int(z[b, r]), int(c[b, r]))) < lo[b]
         z[~valid], c[~valid] = 0, -1                      # the no-op edit: candidate == original sentence
     need_strings = (constrain and not native_constrain) or trace is not None or not native
     SS = None
@@ -204,9 +225,24 @@ def _stage_candidates(tokenizer, sentences, z, c, constrain, trace):
     return toks, lens
 
 
+def duplicate_map(toks: np.ndarray, B: int, n: int) -> np.ndarray:
+    """dup_of[b, r] = the first r' <= r whose token row equals candidate r's (r itself when the row is new).  The CLIP
+    tokenizer lower-cases and collapses whitespace (src/open_clip/tokenizer.py:83-85,139), so stage 2's 'a' / 'A', a space
+    inserted next to a space and with-replacement draws (utils_attacks.py:317: replace = rho > 2 len + 1) all give identical
+    id rows -- and identical losses: only the first needs computing."""
+    t = np.ascontiguousarray(toks.reshape(B, n, -1))
+    dup = np.tile(np.arange(n, dtype=np.int64), (B, 1))
+    keys = t.view(np.dtype((np.void, t.dtype.itemsize * t.shape[-1]))).reshape(B, n)
+    for b in range(B):
+        _, first, inv = np.unique(keys[b], return_index=True, return_inverse=True)
+        # np.unique's return_index is the first occurrence in the ORIGINAL order
+        dup[b] = first[inv.reshape(-1)]
+    return dup
+
+
 def attack_text_leaf(model, tokenizer, sentences, anchor_features, device=None, objective="l2", n=10, k=1,
                      V=DEFAULT_V, constrain=False, debug=False, return_trace: Optional[list] = None,
-                     return_picks: Optional[list] = None):
+                     return_picks: Optional[list] = None, dedupe: bool = True):
     """LEAF attack on a batch of sentences.  ``model`` is a ``leaf_amd.model.LeafCLIPText`` (anything with
     ``score_candidates``); ``anchor_features`` a float32 CUDA tensor [B, D].  Returns
     ``(best_features [B,D], adversarial sentences)`` like the reference.  The numpy global RNG is consumed exactly as
@@ -218,6 +254,40 @@ def attack_text_leaf(model, tokenizer, sentences, anchor_features, device=None, 
     best_feat = None
     Varr = np.asarray(V, dtype=np.int32)
     reuse = hasattr(model, "encode_text_kv") and getattr(model, "trim_rows", False)
+    dedupe = dedupe and reuse
+
+    def score(toks, lens, base, kv, want_features):
+        """One stage's scoring call -> (winner indices [B] on the host, winner features or None).  With ``dedupe`` a candidate
+        whose id row repeats an earlier candidate's of the same caption is not computed again: its slot is handed to the
+        no-op edit (the clean caption: ONE row under prefix reuse), the loss of its first occurrence is copied into it and the
+        arg-max runs over the completed [B, rho] losses -- first index wins, so the first occurrence beats its copies exactly as
+        in torch.argmax over the reference's full loss matrix (utils_attacks.py:348,386)."""
+        import torch
+        pl = prefix_lens(toks, base) if reuse else None
+        dup = duplicate_map(toks, B, n) if dedupe else None
+        if dup is None or not (dup != np.arange(n)[None, :]).any():
+            ids, feat = model.score_candidates(toks, anchor_features, n, objective, want_features=want_features, seq_lens=lens,
+                                               prefix_lens=pl, kv=kv)
+            return ids.cpu().numpy(), feat
+        is_dup = (dup != np.arange(n)[None, :]).reshape(-1)
+        toks = toks.copy().reshape(B * n, -1)
+        rep = np.repeat(np.arange(B), n)[is_dup]
+        toks[is_dup] = base[rep]
+        if lens is not None:
+            lens = lens.copy()
+            lens[is_dup] = (base.argmax(-1) + 1)[rep]
+        pl = pl.copy()
+        pl[is_dup] = toks.shape[-1]                          # nothing differs from the clean caption
+        dup_dev = torch.from_numpy(dup).to(anchor_features.device)
+        ids_k, feat, loss = model.score_candidates(toks, anchor_features, n, objective, want_features=want_features, want_loss=True,
+                                                   seq_lens=lens, prefix_lens=pl, kv=kv)
+        ids = loss.gather(1, dup_dev).argmax(-1)             # first maximum wins
+        ids_h, ids_k_h = ids.cpu().numpy(), ids_k.cpu().numpy()
+        if want_features and (ids_h != ids_k_h).any():
+            # (only when the clean caption itself out-scored every candidate in a slot it was lent: re-encode the winners;
+            # rows are bit-identical whichever launch computes them)
+            feat = model.encode_text(toks.reshape(B, n, -1)[np.arange(B), ids_h])
+        return ids_h, feat
 
     def prefix_lens(toks, base):
         """leading positions where a candidate's ids equal its clean caption's (>= 1: SOT)"""
@@ -236,10 +306,7 @@ def attack_text_leaf(model, tokenizer, sentences, anchor_features, device=None, 
         c = np.full((B, n), ord(' '), dtype=np.int32)
         positions = z.copy()            # the reference reads the winner's position from the sampled ones (:351-353)
         toks, lens = _stage_candidates(tokenizer, sentences, z, c, constrain, return_trace)
-        pl = prefix_lens(toks, base) if reuse else None
-        ids_best, _ = model.score_candidates(toks, anchor_features, n, objective, want_features=False, seq_lens=lens,
-                                             prefix_lens=pl, kv=kv)
-        ids_best = ids_best.cpu().numpy()
+        ids_best, _ = score(toks, lens, base, kv, False)
         if return_picks is not None:
             return_picks.append(ids_best.copy())
         best_pos = positions[np.arange(B), ids_best]
@@ -248,10 +315,7 @@ def attack_text_leaf(model, tokenizer, sentences, anchor_features, device=None, 
         c = Varr[u]
         z = np.repeat(best_pos[:, None], n, axis=1).astype(np.int32)
         toks, lens = _stage_candidates(tokenizer, sentences, z, c, constrain, return_trace)
-        pl = prefix_lens(toks, base) if reuse else None
-        ids_best, best_feat = model.score_candidates(toks, anchor_features, n, objective, want_features=True, seq_lens=lens,
-                                                     prefix_lens=pl, kv=kv)
-        ids_best = ids_best.cpu().numpy()
+        ids_best, best_feat = score(toks, lens, base, kv, True)
         if return_picks is not None:
             return_picks.append(ids_best.copy())
         sentences = [_apply_edit(S, int(z[b, ids_best[b]]), int(c[b, ids_best[b]])) for b, S in enumerate(sentences)]

@@ -291,9 +291,9 @@ extern "C" int leaf_tok_mutate_encode(leaf_tok_t tk, const char* const* sentence
 // Two word tokenizers (the caller says which one its Dictionary uses):
 //   kind 0  the regex stand-in  [A-Za-z0-9]+ | [^\sA-Za-z0-9]  (leaf_amd/attacks.py, used when nltk is absent): tokens never
 //           span whitespace, so the window logic is exact for every ASCII string;
-//   kind 1  nltk.word_tokenize: for text made of letters, digits and whitespace only it is a whitespace split, except for the
-//           Treebank contraction words (cannot, gimme, gonna, gotta, lemme, wanna); any other sentence / candidate (punctuation,
-//           quotes, periods ...) is declined (fallback = 1) and decided by the caller with the real tokenizer.
+//   kind 1  nltk.word_tokenize: the Treebank substitution pipeline restated below (tb_tokenize_piece), exact on any ASCII text
+//           whose tokens cannot depend on Punkt's sentence boundaries; a sentence / candidate in which a lone '.' ends a chunk
+//           before the end of the text is declined (fallback = 1) and decided by the caller with the real tokenizer.
 namespace {
 
 struct Dict {
@@ -303,13 +303,273 @@ struct Dict {
 inline bool is_alnum(unsigned char c) { return is_letter(c) || is_digit(c); }
 inline char lower(unsigned char c) { return (char)((c >= 'A' && c <= 'Z') ? c + 32 : c); }
 
-bool treebank_special(const std::string& w) {
-    return w == "cannot" || w == "gimme" || w == "gonna" || w == "gotta" || w == "lemme" || w == "wanna";
+
+// ---- kind 1: nltk.word_tokenize = Punkt sentence splitting + NLTKWordTokenizer (nltk/tokenize/destructive.py, a third-party
+// dependency of the reference: requirements.txt:14).  The Treebank step is a fixed pipeline of regular-expression
+// substitutions; it is restated here rule for rule (same order, same non-overlapping left-to-right matching) on a PIECE of the
+// lower-cased text that is bounded by whitespace or the text's ends.  Every rule looks at most one character past a space, so a
+// piece tokenises as it would inside the whole text once it is told whether it starts at the text's first character
+// (`at_start`: the ^" rule), ends at its last (`at_end`: the ([:,])$ rule) and whether only whitespace follows it (`ws_after`:
+// the two final-period rules, which end in \s*$).  Checked against nltk 3.6.5's own output (tests/golden/treebank_kat.json)
+// and against leaf_amd/treebank.py (tests/test_constrain_native.py).  What Punkt decides is NOT restated: texts in which a
+// lone '.' ends a chunk before the text's end are declined (tb_punkt_free), the caller asks the real nltk.
+inline bool tb_word(unsigned char c) { return is_alnum(c) || c == '_'; }
+inline bool tb_closer(unsigned char c) { return c == ']' || c == ')' || c == '}' || c == '>' || c == '"' || c == '\''; }
+
+// text[0, n): true when sentence boundaries cannot change the tokens (leaf_amd/treebank.py punkt_free)
+bool tb_punkt_free(const char* t, size_t n) {
+    size_t i = 0;
+    while (i < n) {
+        if (t[i] != '.') { ++i; continue; }
+        size_t j = i;
+        while (j < n && t[j] == '.') ++j;
+        if (j - i == 1) {
+            size_t k = j;
+            while (k < n && tb_closer((unsigned char)t[k])) ++k;
+            if (k == n || is_space((unsigned char)t[k])) {                 // the period ends its chunk ...
+                for (size_t q = k; q < n; ++q)                             // ... and something other than closers / blanks follows
+                    if (!tb_closer((unsigned char)t[q]) && !is_space((unsigned char)t[q])) return false;
+            }
+        }
+        i = j;
+    }
+    return true;
 }
 
-// tokens of a whitespace-free-bounded piece of text, lower-cased; returns false when the text leaves the fast path of `kind`
+// final-period rules:  ([^\.])(\.)(CLASS*)\s*$  ->  "\1 \2" + mid + "\3 "   (first form: CLASS includes ' ', mid = " ")
+void tb_final_period(std::string& w, bool with_space, bool anchored_end) {
+    if (!anchored_end) return;
+    size_t q = w.size();
+    while (q > 0 && is_space((unsigned char)w[q - 1])) --q;
+    size_t r = q;
+    while (r > 0 && (tb_closer((unsigned char)w[r - 1]) || (with_space && w[r - 1] == ' '))) --r;
+    if (r < 2 || w[r - 1] != '.' || w[r - 2] == '.') return;
+    std::string o = w.substr(0, r - 1);
+    o += " .";
+    if (with_space) o += ' ';
+    o.append(w, r, q - r);
+    o += ' ';
+    w.swap(o);
+}
+
+template <class Pred>
+void tb_pad_chars(std::string& w, Pred pred) {
+    std::string o;
+    o.reserve(w.size() + 8);
+    for (char c : w) { if (pred((unsigned char)c)) { o += ' '; o += c; o += ' '; } else o += c; }
+    w.swap(o);
+}
+
+inline bool tb_ieq(const std::string& w, size_t i, const char* lit) {     // case-insensitive literal at w[i..]
+    for (size_t k = 0; lit[k]; ++k)
+        if (i + k >= w.size() || lower((unsigned char)w[i + k]) != lit[k]) return false;
+    return true;
+}
+
+// \b(A)(B)\b (case-insensitive) -> " A B "; `need_space`: the (wan)(na)\s form (the blank is consumed)
+void tb_contraction(std::string& w, const char* a, const char* b, bool need_space) {
+    const size_t la = strlen(a), lb = strlen(b);
+    std::string o;
+    size_t i = 0;
+    bool any = false;
+    while (i < w.size()) {
+        const bool wb0 = (i == 0 || !tb_word((unsigned char)w[i - 1])) && tb_word((unsigned char)w[i]);
+        if (wb0 && tb_ieq(w, i, a) && tb_ieq(w, i + la, b)) {
+            const size_t e = i + la + lb;
+            const bool ok = need_space ? (e < w.size() && is_space((unsigned char)w[e]))
+                                       : (e == w.size() || !tb_word((unsigned char)w[e]));
+            if (ok) {
+                o += ' '; o.append(w, i, la); o += ' '; o.append(w, i + la, lb); o += ' ';
+                i = e + (need_space ? 1 : 0);
+                any = true;
+                continue;
+            }
+        }
+        o += w[i++];
+    }
+    if (any) w.swap(o);
+}
+
 template <class F>
-bool tokenize_piece(const char* s, size_t n, int kind, F emit) {
+bool tb_tokenize_piece(const char* s, size_t n, bool at_start, bool at_end, bool ws_after, F emit) {
+    std::string w;
+    w.reserve(n + 16);
+    if (!at_start) w += ' ';
+    for (size_t i = 0; i < n; ++i) {
+        const unsigned char c = (unsigned char)s[i];
+        if (c >= 128) return false;
+        w += lower(c);
+    }
+    if (!at_end) w += ' ';
+    std::string o;
+    // ---- STARTING_QUOTES
+    {   // ([`]+) -> " \1 "
+        o.clear();
+        for (size_t i = 0; i < w.size();) {
+            if (w[i] == '`') { size_t j = i; while (j < w.size() && w[j] == '`') ++j; o += ' '; o.append(w, i, j - i); o += ' '; i = j; }
+            else o += w[i++];
+        }
+        w.swap(o);
+    }
+    if (at_start && !w.empty() && w[0] == '"') w.replace(0, 1, "``");                       // ^" -> ``
+    {   // (``) -> " `` "
+        o.clear();
+        for (size_t i = 0; i < w.size();) {
+            if (w[i] == '`' && i + 1 < w.size() && w[i + 1] == '`') { o += " `` "; i += 2; } else o += w[i++];
+        }
+        w.swap(o);
+    }
+    {   // ([ \(\[{<])("|'') -> "\1 `` "
+        o.clear();
+        for (size_t i = 0; i < w.size();) {
+            const char c = w[i];
+            if ((c == ' ' || c == '(' || c == '[' || c == '{' || c == '<') && i + 1 < w.size()) {
+                if (w[i + 1] == '"') { o += c; o += " `` "; i += 2; continue; }
+                if (w[i + 1] == '\'' && i + 2 < w.size() && w[i + 2] == '\'') { o += c; o += " `` "; i += 3; continue; }
+            }
+            o += w[i++];
+        }
+        w.swap(o);
+    }
+    {   // (?i)(')(?!re|ve|ll|m|t|s|d|n)(\w)\b -> "\1 \2": an apostrophe before a ONE-character word that is not a clitic letter
+        o.clear();
+        for (size_t i = 0; i < w.size();) {
+            if (w[i] == '\'' && i + 1 < w.size() && tb_word((unsigned char)w[i + 1]) &&
+                (i + 2 == w.size() || !tb_word((unsigned char)w[i + 2]))) {
+                const char c = lower((unsigned char)w[i + 1]);
+                if (c != 'm' && c != 't' && c != 's' && c != 'd' && c != 'n') { o += "' "; o += w[i + 1]; i += 2; continue; }
+            }
+            o += w[i++];
+        }
+        w.swap(o);
+    }
+    // ---- PUNCTUATION
+    tb_final_period(w, true, at_end || ws_after);
+    {   // ([:,])([^\d]) -> " \1 \2"
+        o.clear();
+        for (size_t i = 0; i < w.size();) {
+            if ((w[i] == ':' || w[i] == ',') && i + 1 < w.size() && !is_digit((unsigned char)w[i + 1])) {
+                o += ' '; o += w[i]; o += ' '; o += w[i + 1]; i += 2;
+            } else o += w[i++];
+        }
+        w.swap(o);
+    }
+    if (at_end && !w.empty() && (w.back() == ':' || w.back() == ',')) {                     // ([:,])$ -> " \1 "
+        const char c = w.back(); w.pop_back(); w += ' '; w += c; w += ' ';
+        // (the text now ends in a blank: the anchored rules below see it, as re.sub on the rewritten text does)
+    }
+    {   // \.{2,} -> " \g<0> "
+        o.clear();
+        for (size_t i = 0; i < w.size();) {
+            if (w[i] == '.') {
+                size_t j = i; while (j < w.size() && w[j] == '.') ++j;
+                if (j - i >= 2) { o += ' '; o.append(w, i, j - i); o += ' '; } else o += '.';
+                i = j;
+            } else o += w[i++];
+        }
+        w.swap(o);
+    }
+    tb_pad_chars(w, [](unsigned char c) { return c == ';' || c == '@' || c == '#' || c == '$' || c == '%' || c == '&'; });
+    tb_final_period(w, false, at_end || ws_after);
+    tb_pad_chars(w, [](unsigned char c) { return c == '?' || c == '!'; });
+    {   // ([^'])' (blank) -> "\1 ' "
+        o.clear();
+        for (size_t i = 0; i < w.size();) {
+            if (w[i] != '\'' && i + 2 < w.size() && w[i + 1] == '\'' && w[i + 2] == ' ') { o += w[i]; o += " ' "; i += 3; }
+            else o += w[i++];
+        }
+        w.swap(o);
+    }
+    tb_pad_chars(w, [](unsigned char c) { return c == '*'; });
+    tb_pad_chars(w, [](unsigned char c) { return c == ']' || c == '[' || c == '(' || c == ')' || c == '{' || c == '}' || c == '<' || c == '>'; });
+    {   // -- -> " -- "
+        o.clear();
+        for (size_t i = 0; i < w.size();) {
+            if (w[i] == '-' && i + 1 < w.size() && w[i + 1] == '-') { o += " -- "; i += 2; } else o += w[i++];
+        }
+        w.swap(o);
+    }
+    w = " " + w + " ";
+    // ---- ENDING_QUOTES
+    {   // " -> " '' "
+        o.clear();
+        for (char c : w) { if (c == '"') o += " '' "; else o += c; }
+        w.swap(o);
+    }
+    {   // (\S)('') -> "\1 \2 "
+        o.clear();
+        for (size_t i = 0; i < w.size();) {
+            if (!is_space((unsigned char)w[i]) && i + 2 < w.size() && w[i + 1] == '\'' && w[i + 2] == '\'') { o += w[i]; o += " '' "; i += 3; }
+            else o += w[i++];
+        }
+        w.swap(o);
+    }
+    {   // ([^' ])('[sS]|'[mM]|'[dD]|') (blank) -> "\1 \2 "
+        o.clear();
+        for (size_t i = 0; i < w.size();) {
+            if (w[i] != '\'' && w[i] != ' ' && i + 1 < w.size() && w[i + 1] == '\'') {
+                const char c = i + 2 < w.size() ? lower((unsigned char)w[i + 2]) : 0;
+                if ((c == 's' || c == 'm' || c == 'd') && i + 3 < w.size() && w[i + 3] == ' ') {
+                    o += w[i]; o += ' '; o.append(w, i + 1, 2); o += ' '; i += 4; continue;
+                }
+                if (i + 2 < w.size() && w[i + 2] == ' ') { o += w[i]; o += " ' "; i += 3; continue; }
+            }
+            o += w[i++];
+        }
+        w.swap(o);
+    }
+    {   // ([^' ])('ll|'re|'ve|n't) (blank) -> "\1 \2 "   (upper-case forms: the text is lower-cased)
+        o.clear();
+        for (size_t i = 0; i < w.size();) {
+            if (w[i] != '\'' && w[i] != ' ' && i + 4 < w.size() && w[i + 4] == ' ' &&
+                (tb_ieq(w, i + 1, "'ll") || tb_ieq(w, i + 1, "'re") || tb_ieq(w, i + 1, "'ve") || tb_ieq(w, i + 1, "n't"))) {
+                // 'lL / 'Ll etc. are not in nltk's alternation, but lower-cased text never holds them
+                o += w[i]; o += ' '; o.append(w, i + 1, 3); o += ' '; i += 5; continue;
+            }
+            o += w[i++];
+        }
+        w.swap(o);
+    }
+    // ---- CONTRACTIONS2 / CONTRACTIONS3
+    tb_contraction(w, "can", "not", false);
+    tb_contraction(w, "d", "'ye", false);
+    tb_contraction(w, "gim", "me", false);
+    tb_contraction(w, "gon", "na", false);
+    tb_contraction(w, "got", "ta", false);
+    tb_contraction(w, "lem", "me", false);
+    tb_contraction(w, "more", "'n", false);
+    tb_contraction(w, "wan", "na", true);
+    for (const char* rest : {"is", "was"}) {   // (?i) ('t)(is|was)\b -> " \1 \2 "
+        const size_t lr = strlen(rest);
+        o.clear();
+        bool any = false;
+        for (size_t i = 0; i < w.size();) {
+            if (w[i] == ' ' && tb_ieq(w, i + 1, "'t") && tb_ieq(w, i + 3, rest) &&
+                (i + 3 + lr == w.size() || !tb_word((unsigned char)w[i + 3 + lr]))) {
+                o += " 't "; o.append(w, i + 3, lr); o += ' '; i += 3 + lr; any = true; continue;
+            }
+            o += w[i++];
+        }
+        if (any) w.swap(o);
+    }
+    // ---- split
+    size_t i = 0;
+    std::string tok;
+    while (i < w.size()) {
+        while (i < w.size() && is_space((unsigned char)w[i])) ++i;
+        size_t j = i;
+        while (j < w.size() && !is_space((unsigned char)w[j])) ++j;
+        if (j > i) { tok.assign(w, i, j - i); emit(tok); }
+        i = j;
+    }
+    return true;
+}
+
+// tokens of a piece of text bounded by whitespace or the text's ends, lower-cased; returns false when the text leaves the fast path
+// of `kind` (kind 0: never for ASCII; kind 1: non-ASCII).  at_start / at_end / ws_after: where the piece sits (kind 1 only).
+template <class F>
+bool tokenize_piece(const char* s, size_t n, int kind, F emit, bool at_start = true, bool at_end = true, bool ws_after = true) {
+    if (kind == 1) return tb_tokenize_piece(s, n, at_start, at_end, ws_after, emit);
     size_t i = 0;
     std::string w;
     while (i < n) {
@@ -319,10 +579,8 @@ bool tokenize_piece(const char* s, size_t n, int kind, F emit) {
         if (is_alnum(c)) {
             w.clear();
             while (i < n && is_alnum((unsigned char)s[i])) { w += lower((unsigned char)s[i]); ++i; }
-            if (kind == 1 && treebank_special(w)) return false;
             emit(w);
         } else {
-            if (kind == 1) return false;          // punctuation: nltk's rules are not local
             w.assign(1, (char)c);
             emit(w);
             ++i;
@@ -368,8 +626,19 @@ extern "C" int leaf_tok_constrain(leaf_dict_t d, int kind, const char* const* se
         uint8_t* v = valid + (size_t)b * rho;
         uint8_t* fb = fallback + (size_t)b * rho;
         std::unordered_map<std::string, int> mult;       // dictionary words of the sentence -> occurrences
-        const bool ok = tokenize_piece(s, (size_t)n, kind, [&](const std::string& w) { if (d->words.count(w)) ++mult[w]; });
+        bool ok = kind == 0 || tb_punkt_free(s, (size_t)n);
+        ok = ok && tokenize_piece(s, (size_t)n, kind, [&](const std::string& w) { if (d->words.count(w)) ++mult[w]; });
         if (!ok) { for (int r = 0; r < rho; ++r) { fb[r] = 1; v[r] = 0; } return; }
+        // kind 1: index of the text's final period, when it has one that ends its chunk (its split depends on what follows it)
+        int final_period = -1;
+        if (kind == 1) {
+            for (int i = n - 1; i >= 0; --i) {
+                const unsigned char ch = (unsigned char)s[i];
+                if (ch == '.') { if (i == 0 || s[i - 1] != '.') final_period = i; break; }
+                if (!tb_closer(ch) && !is_space(ch)) break;
+            }
+        }
+        std::string cand;
         const int lo = (int)mult.size();
         std::unordered_map<std::string, int> delta;
         std::string win;
@@ -395,11 +664,24 @@ extern "C" int leaf_tok_constrain(leaf_dict_t d, int kind, const char* const* se
             while (L > 0 && !is_space((unsigned char)s[L - 1])) --L;
             while (R < n && !is_space((unsigned char)s[R])) ++R;
             delta.clear();
-            bool okw = tokenize_piece(s + L, (size_t)(R - L), kind, [&](const std::string& w) { if (d->words.count(w)) --delta[w]; });
+            bool at_start = true, at_end = true, ws_after = true;
+            if (kind == 1) {
+                // the candidate as a whole must stay independent of sentence boundaries, and an edit behind the final period's
+                // chunk could change how THAT chunk (outside the window) splits
+                cand.assign(s, (size_t)e0);
+                if (has_ins) cand += ins;
+                cand.append(s + e1, (size_t)(n - e1));
+                if (!tb_punkt_free(cand.data(), cand.size()) || (final_period >= 0 && L > final_period)) { fb[r] = 1; v[r] = 0; continue; }
+                at_start = L == 0; at_end = R == n;
+                for (int q = R; q < n && ws_after; ++q) ws_after = is_space((unsigned char)s[q]);
+            }
+            bool okw = tokenize_piece(s + L, (size_t)(R - L), kind, [&](const std::string& w) { if (d->words.count(w)) --delta[w]; },
+                                      at_start, at_end, ws_after);
             win.assign(s + L, (size_t)(e0 - L));
             if (has_ins) win += ins;
             win.append(s + e1, (size_t)(R - e1));
-            okw = okw && tokenize_piece(win.data(), win.size(), kind, [&](const std::string& w) { if (d->words.count(w)) ++delta[w]; });
+            okw = okw && tokenize_piece(win.data(), win.size(), kind, [&](const std::string& w) { if (d->words.count(w)) ++delta[w]; },
+                                        at_start, at_end, ws_after);
             if (!okw) { fb[r] = 1; v[r] = 0; continue; }
             int cnt = lo;
             for (auto& kv : delta) {
@@ -412,4 +694,19 @@ extern "C" int leaf_tok_constrain(leaf_dict_t d, int kind, const char* const* se
         }
     });
     return bad ? 3 : 0;
+}
+
+// Debug / test hook: word tokens of `text` under tokenizer `kind` (0 regex stand-in, 1 nltk.word_tokenize), joined by '\n' into
+// out[0, cap).  Returns 0, 2 when the text is declined (kind 1: non-ASCII or sentence-boundary dependent), 1 on bad arguments /
+// overflow.
+extern "C" int leaf_tok_word_tokens(int kind, const char* text, int len, char* out, int cap, int* out_len) {
+    if (!text || !out || !out_len || len < 0 || cap < 1 || (kind != 0 && kind != 1)) return 1;
+    if (kind == 1 && !tb_punkt_free(text, (size_t)len)) return 2;
+    std::string joined;
+    const bool ok = tokenize_piece(text, (size_t)len, kind, [&](const std::string& w) { joined += w; joined += '\n'; });
+    if (!ok) return 2;
+    if ((int)joined.size() > cap) return 1;
+    memcpy(out, joined.data(), joined.size());
+    *out_len = (int)joined.size();
+    return 0;
 }

@@ -68,27 +68,87 @@ def test_native_equals_python_on_random_edits(tok, kat):
     assert total == 120 * 5 * 40
 
 
-def test_nltk_mode_decides_only_what_it_can_decide_exactly(tok, kat):
-    """kind 'nltk': nltk.word_tokenize is a whitespace split for letters / digits / whitespace (Treebank contraction words
-    excepted); everything else must come back as fallback for the caller's real tokenizer."""
-    split = lambda s: s.split()
-    D = attacks.Dictionary(kat["stub_words"] + ["can", "not"], tokenize=split, kind="nltk")
-    sents = ["a photo of a cat", "the red car", "we cannot go", "a photo, of a cat", "gonna do it"]
-    rho = 2 * max(len(s) for s in sents) + 1
-    z = np.stack([np.arange(rho) % (2 * len(S) + 1) for S in sents]).astype(np.int32)
-    for ch in (ord(' '), ord('x'), -1, ord('!')):
-        c = np.full(z.shape, ch, dtype=np.int32)
+@pytest.fixture(scope="module")
+def tb_kat(golden_dir):
+    with open(os.path.join(golden_dir, "treebank_kat.json")) as f:
+        return json.load(f)
+
+
+def _native_tokens(text, kind=1):
+    import ctypes as C
+    from leaf_amd import _lib
+    b = text.encode()
+    out, n = C.create_string_buffer(8 * len(b) + 64), C.c_int()
+    rc = _lib.lib().leaf_tok_word_tokens(kind, b, len(b), out, len(out), C.byref(n))
+    if rc == 2:
+        return None
+    assert rc == 0
+    r = out.raw[:n.value].decode()
+    return r.split("\n")[:-1] if r else []
+
+
+def test_treebank_restatements_reproduce_nltk(tb_kat):
+    """The word tokenizer of --constrain is nltk.word_tokenize (utils_attacks.py:135,139).  Both restatements of its Treebank
+    step -- leaf_amd/treebank.py (regex pipeline) and the native one in host_text.cpp -- against 1,800 strings tokenised by the
+    REAL nltk 3.6.5 (tests/golden/make_golden_treebank.py): punctuation, quotes, clitics, contractions, brackets, single-character
+    edits of captions with every character of V."""
+    from leaf_amd.treebank import punkt_free, treebank_tokenize
+    assert "nltk 3.6.5" in tb_kat["source"] and len(tb_kat["cases"]) > 1500
+    for s, want in tb_kat["cases"]:
+        assert punkt_free(s.lower()), s
+        assert treebank_tokenize(s.lower()) == want, s
+        assert _native_tokens(s) == want, s
+    # texts whose tokens depend on the Punkt sentence model are declined, not guessed
+    from leaf_amd.treebank import word_tokenize
+    for s in ("a cat. a dog", "e.g. this", "the end.) x", "one. two."):
+        assert not punkt_free(s) and _native_tokens(s) is None
+        with pytest.raises(ValueError):
+            word_tokenize(s)
+    assert _native_tokens("caf\u00e9 au lait") is None, "non-ASCII: the Python path"
+
+
+def test_nltk_mode_native_equals_the_treebank_tokenizer_on_random_edits(tok, kat):
+    """kind 'nltk': leaf_tok_constrain re-tokenises only the window around the edit with the restated Treebank pipeline (told
+    whether the window touches the text's ends).  On 30,000 random single edits -- all 96 characters of V, captions with commas,
+    quotes, clitics, brackets, a final period -- every candidate it decides must agree with tokenising the WHOLE candidate, and it
+    may decline only what really depends on sentence boundaries (plus edits behind the text's final period)."""
+    from leaf_amd.treebank import punkt_free, treebank_tokenize
+    words = kat["stub_words"] + ["can", "not", "it", "s", "do", "wan", "na", "end", "hi", "b", "t", "is"]
+    D = attacks.Dictionary(words, tokenize=lambda s: treebank_tokenize(s), kind="nltk")
+    rng = random.Random(5)
+    vocab = kat["stub_words"] + ["zebra", "x1", "42", "don't", "it's", "(hi)", "a,b", "1,000", "cannot", "wanna", "\"cat\"", "dog's", "dogs'",
+                                 "'tis", "rock'n'roll", "a--b", "wait...", "what?!", "50%", "me&you", "'a'", "[the]", "e.g", "CAT", "The", "a:b", "2:30"]
+    decided = declined = 0
+    for trial in range(150):
+        sents = [" ".join(rng.choice(vocab) for _ in range(rng.randint(1, 8))) for _ in range(5)]
+        if trial % 3 == 0:
+            sents[0] += "."                       # a final period
+        if trial % 7 == 0:
+            sents[1] = "  " + sents[1] + ". "
+        if trial % 10 == 0:
+            sents[2] = sents[2] + ". and more"    # sentence-boundary dependent: the whole caption is declined
+        rho = 40
+        z = np.stack([np.array([rng.randrange(2 * len(S) + 1) for _ in range(rho)]) for S in sents]).astype(np.int32)
+        c = np.array([[rng.choice(attacks.DEFAULT_V) for _ in range(rho)] for _ in sents], dtype=np.int32)
         valid, fb = tok.constrain_mask(D, sents, z, c)
-        assert fb[2].all() and fb[3].all() and fb[4].all(), "contraction words / punctuation in the sentence: declined"
-        for b in (0, 1):
-            S = sents[b]
+        for b, S in enumerate(sents):
+            if not punkt_free(S.lower()):
+                assert fb[b].all(), S
+                declined += rho
+                continue
+            lo = D.count(S)
             for r in range(rho):
-                cand = attacks._apply_edit(S, int(z[b, r]), ch)
-                if ch == ord('!') and cand != S:
-                    assert fb[b, r], "a candidate with punctuation is declined"
+                cand = attacks._apply_edit(S, int(z[b, r]), int(c[b, r]))
+                if fb[b, r]:
+                    declined += 1
+                    last_period = S.rstrip(" \t])}>\"'").rfind(".")
+                    behind = S.rstrip(" \t])}>\"'").endswith(".") and (int(z[b, r]) // 2) > last_period
+                    assert not punkt_free(cand.lower()) or behind, (S, cand)
                     continue
-                assert not fb[b, r]
-                assert bool(valid[b, r]) == (D.count(cand) < D.count(S)), (S, cand)
+                decided += 1
+                assert bool(valid[b, r]) == (D.count(cand) < lo), (S, cand, int(z[b, r]), int(c[b, r]))
+    print("nltk-mode native constraint: decided", decided, "declined", declined)
+    assert decided > 25000 and declined < 0.15 * (decided + declined)
 
 
 def test_stage_candidates_constrained_native_equals_python(tok, kat):

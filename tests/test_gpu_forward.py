@@ -166,6 +166,41 @@ def test_attack_text_replays_reference_trace(torch_mod, golden_dir, native):
     attacks.set_dictionary(None)
 
 
+@pytest.mark.parametrize("native", [False, True])
+def test_token_identical_candidates_are_computed_once(torch_mod, native):
+    """SURVEY 8f-2 (third item): the tokenizer lower-cases and collapses whitespace (src/open_clip/tokenizer.py:83-85,139), so
+    'a' / 'A' at the same slot, a space beside a space and with-replacement draws give identical id rows.  With dedupe they are
+    computed once and the first-index tie-break of torch.argmax (utils_attacks.py:348,386) is preserved: same picks at every
+    stage, same adversarial sentences, bit-identical features, fewer rows."""
+    from leaf_amd import attacks
+    from leaf_amd.tokenizer import SimpleTokenizer
+    if native:
+        from leaf_amd.native_text import NativeTokenizer
+        tok = NativeTokenizer(n_threads=4)
+    else:
+        tok = SimpleTokenizer()
+    m = _model("tiny-test-quickgelu", 12)
+    sents = ["ab", "a  photo of a cat", "two dogs", "x"]          # 'ab': 5 slots < rho -> stage 1 draws with replacement
+    anchor = m.encode_text(tok.encode_batch(sents)) + 0.05
+    rho, k = 60, 2                                                  # 60 of the 96 stage-2 characters: many 'q' / 'Q' pairs
+    out = {}
+    for dd in (True, False):
+        np.random.seed(7)
+        picks, trace = [], []
+        rows0 = m.rows_scored
+        feats, adv = attacks.attack_text_leaf(m, tok, list(sents), anchor.clone(), objective="l2", n=rho, k=k, V=attacks.DEFAULT_V,
+                                              return_picks=picks, return_trace=trace, dedupe=dd)
+        out[dd] = (adv, [p.tolist() for p in picks], feats.cpu().numpy(), m.rows_scored - rows0, trace)
+    assert out[True][0] == out[False][0] and out[True][1] == out[False][1]
+    assert np.array_equal(out[True][2], out[False][2]), "winner features must be the same bits"
+    assert out[True][3] < 0.9 * out[False][3], (out[True][3], out[False][3])
+    # the planted duplicates really occurred, and a winner is never a later copy of an earlier candidate
+    ids = tok.encode_batch(out[True][4][1])                         # stage-2 candidates of the first edit
+    dup = attacks.duplicate_map(np.asarray(ids), len(sents), rho)
+    assert (dup != np.arange(rho)[None, :]).sum() >= 8
+    assert all(dup[b, out[True][1][1][b]] == out[True][1][1][b] for b in range(len(sents)))
+
+
 def test_packed_rows_are_bit_exact(torch_mod, monkeypatch):
     """EOT trimming (compute only rows <= EOT) is exact work skipping: outputs, search decisions and losses are
     bit-identical to the dense 77-row computation, for host tokens (lengths inferred) and device tokens + lens."""

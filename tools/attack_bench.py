@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Throughput of the REAL (string) search: attack_text on B captions, rho=50, k=1, ViT-L, native vs Python host side,
-unconstrained and with --constrain (dictionary = the caption vocabulary + filler words written to a word-list file, the
-regex word tokenizer -- nltk is absent here; the native constraint of leaf_amd/csrc/host_text.cpp covers both)."""
+unconstrained and with --constrain (dictionary = the caption vocabulary + filler words written to a word-list file).
+--tokenizer regex: the stand-in word tokenizer; --tokenizer treebank: nltk.word_tokenize's Treebank pipeline (leaf_amd/treebank.py
+as the Python side -- nltk itself is not installed for the system interpreter -- and its window-local native restatement),
+on captions WITH punctuation (--punct: commas, clitics, quotes, a final period), the case every launch script runs
+(--constrain, scripts/train_leaf_vit*.sh)."""
 import argparse
 import os
 import random
@@ -23,11 +26,22 @@ ap.add_argument("--constrain", action="store_true", help="also time the constrai
 ap.add_argument("--dict-words", type=int, default=236736, help="size of the word list (nltk's `words` corpus has 236,736 entries)")
 ap.add_argument("--batch", type=int, default=128)
 ap.add_argument("--rho", type=int, default=50)
+ap.add_argument("--tokenizer", default="regex", choices=["regex", "treebank"])
+ap.add_argument("--punct", action="store_true", help="captions with punctuation (commas, 's, quotes, brackets, a final period)")
+ap.add_argument("--no-dedupe", action="store_true")
 a = ap.parse_args()
 
 B, rho = a.batch, a.rho
 rng = random.Random(0)
 caps = [" ".join(rng.choice(_SYN_WORDS) for _ in range(rng.randint(4, 16))) for _ in range(B)]
+if a.punct:
+    def deco(c):
+        w = c.split()
+        for _ in range(rng.randint(1, 3)):
+            i = rng.randrange(len(w))
+            w[i] = rng.choice([w[i] + ",", w[i] + "'s", '"' + w[i] + '"', "(" + w[i] + ")", w[i] + "!", w[i] + ":", "don't " + w[i]])
+        return " ".join(w) + rng.choice([".", "", ".", "!"])
+    caps = [deco(c) for c in caps]
 m = create_model("ViT-L-14-quickgelu", seed=1)
 modes = [False, True] if a.constrain else [False]
 if a.constrain:
@@ -37,7 +51,7 @@ if a.constrain:
     path = os.path.join(tempfile.gettempdir(), "leaf_words.txt")
     with open(path, "w") as f:
         f.write("\n".join(sorted(filler)))
-    attacks.set_dictionary(attacks.Dictionary.from_file(path))
+    attacks.set_dictionary(attacks.Dictionary.from_file(path, tokenizer=a.tokenizer))
 for constrain in modes:
     for name, tok in (("python", SimpleTokenizer()), ("native", NativeTokenizer())):
         anchor = m.encode_text(tok.encode_batch(caps))
@@ -46,10 +60,14 @@ for constrain in modes:
             np.random.seed(it)
             torch.cuda.synchronize()
             t0 = time.time()
-            feats, adv = attacks.attack_text(m, tok, caps, anchor, objective="l2", n=rho, k=1, constrain=constrain)
+            rows0 = m.rows_scored
+            feats, adv = attacks.attack_text_leaf(m, tok, caps, anchor, objective="l2", n=rho, k=1, constrain=constrain,
+                                                  dedupe=not a.no_dedupe)
+            rows = m.rows_scored - rows0
             torch.cuda.synchronize()
             ts.append(time.time() - t0)
         dt = min(ts[1:])
         changed = sum(x != y for x, y in zip(adv, caps))
-        print(f"{name:6s} constrain={int(constrain)}: attack_text B={B} rho={rho} k=1: {dt * 1e3:.1f} ms -> {B / dt:.0f} captions/s "
-              f"(search only; {changed}/{B} captions changed)", flush=True)
+        print(f"{name:6s} constrain={int(constrain)} tokenizer={a.tokenizer} punct={int(a.punct)} dedupe={int(not a.no_dedupe)}: attack_text B={B} "
+              f"rho={rho} k=1: {dt * 1e3:.1f} ms -> {B / dt:.0f} captions/s (search only; {changed}/{B} captions changed; {rows} rows scored)",
+              flush=True)
