@@ -37,6 +37,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS_16BIT = 2500.0  # MI355X dense bf16/fp16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_HBM_GBS = 8000.0       # HBM3E spec peak (same table; ~6.3 TB/s achievable)
+TRAFFIC_FILE = "r03_traffic.json"   # PMC summary of the dominant kernel (tools/pmc_passes.sh, tools/pmc_summary.py)
 FAMILY = {0: "gemm_nt_kernel", 1: "gemm_nt256_kernel", 4: "gemm_nt256_half_kernel", 6: "gemm_nt64_ring_kernel", 7: "gemm_nt128pp_kernel"}
 EPI_NAMES = {0: "store16", 1: "act16", 2: "resid32", 3: "store32", 4: "actgrad16", 5: "lnfold16", 6: "lnfold_act16", 7: "resid32+x16+stats"}
 
@@ -331,16 +332,20 @@ def main():
         value = B * world * args.steps / dt
         traffic, traffic_note = None, "no PMC summary under profiles/ for this kernel build"
         try:    # HBM bytes per launch of the dominant kernel from the committed PMC passes; only for the build they were taken on
-            with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)) as f:
                 tj = json.load(f)
             default_cfg = not args.dense and not args.no_prefix_reuse and args.model == "ViT-L-14-quickgelu" and B == 128 \
                 and args.k_adv == 1 and args.attack == "leaf"
             if tj.get("kernel") == dom_name and tj.get("kernel_sources_sha16") == kernel_sources_hash() and default_cfg:
                 traffic = tj["traffic_bytes_per_launch"]
                 traffic_note = ("HBM bytes per launch, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) * 1024, separate passes, "
-                                "profiles/r02_traffic.json (same kernel sources, sha16 " + tj["kernel_sources_sha16"] + ")")
+                                "profiles/" + TRAFFIC_FILE + " (same kernel sources, sha16 " + tj["kernel_sources_sha16"] + "; that run's own "
+                                f"algorithmic bytes per launch: {tj.get('algorithmic_bytes_per_launch')})")
             elif tj.get("kernel_sources_sha16") != kernel_sources_hash():
-                traffic_note = "profiles/r02_traffic.json was taken on different kernel sources: not attached"
+                traffic_note = "profiles/" + TRAFFIC_FILE + " was taken on different kernel sources: not attached"
+            elif not default_cfg:
+                traffic_note = ("profiles/" + TRAFFIC_FILE + " holds the default configuration (configs[1]); no PMC pass exists for this one: "
+                                "tools/pmc_passes.sh + tools/pmc_summary.py produce it")
         except (OSError, ValueError, KeyError):
             pass
         out = {
@@ -403,6 +408,9 @@ def main():
             oracle_name = args.model if args.model in ("ViT-L-14", "ViT-L-14-quickgelu", "ViT-H-14", "ViT-g-14", "ViT-bigG-14") else "ViT-L-14"
             out["cpu_baseline"] = cpu_baseline(oracle_name, args.rho, args.k_adv, args.cpu_batch, seed=1234, budget_s=args.cpu_budget_s)
         print(json.dumps(out), flush=True)
+        if os.environ.get("LEAF_BENCH_JSON_OUT"):     # the PMC passes keep the line of THEIR run (tools/pmc_passes.sh): own algorithmic bytes
+            with open(os.environ["LEAF_BENCH_JSON_OUT"], "w") as f:
+                json.dump(out, f)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -232,6 +232,10 @@ int leaf_tok_constrain(leaf_dict_t d, int tokenizer_kind, const char* const* sen
  * Returns 0; 2 when the text is declined (kind 1: non-ASCII, or a lone '.' ends a chunk inside the text, where the result would
  * depend on nltk's trained Punkt sentence splitter); 1 on bad arguments. */
 int leaf_tok_word_tokens(int tokenizer_kind, const char* text, int len, char* out, int cap, int* out_len);
+/* dup_of[b * rho + r] = first r' <= r with tokens[b, r', :] == tokens[b, r, :] (SURVEY 8f-2 dedupe: src/open_clip/tokenizer.py:83-85,139
+ * lower-cases and collapses whitespace, so distinct edits can tokenise identically; first index wins as in torch.argmax,
+ * utils_attacks.py:348,386).  tokens int32 [B, rho, ctx] on the host. */
+int leaf_tok_duplicate_map(const int32_t* tokens, int B, int rho, int ctx, int32_t* dup_of, int n_threads);
 
 /* ---- per-launch GEMM timing (bench.py roofline): between begin/end every GEMM launch is bracketed by HIP events on
  * its stream; end() sums duration / algorithmic FLOPs / algorithmic bytes / launches per key = kernel_family*16 + operand_dtype*8 + epilogue id

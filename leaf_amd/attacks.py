@@ -230,14 +230,13 @@ def duplicate_map(toks: np.ndarray, B: int, n: int) -> np.ndarray:
     tokenizer lower-cases and collapses whitespace (src/open_clip/tokenizer.py:83-85,139), so stage 2's 'a' / 'A', a space
     inserted next to a space and with-replacement draws (utils_attacks.py:317: replace = rho > 2 len + 1) all give identical
     id rows -- and identical losses: only the first needs computing."""
-    t = np.ascontiguousarray(toks.reshape(B, n, -1))
-    dup = np.tile(np.arange(n, dtype=np.int64), (B, 1))
-    keys = t.view(np.dtype((np.void, t.dtype.itemsize * t.shape[-1]))).reshape(B, n)
-    for b in range(B):
-        _, first, inv = np.unique(keys[b], return_index=True, return_inverse=True)
-        # np.unique's return_index is the first occurrence in the ORIGINAL order
-        dup[b] = first[inv.reshape(-1)]
-    return dup
+    from . import _lib
+    t = np.ascontiguousarray(toks.reshape(B, n, -1), dtype=np.int32)
+    dup = np.empty((B, n), dtype=np.int32)
+    rc = _lib.lib().leaf_tok_duplicate_map(t.ctypes.data, B, n, t.shape[-1], dup.ctypes.data, 1)
+    if rc != 0:
+        raise _lib.LeafHipError(f"leaf_tok_duplicate_map failed ({rc})")
+    return dup.astype(np.int64)
 
 
 def attack_text_leaf(model, tokenizer, sentences, anchor_features, device=None, objective="l2", n=10, k=1,
@@ -278,11 +277,12 @@ def attack_text_leaf(model, tokenizer, sentences, anchor_features, device=None, 
             lens[is_dup] = (base.argmax(-1) + 1)[rep]
         pl = pl.copy()
         pl[is_dup] = toks.shape[-1]                          # nothing differs from the clean caption
-        dup_dev = torch.from_numpy(dup).to(anchor_features.device)
+        dup_dev = torch.from_numpy(dup).pin_memory().to(anchor_features.device, non_blocking=True)
         ids_k, feat, loss = model.score_candidates(toks, anchor_features, n, objective, want_features=want_features, want_loss=True,
                                                    seq_lens=lens, prefix_lens=pl, kv=kv)
         ids = loss.gather(1, dup_dev).argmax(-1)             # first maximum wins
-        ids_h, ids_k_h = ids.cpu().numpy(), ids_k.cpu().numpy()
+        both = torch.stack([ids.to(torch.int64), ids_k.to(torch.int64)]).cpu().numpy()
+        ids_h, ids_k_h = both[0], both[1]
         if want_features and (ids_h != ids_k_h).any():
             # (only when the clean caption itself out-scored every candidate in a slot it was lent: re-encode the winners;
             # rows are bit-identical whichever launch computes them)

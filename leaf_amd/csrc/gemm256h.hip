@@ -487,8 +487,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
                     const float gq = row16_sum(lnfold_dev4(v.x, v.y, v.z, v.w, gs * (1.0f / 64.0f)));
                     if (m < p.M) {
                         typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+#ifdef LEAF_X16_REGULAR   // A/B build: the 16-bit copy (re-read by the next GEMM) through the cache hierarchy instead of around it
+                        *(u32x2_t*)((u16*)p.x16 + (size_t)m * p.ldx16 + nb + ((pc ^ (row & 15)) << 2)) =
+                            __builtin_bit_cast(u32x2_t, pack4<TT>(v.x, v.y, v.z, v.w));
+#else
                         __builtin_nontemporal_store(__builtin_bit_cast(u32x2_t, pack4<TT>(v.x, v.y, v.z, v.w)),
                                                     (u32x2_t*)((u16*)p.x16 + (size_t)m * p.ldx16 + nb + ((pc ^ (row & 15)) << 2)));
+#endif
                         if (pc == 0) p.stat_out[(size_t)(nb >> 6) * p.stat_ld + m] = float2{gs, gq};
                     }
                 }

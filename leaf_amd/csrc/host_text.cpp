@@ -710,3 +710,27 @@ extern "C" int leaf_tok_word_tokens(int kind, const char* text, int len, char* o
     *out_len = (int)joined.size();
     return 0;
 }
+
+// dup_of[b * rho + r] = the first r' <= r whose token row equals candidate r's (the tokenizer lower-cases and
+// collapses whitespace, so different edits can give identical id rows; only the first needs computing).  Exact: rows with equal
+// hashes are compared element-wise.
+extern "C" int leaf_tok_duplicate_map(const int32_t* tokens, int B, int rho, int ctx, int32_t* dup_of, int n_threads) {
+    if (!tokens || !dup_of || B < 1 || rho < 1 || ctx < 1) return 1;
+    if (n_threads < 1) n_threads = 1;
+    parallel_for(B, n_threads, [&](int b, int) {
+        const int32_t* t = tokens + (size_t)b * rho * ctx;
+        int32_t* d = dup_of + (size_t)b * rho;
+        std::vector<uint64_t> h(rho);
+        for (int r = 0; r < rho; ++r) {
+            // position-weighted sum (independent terms: vectorises; a serial FNV chain cost 0.5 ms per stage)
+            uint64_t x = 0;
+            const int32_t* row = t + (size_t)r * ctx;
+            for (int i = 0; i < ctx; ++i) x += (uint64_t)(uint32_t)row[i] * (0x9E3779B97F4A7C15ull * (uint64_t)(2 * i + 1));
+            h[r] = x;
+            d[r] = r;
+            for (int q = 0; q < r; ++q)
+                if (h[q] == x && d[q] == q && memcmp(t + (size_t)q * ctx, row, (size_t)ctx * 4) == 0) { d[r] = q; break; }
+        }
+    });
+    return 0;
+}

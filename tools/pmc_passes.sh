@@ -6,7 +6,7 @@ set -e
 OUT=$1; shift
 export TMPDIR=/tmp
 BENCH="python3 $PWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-dense-leg $*"
-run() { name=$1; shift; rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -o run -- $BENCH > $OUT/$name.log 2>&1; echo "pass $name done"; }
+run() { name=$1; shift; export LEAF_BENCH_JSON_OUT=$PWD/$OUT/$name.bench.json; rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -o run -- $BENCH > $OUT/$name.log 2>&1; echo "pass $name done"; }
 mkdir -p $OUT
 run sq1 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE
 run sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS GRBM_GUI_ACTIVE

@@ -1,6 +1,10 @@
 """Summarise rocprofv3 PMC passes into the per-kernel CSV / traffic JSON kept under profiles/.
 
-    python tools/pmc_summary.py FETCH_DIR WRITE_DIR OUT_PREFIX [KERNEL_SUBSTR]
+    python tools/pmc_summary.py FETCH_DIR WRITE_DIR OUT_PREFIX [KERNEL_SUBSTR] [BENCH_JSON]
+
+BENCH_JSON: the line bench.py printed in the FETCH pass (tools/pmc_passes.sh sets LEAF_BENCH_JSON_OUT): the algorithmic bytes per
+launch of the same kernel in the SAME run are stored beside the measured traffic (the step is data dependent, a short PMC run
+and a long timing run process different row counts).
 
 FETCH_DIR / WRITE_DIR are the `-d` directories of two SEPARATE passes
 (`rocprofv3 --pmc FETCH_SIZE --kernel-trace …` and `--pmc WRITE_SIZE --kernel-trace …`) of the same bench command.
@@ -47,7 +51,8 @@ def short(name):
 
 def main():
     fd, wd, out = sys.argv[1:4]
-    want = sys.argv[4] if len(sys.argv) > 4 else None
+    want = sys.argv[4] if len(sys.argv) > 4 and sys.argv[4] else None
+    bench_json = sys.argv[5] if len(sys.argv) > 5 else None
     fe, wr = per_kernel(fd, "FETCH_SIZE"), per_kernel(wd, "WRITE_SIZE")
     write_csv(out + "_pmc_fetch.csv", fe, "FETCH_SIZE")
     write_csv(out + "_pmc_write.csv", wr, "WRITE_SIZE")
@@ -55,6 +60,12 @@ def main():
     k = max(gemms, key=lambda x: gemms[x][0])
     fkb, wkb = fe[k][0] / fe[k][1], wr[k][0] / wr[k][1]
     from bench import kernel_sources_hash
+    algo = None
+    if bench_json and os.path.exists(bench_json):
+        bj = json.load(open(bench_json))
+        if bj["roofline"]["kernel"].split(" ")[0] == short(k):
+            algo = bj["roofline"]["algorithmic_bytes_per_launch"]
+    traffic = (2 * fkb + wkb) * 1024
     json.dump({
         "kernel": short(k),
         "kernel_sources_sha16": kernel_sources_hash(),   # bench.py attaches this summary only to lines from the same kernel sources
@@ -62,7 +73,9 @@ def main():
                   "--no-cpu-baseline --no-dense-leg`, mean over that kernel's dispatches (tools/pmc_summary.py)",
         "fetch_kb_mean": fkb, "write_kb_mean": wkb,
         "correction": "gfx950: FETCH_SIZE counts 128-B requests at 64 B -> doubled (MI355X_MICROARCH.md, HBM)",
-        "traffic_bytes_per_launch": (2 * fkb + wkb) * 1024,
+        "traffic_bytes_per_launch": traffic,
+        "algorithmic_bytes_per_launch": algo,      # of the SAME run (bench.py's line of the FETCH pass), or null
+        "traffic_over_algorithmic": traffic / algo if algo else None,
     }, open(out + "_traffic.json", "w"), indent=1)
     print(short(k), "fetch KB", fkb, "write KB", wkb, "traffic B/launch", (2 * fkb + wkb) * 1024)
 
