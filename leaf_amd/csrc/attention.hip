@@ -95,8 +95,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const u16* __restrict__ q
         if (kt < nt) {
             int row = kt * 16 + r16; row = row < ctx ? row : ctx - 1;
             const u16* kp = rowptr(row) + d + g * 8;
+#ifdef LEAF_DIAG_NOPREFIX   // diagnostic only (wrong results): the cached prefix's K / V are never fetched -- an upper bound on what
+                            // sharing a caption's prefix across its candidates in LDS could save
+            if (row < pfx) { kf[kt][0] = typename TT::vec8{}; kf[kt][1] = typename TT::vec8{}; } else
+#endif
+            {
             kf[kt][0] = __builtin_bit_cast(typename TT::vec8, *(const uint4*)(kp));
             kf[kt][1] = __builtin_bit_cast(typename TT::vec8, *(const uint4*)(kp + 32));
+            }
         }
     }
     // ---- V rows -> LDS by LDS-DMA: piece pc = rows 8 pc .. 8 pc + 7, lane -> (row 8 pc + lane / 8, position lane % 8) fetches the
@@ -109,7 +115,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const u16* __restrict__ q
         for (int key = ctx + vr; key < nt * 16; key += 8) *(uint4*)(vlds + key * V_ROW + vc * 16) = uint4{0u, 0u, 0u, 0u};
         for (int pc = 0; pc < 2 * nt; ++pc) {
             const int key = 8 * pc + vr;
+#ifdef LEAF_DIAG_NOPREFIX
+            if (key < ctx && key >= pfx)
+#else
             if (key < ctx)
+#endif
                 __builtin_amdgcn_global_load_lds((glb_void_t*)(rowptr(key) + 2 * d + ((vc ^ vswz(key)) << 3)),
                                                  (lds_void_t*)(vlds + pc * 8 * V_ROW), 16, 0, 0);
         }

@@ -123,6 +123,8 @@ def search_synthetic(model, anchor: torch.Tensor, base: torch.Tensor, cfg: StepC
             kv = model.encode_text_kv(cur, seq_lens=base_lens) if reuse else None
             best1, _ = model.score_candidates(cand.view(B * cfg.rho, -1), anchor, cfg.rho, "l2", want_features=False,
                                               seq_lens=cand_lens, prefix_lens=pos.reshape(-1) if reuse else None, kv=kv)
+        if os.environ.get("LEAF_DIAG_FIXED_WINNER") == "1":
+            best1 = torch.zeros_like(best1)      # diagnostic A/B runs only: the same row plan whatever the (garbage) scores say
         cand = gen.stage2_device(cur, best1)                             # queued behind stage 1, before the host waits
         pos2 = gen.stage2_positions(pos, best1.cpu().numpy())           # the search's device->host sync (B indices)
         best2, _ = model.score_candidates(cand.view(B * cfg.rho, -1), anchor, cfg.rho, "l2", want_features=False,
