@@ -225,6 +225,17 @@ def _stage_candidates(tokenizer, sentences, z, c, constrain, trace):
     return toks, lens
 
 
+def _choice_range(pop: int, size: int, replace: bool) -> np.ndarray:
+    """``np.random.choice(range(pop), size=size, replace=replace)`` on the GLOBAL numpy RNG, drawing exactly the same numbers from
+    exactly the same stream: numpy's legacy ``RandomState.choice`` without ``p`` is ``permutation(pop)[:size]`` (no replacement) or
+    ``randint(0, pop, size)`` (with), and indexing ``range(pop)`` with the result is the identity.  The direct forms skip the
+    range -> array conversion, which costs more than the draw (2 x 128 calls per search: several ms of a 33-ms search);
+    ``tests/test_host_cpu.py::test_rng_draws_are_stream_identical`` compares the streams, the reference traces replay through it."""
+    if replace:
+        return np.random.randint(0, pop, size=size)
+    return np.random.permutation(pop)[:size]
+
+
 def duplicate_map(toks: np.ndarray, B: int, n: int) -> np.ndarray:
     """dup_of[b, r] = the first r' <= r whose token row equals candidate r's (r itself when the row is new).  The CLIP
     tokenizer lower-cases and collapses whitespace (src/open_clip/tokenizer.py:83-85,139), so stage 2's 'a' / 'A', a space
@@ -241,84 +252,137 @@ def duplicate_map(toks: np.ndarray, B: int, n: int) -> np.ndarray:
 
 def attack_text_leaf(model, tokenizer, sentences, anchor_features, device=None, objective="l2", n=10, k=1,
                      V=DEFAULT_V, constrain=False, debug=False, return_trace: Optional[list] = None,
-                     return_picks: Optional[list] = None, dedupe: bool = True):
+                     return_picks: Optional[list] = None, dedupe: bool = True, pipeline: Optional[int] = None):
     """LEAF attack on a batch of sentences.  ``model`` is a ``leaf_amd.model.LeafCLIPText`` (anything with
     ``score_candidates``); ``anchor_features`` a float32 CUDA tensor [B, D].  Returns
     ``(best_features [B,D], adversarial sentences)`` like the reference.  The numpy global RNG is consumed exactly as
-    the reference does (one ``np.random.choice`` per sentence and stage, utils_attacks.py:317,236)."""
+    the reference does (one draw per sentence and stage, utils_attacks.py:317,236).
+
+    ``pipeline`` (default 2 for B >= 64 with prefix reuse, else 1): the captions are handled in that many contiguous groups
+    whose stages are interleaved -- while the GPU scores one group's candidates the host mutates, tokenises and constrains the
+    next group's (the GPU used to idle for every stage's host preparation: a quarter of a 33-ms search).  Captions are
+    independent and every row has the same bits whichever launch computes it, so the result does not depend on the grouping
+    (``tests/test_gpu_forward.py::test_token_identical_candidates_are_computed_once``); all random draws of an edit are made up
+    front in the reference's order (stage-1 positions for every sentence, then stage-2 characters for every sentence: the
+    reference draws nothing in between)."""
+    import torch
     sentences = list(sentences)
     B = len(sentences)
     if objective in ("dissim", "sim"):
         anchor_features /= anchor_features.norm(dim=-1, keepdim=True)   # in place, as the reference does
-    best_feat = None
     Varr = np.asarray(V, dtype=np.int32)
     reuse = hasattr(model, "encode_text_kv") and getattr(model, "trim_rows", False)
     dedupe = dedupe and reuse
+    if pipeline is None:
+        pipeline = 2 if (reuse and B >= 64) else 1
+    if return_trace is not None or not reuse:
+        pipeline = 1                      # a trace lists a stage's candidates of ALL sentences in one piece
+    pipeline = max(1, min(int(pipeline), B))
+    bounds = np.linspace(0, B, pipeline + 1).astype(int)
+    groups = [np.arange(bounds[g], bounds[g + 1]) for g in range(pipeline)]
+    dev = anchor_features.device
 
-    def score(toks, lens, base, kv, want_features):
-        """One stage's scoring call -> (winner indices [B] on the host, winner features or None).  With ``dedupe`` a candidate
-        whose id row repeats an earlier candidate's of the same caption is not computed again: its slot is handed to the
-        no-op edit (the clean caption: ONE row under prefix reuse), the loss of its first occurrence is copied into it and the
-        arg-max runs over the completed [B, rho] losses -- first index wins, so the first occurrence beats its copies exactly as
-        in torch.argmax over the reference's full loss matrix (utils_attacks.py:348,386)."""
-        import torch
-        pl = prefix_lens(toks, base) if reuse else None
-        dup = duplicate_map(toks, B, n) if dedupe else None
-        if dup is None or not (dup != np.arange(n)[None, :]).any():
-            ids, feat = model.score_candidates(toks, anchor_features, n, objective, want_features=want_features, seq_lens=lens,
-                                               prefix_lens=pl, kv=kv)
-            return ids.cpu().numpy(), feat
-        is_dup = (dup != np.arange(n)[None, :]).reshape(-1)
-        toks = toks.copy().reshape(B * n, -1)
-        rep = np.repeat(np.arange(B), n)[is_dup]
-        toks[is_dup] = base[rep]
-        if lens is not None:
-            lens = lens.copy()
-            lens[is_dup] = (base.argmax(-1) + 1)[rep]
-        pl = pl.copy()
-        pl[is_dup] = toks.shape[-1]                          # nothing differs from the clean caption
-        dup_dev = torch.from_numpy(dup).pin_memory().to(anchor_features.device, non_blocking=True)
-        ids_k, feat, loss = model.score_candidates(toks, anchor_features, n, objective, want_features=want_features, want_loss=True,
-                                                   seq_lens=lens, prefix_lens=pl, kv=kv)
-        ids = loss.gather(1, dup_dev).argmax(-1)             # first maximum wins
-        both = torch.stack([ids.to(torch.int64), ids_k.to(torch.int64)]).cpu().numpy()
-        ids_h, ids_k_h = both[0], both[1]
-        if want_features and (ids_h != ids_k_h).any():
-            # (only when the clean caption itself out-scored every candidate in a slot it was lent: re-encode the winners;
-            # rows are bit-identical whichever launch computes them)
-            feat = model.encode_text(toks.reshape(B, n, -1)[np.arange(B), ids_h])
-        return ids_h, feat
-
-    def prefix_lens(toks, base):
+    def prefix_lens(toks, base, Bg):
         """leading positions where a candidate's ids equal its clean caption's (>= 1: SOT)"""
-        neq = toks.reshape(B, n, -1) != base[:, None, :]
+        neq = toks.reshape(Bg, n, -1) != base[:, None, :]
         first = neq.argmax(-1)
         first[~neq.any(-1)] = toks.shape[-1]
         return first.reshape(-1)
 
+    def launch(toks, lens, base, kv, anchor_g, want_features):
+        """Queue one stage's scoring of one group; returns finish() -> (winner indices [Bg] on the host, winner features or None).
+        The indices travel to pinned host memory right behind the scoring launches and finish() waits for THAT copy's event
+        only, so work queued later (the next group's scoring) does not delay it.  With ``dedupe`` a candidate whose id row
+        repeats an earlier candidate's of the same caption is not computed again: its slot is handed to the no-op edit (the
+        clean caption: ONE row under prefix reuse), the loss of its first occurrence is copied into it and the arg-max runs over
+        the completed [Bg, rho] losses -- first index wins, so the first occurrence beats its copies exactly as in torch.argmax
+        over the reference's full loss matrix (utils_attacks.py:348,386)."""
+        Bg = anchor_g.shape[0]
+        pl = prefix_lens(toks, base, Bg) if reuse else None
+        dup = duplicate_map(toks, Bg, n) if dedupe else None
+        has_dup = dup is not None and bool((dup != np.arange(n)[None, :]).any())
+        if not has_dup:
+            ids, feat = model.score_candidates(toks, anchor_g, n, objective, want_features=want_features, seq_lens=lens,
+                                               prefix_lens=pl, kv=kv)
+            both = ids.to(torch.int64)[None, :]
+        else:
+            is_dup = (dup != np.arange(n)[None, :]).reshape(-1)
+            toks = toks.copy().reshape(Bg * n, -1)
+            rep = np.repeat(np.arange(Bg), n)[is_dup]
+            toks[is_dup] = base[rep]
+            if lens is not None:
+                lens = lens.copy()
+                lens[is_dup] = (base.argmax(-1) + 1)[rep]
+            pl = pl.copy()
+            pl[is_dup] = toks.shape[-1]                          # nothing differs from the clean caption
+            dup_dev = torch.from_numpy(dup).pin_memory().to(dev, non_blocking=True)
+            ids_k, feat, loss = model.score_candidates(toks, anchor_g, n, objective, want_features=want_features, want_loss=True,
+                                                       seq_lens=lens, prefix_lens=pl, kv=kv)
+            ids = loss.gather(1, dup_dev).argmax(-1)             # first maximum wins
+            both = torch.stack([ids.to(torch.int64), ids_k.to(torch.int64)])
+        host = torch.empty(both.shape, dtype=torch.int64, pin_memory=True)
+        host.copy_(both, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+
+        def finish():
+            nonlocal feat
+            ev.synchronize()
+            h = host.numpy()
+            ids_h = h[0].copy()
+            if has_dup and want_features and (ids_h != h[1]).any():
+                # (only when the clean caption itself out-scored every candidate in a slot it was lent: re-encode the winners;
+                # rows are bit-identical whichever launch computes them)
+                feat = model.encode_text(toks.reshape(Bg, n, -1)[np.arange(Bg), ids_h])
+            return ids_h, feat
+        return finish
+
+    best_feat = None
     for _ in range(k):
-        kv = base = None
-        if reuse:   # clean captions once per edit: their per-layer K/V serve both stages' candidates
-            base = tokenizer.encode_batch(sentences)
-            kv = model.encode_text_kv(base)
-        # stage 1: rho random positions, insert / replace-with / delete a space
-        z = np.stack([np.random.choice(range(2 * len(S) + 1), size=n, replace=n > 2 * len(S) + 1) for S in sentences]).astype(np.int32)
-        c = np.full((B, n), ord(' '), dtype=np.int32)
-        positions = z.copy()            # the reference reads the winner's position from the sampled ones (:351-353)
-        toks, lens = _stage_candidates(tokenizer, sentences, z, c, constrain, return_trace)
-        ids_best, _ = score(toks, lens, base, kv, False)
+        base_all = tokenizer.encode_batch(sentences) if reuse else None
+        # every draw of this edit, in the reference's order: stage-1 positions (utils_attacks.py:317), stage-2 characters (:236)
+        z1 = np.stack([_choice_range(2 * len(S) + 1, n, n > 2 * len(S) + 1) for S in sentences]).astype(np.int32)
+        u2 = np.stack([_choice_range(len(V), n, n > len(V)) for _ in sentences])
+        kvs, st1 = [], []
+        for gi, g in enumerate(groups):
+            sg = [sentences[b] for b in g]
+            base = base_all[g] if reuse else None
+            # clean captions once per edit: their per-layer K/V serve both stages' candidates (queued first: it runs while the
+            # host prepares the first stage)
+            kv = model.encode_text_kv(base, slot=gi) if reuse else None
+            kvs.append((sg, base, kv))
+            # stage 1: rho random positions, insert / replace-with / delete a space
+            z = z1[g].copy()
+            c = np.full((len(g), n), ord(' '), dtype=np.int32)
+            positions = z.copy()        # the reference reads the winner's position from the sampled ones (:351-353)
+            toks, lens = _stage_candidates(tokenizer, sg, z, c, constrain, return_trace)
+            st1.append((positions, launch(toks, lens, base, kv, anchor_features[g[0]:g[-1] + 1], False)))
+        st2, picks1 = [], []
+        for gi, g in enumerate(groups):
+            sg, base, kv = kvs[gi]
+            positions, fin = st1[gi]
+            ids_best, _ = fin()
+            picks1.append(ids_best)
+            best_pos = positions[np.arange(len(g)), ids_best]
+            # stage 2: rho random characters at the chosen position
+            c = Varr[u2[g]]
+            z = np.repeat(best_pos[:, None], n, axis=1).astype(np.int32)
+            toks, lens = _stage_candidates(tokenizer, sg, z, c, constrain, return_trace)
+            st2.append((z, c, launch(toks, lens, base, kv, anchor_features[g[0]:g[-1] + 1], True)))
         if return_picks is not None:
-            return_picks.append(ids_best.copy())
-        best_pos = positions[np.arange(B), ids_best]
-        # stage 2: rho random characters at the chosen position
-        u = np.stack([np.random.choice(range(len(V)), size=n, replace=(n > len(V))) for _ in sentences])
-        c = Varr[u]
-        z = np.repeat(best_pos[:, None], n, axis=1).astype(np.int32)
-        toks, lens = _stage_candidates(tokenizer, sentences, z, c, constrain, return_trace)
-        ids_best, best_feat = score(toks, lens, base, kv, True)
+            return_picks.append(np.concatenate(picks1))
+        new_sentences, feats, picks2 = [], [], []
+        for gi, g in enumerate(groups):
+            sg = kvs[gi][0]
+            z, c, fin = st2[gi]
+            ids_best, f = fin()
+            picks2.append(ids_best)
+            feats.append(f)
+            new_sentences += [_apply_edit(S, int(z[b, ids_best[b]]), int(c[b, ids_best[b]])) for b, S in enumerate(sg)]
         if return_picks is not None:
-            return_picks.append(ids_best.copy())
-        sentences = [_apply_edit(S, int(z[b, ids_best[b]]), int(c[b, ids_best[b]])) for b, S in enumerate(sentences)]
+            return_picks.append(np.concatenate(picks2))
+        sentences = new_sentences
+        best_feat = feats[0] if len(feats) == 1 else torch.cat(feats, 0)
         if debug:
             print(sentences[0])
     return best_feat, sentences

@@ -275,9 +275,11 @@ class LeafCLIPText:
                    "leaf_text_forward")
         return out
 
-    def encode_text_kv(self, text, seq_lens=None, want_features: bool = False):
+    def encode_text_kv(self, text, seq_lens=None, want_features: bool = False, slot: int = 0):
         """Forward of the clean captions that keeps every layer's q|k|v rows for prefix reuse by the search
-        (include/leaf_hip.h, "prefix reuse").  Returns an opaque cache (and the features when asked)."""
+        (include/leaf_hip.h, "prefix reuse").  Returns an opaque cache (and the features when asked).  ``slot``: which of the
+        model's cache buffers to fill -- caches of different slots can be alive at the same time (the string search pipelines
+        groups of captions, leaf_amd/attacks.py)."""
         if not self._packed:
             self.pack()
         if seq_lens is None:
@@ -290,17 +292,26 @@ class LeafCLIPText:
         t = self._tokens(text)
         n = t.shape[0]
         need = int(cu[-1]) * 3 * self.cfg.width * 2 * self.cfg.layers
-        if getattr(self, "_kv", None) is None or self._kv.numel() < need:
-            self._kv = None
-            with torch.cuda.device(self.device):
-                self._kv = torch.empty(max(need, 1), dtype=torch.uint8, device=self.device)
+        if slot == 0:
+            if getattr(self, "_kv", None) is None or self._kv.numel() < need:
+                self._kv = None
+                with torch.cuda.device(self.device):
+                    self._kv = torch.empty(max(need, 1), dtype=torch.uint8, device=self.device)
+            kvbuf = self._kv
+        else:
+            slots = self.__dict__.setdefault("_kv_slots", {})
+            if slots.get(slot) is None or slots[slot].numel() < need:
+                slots[slot] = None
+                with torch.cuda.device(self.device):
+                    slots[slot] = torch.empty(max(need, 1), dtype=torch.uint8, device=self.device)
+            kvbuf = slots[slot]
         out = torch.empty(n, self.cfg.embed_dim, dtype=torch.float32, device=self.device) if want_features else None
         ws = self._workspace(0, n)
         _lib.check(self._lib.leaf_text_forward_kv(self._h, _ptr(self.flat), _ptr(self.w16), _ptr(t),
                                                   C.c_void_p(lens.ctypes.data), _ptr(cu_dev), n, _ptr(out), 0,
-                                                  _ptr(self._kv), self._kv.numel(), _ptr(ws), ws.numel(), self._stream()),
+                                                  _ptr(kvbuf), kvbuf.numel(), _ptr(ws), ws.numel(), self._stream()),
                    "leaf_text_forward_kv")
-        cache = {"kv": self._kv, "base_cu": cu_dev, "base_rows": int(cu[-1]), "lens": lens, "n": n}
+        cache = {"kv": kvbuf, "base_cu": cu_dev, "base_rows": int(cu[-1]), "lens": lens, "n": n}
         return (cache, out) if want_features else cache
 
     def score_candidates(self, tokens, anchor: torch.Tensor, rho: int, objective: str = "l2", want_features=True,

@@ -199,6 +199,15 @@ def test_token_identical_candidates_are_computed_once(torch_mod, native):
     dup = attacks.duplicate_map(np.asarray(ids), len(sents), rho)
     assert (dup != np.arange(rho)[None, :]).sum() >= 8
     assert all(dup[b, out[True][1][1][b]] == out[True][1][1][b] for b in range(len(sents)))
+    # the grouped pipeline (host preparation of one group of captions beside the GPU scoring of another): captions are
+    # independent and rows have the same bits whichever launch computes them -> nothing may depend on the grouping
+    for pipe in (1, 2, 3):
+        np.random.seed(7)
+        picks = []
+        feats, adv = attacks.attack_text_leaf(m, tok, list(sents), anchor.clone(), objective="l2", n=rho, k=k, V=attacks.DEFAULT_V,
+                                              return_picks=picks, pipeline=pipe)
+        assert adv == out[True][0] and [p.tolist() for p in picks] == out[True][1], pipe
+        assert np.array_equal(feats.cpu().numpy(), out[True][2]), pipe
 
 
 def test_packed_rows_are_bit_exact(torch_mod, monkeypatch):

@@ -189,3 +189,19 @@ def test_wgrad_dma_asm_owns_m0(tmp_path):
         for i in dma:
             assert body[i - 1].startswith("s_mov_b32 m0"), body[i - 1]
         assert sum("m0" in l for l in body) == len(dma)
+
+
+def test_rng_draws_are_stream_identical():
+    """attacks._choice_range replaces np.random.choice(range(N), size, replace) (utils_attacks.py:236,317) by the two primitives numpy's
+    legacy RandomState.choice is made of: the numbers AND the state left behind must be identical, or every later draw of a run
+    would differ from the reference's."""
+    from leaf_amd import attacks
+    for seed, (pop, size) in enumerate([(5, 50), (121, 50), (96, 50), (96, 120), (1, 3), (51, 50), (50, 50), (49, 50)]):
+        for replace in (size > pop, True) if size <= pop else (True,):
+            np.random.seed(seed)
+            want = [np.random.choice(range(pop), size=size, replace=replace) for _ in range(3)]
+            tail_w = np.random.random(4)
+            np.random.seed(seed)
+            got = [attacks._choice_range(pop, size, replace) for _ in range(3)]
+            tail_g = np.random.random(4)
+            assert all(np.array_equal(a, b) for a, b in zip(want, got)) and np.array_equal(tail_w, tail_g), (pop, size, replace)

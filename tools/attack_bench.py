@@ -29,6 +29,7 @@ ap.add_argument("--rho", type=int, default=50)
 ap.add_argument("--tokenizer", default="regex", choices=["regex", "treebank"])
 ap.add_argument("--punct", action="store_true", help="captions with punctuation (commas, 's, quotes, brackets, a final period)")
 ap.add_argument("--no-dedupe", action="store_true")
+ap.add_argument("--pipeline", type=int, default=None, help="caption groups interleaved in the search (default: 2 for B >= 64)")
 a = ap.parse_args()
 
 B, rho = a.batch, a.rho
@@ -62,12 +63,12 @@ for constrain in modes:
             t0 = time.time()
             rows0 = m.rows_scored
             feats, adv = attacks.attack_text_leaf(m, tok, caps, anchor, objective="l2", n=rho, k=1, constrain=constrain,
-                                                  dedupe=not a.no_dedupe)
+                                                  dedupe=not a.no_dedupe, pipeline=a.pipeline)
             rows = m.rows_scored - rows0
             torch.cuda.synchronize()
             ts.append(time.time() - t0)
         dt = min(ts[1:])
         changed = sum(x != y for x, y in zip(adv, caps))
-        print(f"{name:6s} constrain={int(constrain)} tokenizer={a.tokenizer} punct={int(a.punct)} dedupe={int(not a.no_dedupe)}: attack_text B={B} "
+        print(f"{name:6s} constrain={int(constrain)} tokenizer={a.tokenizer} punct={int(a.punct)} dedupe={int(not a.no_dedupe)} pipeline={a.pipeline}: attack_text B={B} "
               f"rho={rho} k=1: {dt * 1e3:.1f} ms -> {B / dt:.0f} captions/s (search only; {changed}/{B} captions changed; {rows} rows scored)",
               flush=True)
