@@ -252,7 +252,8 @@ def duplicate_map(toks: np.ndarray, B: int, n: int) -> np.ndarray:
 
 def attack_text_leaf(model, tokenizer, sentences, anchor_features, device=None, objective="l2", n=10, k=1,
                      V=DEFAULT_V, constrain=False, debug=False, return_trace: Optional[list] = None,
-                     return_picks: Optional[list] = None, dedupe: bool = True, pipeline: Optional[int] = None):
+                     return_picks: Optional[list] = None, dedupe: bool = True, pipeline: Optional[int] = None,
+                     anchor_ready=None):
     """LEAF attack on a batch of sentences.  ``model`` is a ``leaf_amd.model.LeafCLIPText`` (anything with
     ``score_candidates``); ``anchor_features`` a float32 CUDA tensor [B, D].  Returns
     ``(best_features [B,D], adversarial sentences)`` like the reference.  The numpy global RNG is consumed exactly as
@@ -264,7 +265,8 @@ def attack_text_leaf(model, tokenizer, sentences, anchor_features, device=None, 
     independent and every row has the same bits whichever launch computes it, so the result does not depend on the grouping
     (``tests/test_gpu_forward.py::test_token_identical_candidates_are_computed_once``); all random draws of an edit are made up
     front in the reference's order (stage-1 positions for every sentence, then stage-2 characters for every sentence: the
-    reference draws nothing in between)."""
+    reference draws nothing in between).  ``anchor_ready``: a CUDA event after which ``anchor_features`` is valid (the caller
+    computed it on a side stream); the first scoring launch waits for it, the clean captions' K/V pass before it does not."""
     import torch
     sentences = list(sentences)
     B = len(sentences)
@@ -297,6 +299,10 @@ def attack_text_leaf(model, tokenizer, sentences, anchor_features, device=None, 
         clean caption: ONE row under prefix reuse), the loss of its first occurrence is copied into it and the arg-max runs over
         the completed [Bg, rho] losses -- first index wins, so the first occurrence beats its copies exactly as in torch.argmax
         over the reference's full loss matrix (utils_attacks.py:348,386)."""
+        nonlocal anchor_ready
+        if anchor_ready is not None:
+            torch.cuda.current_stream().wait_event(anchor_ready)
+            anchor_ready = None
         Bg = anchor_g.shape[0]
         pl = prefix_lens(toks, base, Bg) if reuse else None
         dup = duplicate_map(toks, Bg, n) if dedupe else None
@@ -389,8 +395,9 @@ def attack_text_leaf(model, tokenizer, sentences, anchor_features, device=None, 
 
 
 def attack_text(model, tokenizer, sentences, image_features, device=None, objective="l2", n=10, k=1, V=DEFAULT_V,
-                constrain=False, debug=False):
-    return attack_text_leaf(model, tokenizer, sentences, image_features, device, objective, n, k, V, constrain, debug)
+                constrain=False, debug=False, anchor_ready=None):
+    return attack_text_leaf(model, tokenizer, sentences, image_features, device, objective, n, k, V, constrain, debug,
+                            anchor_ready=anchor_ready)
 
 
 # ----------------------------------------------------------------------------- optional embedding-space PGD (a12)

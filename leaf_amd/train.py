@@ -289,10 +289,19 @@ def train_one_epoch_text_only(model, model_frozen, tokenizer, V, data, loss, epo
             scheduler(step)
         _, texts = batch
         model.eval()
-        anchor = model_frozen.encode_text(tokenizer.encode_batch(texts), normalize=normalize_fare)
+        # the anchor forward needs only the captions and the FROZEN weights: it runs on a side stream beside the tail of the
+        # previous step (backward / AdamW / re-pack still queued on this stream) and beside the search's clean-caption K/V pass;
+        # the search's first scoring launch waits for its event (as leaf_amd/step.py does for the token-id step)
+        from .step import _side_stream
+        cur_stream, side = torch.cuda.current_stream(device), _side_stream(device)
+        with torch.cuda.stream(side):
+            anchor = model_frozen.encode_text(tokenizer.encode_batch(texts), normalize=normalize_fare)
+            anchor_ready = torch.cuda.Event()
+            anchor_ready.record(side)
+        anchor.record_stream(cur_stream)
         t0 = time.time()
         _, adv_texts = attack_text(model, tokenizer, texts, anchor, device, objective='l2', n=args.rho, k=args.k_adv,
-                                   V=V, constrain=args.constrain, debug=False)
+                                   V=V, constrain=args.constrain, debug=False, anchor_ready=anchor_ready)
         times.append(time.time() - t0)
         adv_tokens = tokenizer.encode_batch(adv_texts)
         model.train()
