@@ -435,7 +435,8 @@ class LeafCLIPText:
                 # gradient-scaler state + scratch of the guarded optimizer step (include/leaf_hip.h "gradient scaler"): attached to
                 # the handle, so the fp16 backward checks its 16-bit gradient tensors for saturation (LEAF_GRAD_SCALER=0 detaches)
                 self._clip_ws = torch.zeros(_lib.SC_WORDS + 2048, dtype=torch.float32, device=self.device)
-            if os.environ.get("LEAF_GRAD_SCALER", "1") != "0":
+            self._scaler_attached = os.environ.get("LEAF_GRAD_SCALER", "1") != "0"
+            if self._scaler_attached:
                 _lib.check(self._lib.leaf_text_set_grad_scaler(self._h, _ptr(self._clip_ws)), "leaf_text_set_grad_scaler")
             self._packed = False
         return self
@@ -542,6 +543,8 @@ class LeafCLIPText:
         really applied (kept on the device: a skipped step does not advance them, as torch's per-parameter ``step``).
         Returns the 0-d total-norm tensor when clipping or guarding, else None; ``skipped_steps()`` counts skipped steps."""
         self.opt_step += 1
+        # with the gradient scaler attached a saturated backward has poisoned the gradient with a NaN that only the guard stops
+        guard = guard or getattr(self, "_scaler_attached", False)
         if max_norm is not None or guard:
             if getattr(self, "_clip_ws", None) is None:
                 self._clip_ws = torch.zeros(_lib.SC_WORDS + 2048, dtype=torch.float32, device=self.device)

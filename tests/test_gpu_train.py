@@ -213,7 +213,10 @@ def test_non_finite_gradients_skip_the_step(torch_mod):
     norm = m.adamw_step(lr=1e-3, weight_decay=0.1)
     assert bool(torch_mod.isfinite(norm)) and abs(float(norm) - float(good.double().norm())) < 1e-4 * float(norm)
     assert not torch_mod.equal(m.flat, p0) and m.skipped_steps() == 2 and bool(torch_mod.isfinite(m.flat).all())
-    # guard off: the plain kernel (no extra pass over the gradients)
+    # guard off: with the gradient scaler attached (the default for a trainable model) the guard stays on -- a saturated backward
+    # poisons the gradient with a NaN that only the guard stops; without the scaler it is the plain kernel
+    assert m.adamw_step(lr=1e-3, guard=False) is not None
+    m._scaler_attached = False
     assert m.adamw_step(lr=1e-3, guard=False) is None
 
 

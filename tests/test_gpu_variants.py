@@ -13,7 +13,17 @@ VARIANTS = [
     {"LEAF_GEMM256H": "0"},                          # two-stage 256^2 + register-staged kernels instead of the half-stage ring
     {"LEAF_GEMM64_DEEP": "1", "LEAF_GEMM64_MI": "2"},  # 6-slot small-launch ring
     {"LEAF_GEMM64": "0", "LEAF_GEMM_BM64": "1"},     # register-staged 64-row tiles
+    {"LEAF_GEMM_PP": "1", "LEAF_GEMM_PP_MIN_TILES": "32"},   # 128 x 256 tiles, two workgroups per CU (gemm128pp.hip: kept, not dispatched)
 ]
+
+
+def test_pingpong_gemm_rows_have_the_same_bits_as_every_other_kernel():
+    """gemm128pp.hip (the round-3 two-workgroups-per-CU experiment, LEAF_GEMM_PP=1) through the bit-exactness tests of the GEMM
+    family: big launch (ping-pong kernel) against chunked launches (small-launch kernels), all epilogues incl. the LN-folded ones."""
+    full = dict(os.environ, LEAF_GEMM_PP="1", LEAF_GEMM_PP_MIN_TILES="64")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_kernels.py"), "-x", "-q", "-k",
+                        "rows_do_not_depend or lnfold"], env=full, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("env", VARIANTS, ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
