@@ -82,6 +82,36 @@ def const_lr(optimizer, base_lr, warmup_length, steps):
     return _lr_adjuster
 
 
+def const_lr_cooldown(optimizer, base_lr, warmup_length, steps, cooldown_steps, cooldown_power=1.0, cooldown_end_lr=0.):
+    """--lr-scheduler const-cooldown (open_clip_train/scheduler.py:24-41): warm-up, constant, then over the last ``cooldown_steps``
+    a polynomial decay (1 - e / es) ** power from base_lr to cooldown_end_lr."""
+    def _lr_adjuster(step):
+        start = steps - cooldown_steps
+        if step < warmup_length:
+            lr = base_lr * (step + 1) / warmup_length
+        elif step < start:
+            lr = base_lr
+        else:
+            e, es = step - start, steps - start
+            lr = (1 - (e / es)) ** cooldown_power * (base_lr - cooldown_end_lr) + cooldown_end_lr
+        _assign_lr(optimizer, lr)
+        return lr
+    return _lr_adjuster
+
+
+def make_scheduler(args, optimizer, total_steps, num_batches):
+    """train_AT_text_only.py:384-401: --lr-scheduler cosine | const | const-cooldown (the latter needs --epochs-cooldown)."""
+    if args.lr_scheduler == "cosine":
+        return cosine_lr(optimizer, args.lr, args.warmup, total_steps)
+    if args.lr_scheduler == "const":
+        return const_lr(optimizer, args.lr, args.warmup, total_steps)
+    if args.lr_scheduler == "const-cooldown":
+        assert args.epochs_cooldown is not None, "Please specify the number of cooldown epochs for this lr schedule."
+        cooldown_steps = (num_batches // args.accum_freq) * args.epochs_cooldown
+        return const_lr_cooldown(optimizer, args.lr, args.warmup, total_steps, cooldown_steps, args.lr_cooldown_power, args.lr_cooldown_end)
+    raise ValueError(f"Unknown scheduler, {args.lr_scheduler}. Available options are: cosine, const, const-cooldown.")
+
+
 # ----------------------------------------------------------------------------- optimizer
 class LeafAdamW:
     """AdamW over the engine's flat buffers.  ``param_groups`` mirrors the reference's two groups (excluded tensors

@@ -69,3 +69,40 @@ def test_synthetic_and_text_datasets(tmp_path):
     args.rank, args.world_size = 0, 1
     d = T.get_text_data(args)["train"].dataloader
     assert d.num_batches == 3 and all(isinstance(t, str) and t for _, b in d for t in b)
+
+
+def test_lr_schedules_match_the_reference_known_answers(golden_dir):
+    """--lr-scheduler cosine | const | const-cooldown (train_AT_text_only.py:384-401) against values produced by the reference's
+    own open_clip_train/scheduler.py (tests/golden/make_golden_sched.py); both param groups are assigned; an unknown name and a
+    cooldown without --epochs-cooldown are refused as the reference refuses them."""
+    import json
+    import os
+    import types
+    import pytest
+    from leaf_amd import train as T
+    with open(os.path.join(golden_dir, "sched_kat.json")) as f:
+        k = json.load(f)
+
+    class Opt:
+        def __init__(self):
+            self.param_groups = [{"lr": 0.0}, {"lr": 0.0}]
+
+    def args(**kw):
+        base = dict(lr=k["base_lr"], warmup=k["warmup"], accum_freq=1, epochs_cooldown=None, lr_cooldown_power=1.0, lr_cooldown_end=0.0)
+        base.update(kw)
+        return types.SimpleNamespace(**base)
+    nb = 50                                          # batches per epoch: 4 epochs = 200 steps, 1 cooldown epoch = 50 steps
+    makers = {"cosine": args(lr_scheduler="cosine"), "const": args(lr_scheduler="const"),
+              "const-cooldown p=1 end=0": args(lr_scheduler="const-cooldown", epochs_cooldown=1),
+              "const-cooldown p=2 end=1e-6": args(lr_scheduler="const-cooldown", epochs_cooldown=1, lr_cooldown_power=2.0, lr_cooldown_end=1e-6)}
+    for c in k["cases"]:
+        o = Opt()
+        f = T.make_scheduler(makers[c["name"]], o, k["total_steps"], nb)
+        for s_, want in zip(k["steps"], c["values"]):
+            got = f(s_)
+            assert abs(got - want) <= 1e-18 + 1e-12 * abs(want), (c["name"], s_, got, want)
+            assert o.param_groups[0]["lr"] == got and o.param_groups[1]["lr"] == got
+    with pytest.raises(ValueError, match="Unknown scheduler"):
+        T.make_scheduler(args(lr_scheduler="linear"), Opt(), 200, nb)
+    with pytest.raises(AssertionError, match="cooldown epochs"):
+        T.make_scheduler(args(lr_scheduler="const-cooldown"), Opt(), 200, nb)

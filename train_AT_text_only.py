@@ -25,8 +25,8 @@ import torch
 
 from leaf_amd.params import parse_args
 from leaf_amd.tokenizer import get_tokenizer
-from leaf_amd.train import (LATEST_CHECKPOINT_NAME, LeafAdamW, const_lr, cosine_lr, get_latest_checkpoint, get_text_data,
-                            is_master, load_checkpoint, save_checkpoint, train_one_epoch_text_only)
+from leaf_amd.train import (LATEST_CHECKPOINT_NAME, LeafAdamW, get_latest_checkpoint, get_text_data, is_master, load_checkpoint,
+                            make_scheduler, save_checkpoint, train_one_epoch_text_only)
 
 
 def random_seed(seed=42, rank=0):
@@ -113,7 +113,7 @@ def main(argv):
                                else attacks.Dictionary.from_nltk())
     data = get_text_data(args, epoch=start_epoch)
     total_steps = (data["train"].dataloader.num_batches // args.accum_freq) * args.epochs
-    scheduler = (cosine_lr if args.lr_scheduler == "cosine" else const_lr)(optimizer, args.lr, args.warmup, total_steps)
+    scheduler = make_scheduler(args, optimizer, total_steps, data["train"].dataloader.num_batches)
     # frozen anchor model = the weights the run STARTED from (train_AT_text_only.py:439-465)
     frozen = LeafCLIPText(model.cfg, device=device, dtype=dtype)
     if args.resume and args.pretrained:
