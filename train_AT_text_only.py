@@ -52,6 +52,10 @@ def init_distributed_device(args):
 
 def main(argv):
     args = parse_args(argv)
+    if args.lock_text or args.lock_text_unlocked_layers or args.distill_model:
+        # accepted by the parser for command-line compatibility, but they would change WHAT is trained: refuse rather than ignore
+        raise SystemExit("--lock-text / --lock-text-unlocked-layers / --distill-model are not supported by the text-only engine "
+                         "(the reference's CLIP class has no lock_text_tower either: src/open_clip/model.py:256-262)")
     V = [-1] + [ord(c) for c in string.ascii_lowercase + ' ' + string.ascii_uppercase + string.digits + string.punctuation]
     device = init_distributed_device(args)
     if args.name is None:
