@@ -14,6 +14,9 @@
 #include <string.h>
 
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -182,20 +185,83 @@ std::string mutate(const char* s, size_t n, int z, int c) {
     return out;
 }
 
+// Persistent worker pool: a search makes ~10 native calls of 1-2 ms each; creating and joining 16 std::threads per call cost
+// 0.3-0.5 ms of every one of them.  Workers are created once (grown to the largest thread count asked for), sleep on a
+// condition variable between jobs and are joined when the library is unloaded.  One job at a time (the callers are the
+// single Python thread of a rank); the calling thread works as worker 0.
+class WorkerPool {
+public:
+    ~WorkerPool() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_job_.notify_all();
+        for (auto& t : workers_) t.join();
+    }
+    // runs body(t) for t = 0 .. nt-1 concurrently and returns when all are done
+    void run(int nt, const std::function<void(int)>& body) {
+        if (nt <= 1) { body(0); return; }
+        std::unique_lock<std::mutex> lk(m_);
+        while ((int)workers_.size() < nt - 1) {
+            const int id = (int)workers_.size() + 1;
+            workers_.emplace_back([this, id]() { loop(id); });
+        }
+        body_ = &body;
+        job_threads_ = nt;
+        pending_ = nt - 1;
+        ++generation_;
+        lk.unlock();
+        cv_job_.notify_all();
+        body(0);
+        lk.lock();
+        cv_done_.wait(lk, [this]() { return pending_ == 0; });
+        body_ = nullptr;
+    }
+
+private:
+    void loop(int id) {
+        unsigned long seen = 0;
+        std::unique_lock<std::mutex> lk(m_);
+        for (;;) {
+            cv_job_.wait(lk, [&]() { return stop_ || generation_ != seen; });
+            if (stop_) return;
+            seen = generation_;
+            if (id >= job_threads_) continue;          // this job uses fewer workers
+            const std::function<void(int)>* b = body_;
+            lk.unlock();
+            (*b)(id);
+            lk.lock();
+            if (--pending_ == 0) cv_done_.notify_one();
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_job_, cv_done_;
+    std::vector<std::thread> workers_;
+    const std::function<void(int)>* body_ = nullptr;
+    unsigned long generation_ = 0;
+    int job_threads_ = 0, pending_ = 0;
+    bool stop_ = false;
+};
+
+WorkerPool& pool() {
+    static WorkerPool p;
+    return p;
+}
+
 template <class F>
 void parallel_for(int n, int n_threads, F f) {
     if (n_threads <= 1 || n < 2) { for (int i = 0; i < n; ++i) f(i, 0); return; }
+    if (n_threads > n) n_threads = n;
     std::atomic<int> next(0);
-    std::vector<std::thread> th;
-    for (int t = 0; t < n_threads; ++t)
-        th.emplace_back([&, t]() {
-            for (;;) {
-                int i = next.fetch_add(16);
-                if (i >= n) break;
-                for (int k = i; k < i + 16 && k < n; ++k) f(k, t);
-            }
-        });
-    for (auto& x : th) x.join();
+    const std::function<void(int)> body = [&](int t) {
+        for (;;) {
+            const int i = next.fetch_add(16);
+            if (i >= n) break;
+            for (int k = i; k < i + 16 && k < n; ++k) f(k, t);
+        }
+    };
+    pool().run(n_threads, body);
 }
 
 }  // namespace
