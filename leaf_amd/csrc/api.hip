@@ -355,7 +355,11 @@ int forward_chunk(const leaf_text* h, const float* P, const uint16_t* W, const i
         const void* kvl = kv.kv_read ? kv.kv_read + (size_t)l * kv.kv_stride : nullptr;
         if (kv.kv_self_rows) {
             kvl = b.qkv;
-            LEAF_TRY(hipMemcpyAsync(kv.kv_copy + (size_t)l * kv.kv_stride, b.qkv, kv.kv_self_rows * 3 * d * 2, hipMemcpyDeviceToDevice, s));
+#ifdef LEAF_COPY_MEMCPY   // A/B build: the runtime's copy (three dispatches per 15-MB copy)
+            LEAF_TRY(hipMemcpyAsync(kv.kv_copy + (size_t)l * kv.kv_stride, b.qkv, (size_t)kv.kv_self_rows * 3 * d * 2, hipMemcpyDeviceToDevice, s));
+#else
+            LEAF_TRY(leaf_launch_copy_bytes(b.qkv, kv.kv_copy + (size_t)l * kv.kv_stride, (size_t)kv.kv_self_rows * 3 * d * 2, s));
+#endif
         }
         if (last && !out) break;          // K/V-only pass (clean captions for the cache): nothing consumes the rest
         if (last && h->last_trim && !kv.kv_write) {

@@ -484,6 +484,26 @@ hipError_t leaf_launch_score(const float* feat, const float* anchor, int B, int 
     return hipGetLastError();
 }
 
+// device-to-device copy in ONE launch (hipMemcpyAsync splits a 15-MB copy into three dispatches: bulk + two remainders)
+namespace {
+__global__ __launch_bounds__(256) void copy16_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16,
+                                                     const unsigned char* __restrict__ tsrc, unsigned char* __restrict__ tdst, int tail) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+    if (blockIdx.x == 0 && (int)threadIdx.x < tail) tdst[threadIdx.x] = tsrc[threadIdx.x];
+}
+}  // namespace
+hipError_t leaf_launch_copy_bytes(const void* src, void* dst, size_t bytes, hipStream_t s) {
+    if (!bytes) return hipSuccess;
+    if (((uintptr_t)src | (uintptr_t)dst) & 15) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s);
+    const size_t n16 = bytes / 16;
+    const int tail = (int)(bytes - n16 * 16);
+    size_t nb = (n16 + 255) / 256;
+    nb = nb < 1 ? 1 : (nb > 4096 ? 4096 : nb);
+    hipLaunchKernelGGL(copy16_kernel, dim3((unsigned)nb), dim3(256), 0, s, (const uint4*)src, (uint4*)dst, n16,
+                       (const unsigned char*)src + n16 * 16, (unsigned char*)dst + n16 * 16, tail);
+    return hipGetLastError();
+}
+
 hipError_t leaf_launch_cast(const float* src, void* dst, size_t n, int dtype, hipStream_t s) {
     if (n % 4) return hipErrorInvalidValue;
     size_t n4 = n / 4;

@@ -94,6 +94,8 @@ hipError_t leaf_launch_pool_project(const float* x, const int32_t* tokens, const
 // loss[b,r] per objective, arg-max over rho (first maximum wins), best feature gather
 hipError_t leaf_launch_score(const float* feat, const float* anchor, int B, int rho, int D, int objective,
                              int32_t* best_idx, float* best_feat, float* loss, hipStream_t s);
+// device-to-device byte copy in one launch
+hipError_t leaf_launch_copy_bytes(const void* src, void* dst, size_t bytes, hipStream_t s);
 // fp32 -> 16-bit straight copy (weight packing)
 hipError_t leaf_launch_cast(const float* src, void* dst, size_t n, int dtype, hipStream_t s);
 
