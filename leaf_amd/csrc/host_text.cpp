@@ -202,6 +202,7 @@ public:
     // runs body(t) for t = 0 .. nt-1 concurrently and returns when all are done
     void run(int nt, const std::function<void(int)>& body) {
         if (nt <= 1) { body(0); return; }
+        std::lock_guard<std::mutex> one_job(run_m_);       // callers from different host threads take turns
         std::unique_lock<std::mutex> lk(m_);
         while ((int)workers_.size() < nt - 1) {
             const int id = (int)workers_.size() + 1;
@@ -235,7 +236,7 @@ private:
             if (--pending_ == 0) cv_done_.notify_one();
         }
     }
-    std::mutex m_;
+    std::mutex m_, run_m_;
     std::condition_variable cv_job_, cv_done_;
     std::vector<std::thread> workers_;
     const std::function<void(int)>* body_ = nullptr;

@@ -205,3 +205,24 @@ def test_rng_draws_are_stream_identical():
             got = [attacks._choice_range(pop, size, replace) for _ in range(3)]
             tail_g = np.random.random(4)
             assert all(np.array_equal(a, b) for a, b in zip(want, got)) and np.array_equal(tail_w, tail_g), (pop, size, replace)
+
+
+def test_native_tokenizer_from_concurrent_host_threads():
+    """The native pipeline's worker pool runs one job at a time; callers from several Python threads (ctypes releases the GIL during
+    the call) must take turns, not corrupt each other's per-worker BPE caches."""
+    import threading
+    from leaf_amd.native_text import NativeTokenizer
+    from leaf_amd.tokenizer import SimpleTokenizer
+    tok, ref = NativeTokenizer(n_threads=4), SimpleTokenizer()
+    caps = ["a photo of a cat number %d on the table" % i for i in range(120)]
+    want = ref.encode_batch(caps)
+    bad = []
+
+    def work():
+        for _ in range(20):
+            if not np.array_equal(tok.encode_batch(caps), want):
+                bad.append(1)
+    ts = [threading.Thread(target=work) for _ in range(3)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not bad
