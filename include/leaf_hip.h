@@ -227,6 +227,15 @@ void leaf_dict_destroy(leaf_dict_t d);
 int64_t leaf_dict_size(leaf_dict_t d);
 int leaf_tok_constrain(leaf_dict_t d, int tokenizer_kind, const char* const* sentences, const int32_t* sent_len, int B,
                        const int32_t* z, const int32_t* c, int rho, uint8_t* valid, uint8_t* fallback, int n_threads);
+/* the same with the caller's SENTENCE SEGMENTATION (tokenizer_kind 1 only): nltk.word_tokenize tokenises sentence by sentence, and
+ * where a sentence ends is decided by nltk's trained Punkt model, which is not restated.  ranges / ranges_off: for sentence b the
+ * spans [ranges[2 i], ranges[2 i + 1]) , i in [ranges_off[b], ranges_off[b + 1]), as PunktSentenceTokenizer.span_tokenize returns them
+ * for the lower-cased caption (none = handled as by leaf_tok_constrain).  A candidate is decided natively when its edit window lies
+ * inside one span, holds no '.', '?' or '!' before or after the edit and does not directly follow a token that ends in one (Punkt
+ * looks at the token carrying the period and the one after it); the others get fallback = 1. */
+int leaf_tok_constrain_ranges(leaf_dict_t d, int tokenizer_kind, const char* const* sentences, const int32_t* sent_len, int B,
+                              const int32_t* z, const int32_t* c, int rho, const int32_t* ranges, const int32_t* ranges_off,
+                              uint8_t* valid, uint8_t* fallback, int n_threads);
 /* test / debug hook: the word tokens of `text` under tokenizer_kind (0 = the regex stand-in of leaf_amd/attacks.py, 1 =
  * nltk.word_tokenize restated: nltk/tokenize/destructive.py's substitution pipeline), '\n'-joined into out[0, cap).
  * Returns 0; 2 when the text is declined (kind 1: non-ASCII, or a lone '.' ends a chunk inside the text, where the result would

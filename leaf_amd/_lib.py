@@ -79,6 +79,8 @@ _SIGS = {
     "leaf_dict_create": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "leaf_dict_destroy": (None, [C.c_void_p]),
     "leaf_dict_size": (C.c_int64, [C.c_void_p]),
+    "leaf_tok_constrain_ranges": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "leaf_tok_duplicate_map": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "leaf_tok_word_tokens": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int)]),
     "leaf_tok_constrain": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,

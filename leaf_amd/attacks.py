@@ -89,6 +89,10 @@ class Dictionary:
         # 'nltk' = nltk.word_tokenize (native only for letters/digits/whitespace), None = custom callable (Python only)
         self.kind = kind if kind is not None else ("regex" if tokenize is None else None)
         self._native = None
+        # kind 'nltk' only: span_tokenize(text) -> [(start, end), ...] of the sentence splitter that `tokenize` runs in front of
+        # the Treebank step (nltk's Punkt); None = unknown (captions whose tokens depend on it are decided string by string)
+        self.span_tokenize = None
+        self._span_cache = {}
 
     @classmethod
     def from_nltk(cls):
@@ -105,7 +109,25 @@ class Dictionary:
         if not ok:
             logging.warning(f"nltk {getattr(nltk, '__version__', '?')}: word_tokenize differs from the restated Treebank pipeline on the "
                             "self-check strings -- --constrain is decided with nltk itself for every candidate (slow host path)")
-        return cls(words.words(), word_tokenize, kind="nltk" if ok else None)
+        d = cls(words.words(), word_tokenize, kind="nltk" if ok else None)
+        if ok:
+            try:    # the Punkt instance word_tokenize uses (nltk >= 3.8.2: _get_punkt_tokenizer; before: the pickled model)
+                try:
+                    from nltk.tokenize import _get_punkt_tokenizer
+                    punkt = _get_punkt_tokenizer("english")
+                except ImportError:
+                    punkt = nltk.data.load("tokenizers/punkt/english.pickle")
+                spans = lambda t: list(punkt.span_tokenize(t))
+                from .treebank import SPAN_CHECK_STRINGS, treebank_tokenize
+                # sentence by sentence through the restated Treebank step must reproduce word_tokenize on multi-sentence text
+                if all([w for a, b in spans(t) for w in treebank_tokenize(t[a:b])] == word_tokenize(t) for t in SPAN_CHECK_STRINGS):
+                    d.span_tokenize = spans
+                else:
+                    logging.warning("nltk's sentence spans + the restated Treebank step do not reproduce word_tokenize on the self-check "
+                                    "strings: multi-sentence captions are decided with nltk itself, string by string")
+            except Exception as e:      # no Punkt model installed, a different API: the slower path, never a wrong answer
+                logging.warning(f"nltk Punkt sentence spans unavailable ({e}): multi-sentence captions are decided string by string")
+        return d
 
     def native_handle(self):
         """leaf_dict_t of this word set (built once), or None when the tokenizer has no native restatement."""
@@ -141,6 +163,25 @@ class Dictionary:
             from .treebank import treebank_tokenize
             return cls(ws, treebank_tokenize, kind="nltk")
         return cls(ws)
+
+    def sentence_spans(self, sentences):
+        """For the native constraint: per caption the sentence spans of its LOWER-CASED text, for the captions whose word tokens
+        depend on where sentences end (treebank.punkt_free is False) and [] for the others; None when no sentence splitter is
+        known.  One splitter call per such caption (cached: both stages of an edit ask for the same captions)."""
+        if self.span_tokenize is None:
+            return None
+        from .treebank import punkt_free
+        out = []
+        for s in sentences:
+            t = s.lower()
+            sp = self._span_cache.get(t)
+            if sp is None:
+                sp = [] if punkt_free(t) else [(int(a), int(b)) for a, b in self.span_tokenize(t)]
+                if len(self._span_cache) > 65536:
+                    self._span_cache.clear()
+                self._span_cache[t] = sp
+            out.append(sp)
+        return out
 
     def count(self, sentence: str) -> int:
         return len(self.words.intersection(self.tokenize(sentence.lower())))

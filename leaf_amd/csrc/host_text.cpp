@@ -681,9 +681,11 @@ extern "C" int leaf_dict_create(const char* words, size_t len, leaf_dict_t* out)
 extern "C" void leaf_dict_destroy(leaf_dict_t d) { delete d; }
 extern "C" int64_t leaf_dict_size(leaf_dict_t d) { return d ? (int64_t)d->words.size() : -1; }
 
-extern "C" int leaf_tok_constrain(leaf_dict_t d, int kind, const char* const* sentences, const int32_t* sent_len, int B,
-                                  const int32_t* z, const int32_t* c, int rho, uint8_t* valid, uint8_t* fallback, int n_threads) {
+static int constrain_impl(leaf_dict_t d, int kind, const char* const* sentences, const int32_t* sent_len, int B,
+                          const int32_t* z, const int32_t* c, int rho, const int32_t* ranges, const int32_t* ranges_off,
+                          uint8_t* valid, uint8_t* fallback, int n_threads) {
     if (!d || !sentences || !sent_len || !z || !c || !valid || !fallback || rho < 1 || (kind != 0 && kind != 1)) return 1;
+    if ((ranges == nullptr) != (ranges_off == nullptr) || (ranges && kind != 1)) return 1;
     if (n_threads < 1) n_threads = 1;
     std::atomic<int> bad(0);
     // sentences are independent: one task per sentence (its rho candidates share the multiplicity map)
@@ -693,8 +695,25 @@ extern "C" int leaf_tok_constrain(leaf_dict_t d, int kind, const char* const* se
         uint8_t* v = valid + (size_t)b * rho;
         uint8_t* fb = fallback + (size_t)b * rho;
         std::unordered_map<std::string, int> mult;       // dictionary words of the sentence -> occurrences
-        bool ok = kind == 0 || tb_punkt_free(s, (size_t)n);
-        ok = ok && tokenize_piece(s, (size_t)n, kind, [&](const std::string& w) { if (d->words.count(w)) ++mult[w]; });
+        // kind 1 with sentence ranges from the caller's Punkt (leaf_tok_constrain_ranges): the caption is tokenised sentence by
+        // sentence, as nltk.word_tokenize does, whatever its periods look like
+        const int32_t* rg = nullptr;
+        int nrg = 0;
+        if (ranges_off && ranges_off[b + 1] > ranges_off[b]) { rg = ranges + 2 * (size_t)ranges_off[b]; nrg = ranges_off[b + 1] - ranges_off[b]; }
+        bool ok = true;
+        if (rg) {
+            int prev_end = 0;
+            for (int i = 0; i < nrg && ok; ++i) {
+                const int S = rg[2 * i], E = rg[2 * i + 1];
+                ok = S >= prev_end && E >= S && E <= n;
+                prev_end = E;
+                if (ok) ok = tokenize_piece(s + S, (size_t)(E - S), kind, [&](const std::string& w) { if (d->words.count(w)) ++mult[w]; });
+            }
+            for (int q = prev_end; q < n && ok; ++q) ok = is_space((unsigned char)s[q]);     // nothing but blanks outside the sentences
+        } else {
+            ok = kind == 0 || tb_punkt_free(s, (size_t)n);
+            ok = ok && tokenize_piece(s, (size_t)n, kind, [&](const std::string& w) { if (d->words.count(w)) ++mult[w]; });
+        }
         if (!ok) { for (int r = 0; r < rho; ++r) { fb[r] = 1; v[r] = 0; } return; }
         // kind 1: index of the text's final period, when it has one that ends its chunk (its split depends on what follows it)
         int final_period = -1;
@@ -732,7 +751,24 @@ extern "C" int leaf_tok_constrain(leaf_dict_t d, int kind, const char* const* se
             while (R < n && !is_space((unsigned char)s[R])) ++R;
             delta.clear();
             bool at_start = true, at_end = true, ws_after = true;
-            if (kind == 1) {
+            if (kind == 1 && rg) {
+                // Punkt decides a sentence break from the token that carries the period and the token after it: an edit is
+                // decided natively only when its window holds no sentence-final character before or after the edit, is not the
+                // token right behind one, and lies inside ONE sentence of the caller's segmentation
+                auto terminator = [](unsigned char ch) { return ch == '.' || ch == '?' || ch == '!'; };
+                bool clean = !(has_ins && terminator((unsigned char)ins));
+                for (int q = L; q < R && clean; ++q) clean = !terminator((unsigned char)s[q]);
+                int pe = L;                                       // end of the chunk in front of the window
+                while (pe > 0 && is_space((unsigned char)s[pe - 1])) --pe;
+                int pq = pe;
+                while (pq > 0 && tb_closer((unsigned char)s[pq - 1])) --pq;
+                if (clean && pq > 0 && terminator((unsigned char)s[pq - 1])) clean = false;
+                int si = -1;
+                for (int i = 0; i < nrg && clean; ++i)
+                    if (L >= rg[2 * i] && R <= rg[2 * i + 1]) { si = i; break; }
+                if (!clean || si < 0 || L == R) { fb[r] = 1; v[r] = 0; continue; }
+                at_start = L == rg[2 * si]; at_end = R == rg[2 * si + 1]; ws_after = at_end;
+            } else if (kind == 1) {
                 // the candidate as a whole must stay independent of sentence boundaries, and an edit behind the final period's
                 // chunk could change how THAT chunk (outside the window) splits
                 cand.assign(s, (size_t)e0);
@@ -761,6 +797,20 @@ extern "C" int leaf_tok_constrain(leaf_dict_t d, int kind, const char* const* se
         }
     });
     return bad ? 3 : 0;
+}
+
+extern "C" int leaf_tok_constrain(leaf_dict_t d, int kind, const char* const* sentences, const int32_t* sent_len, int B,
+                                  const int32_t* z, const int32_t* c, int rho, uint8_t* valid, uint8_t* fallback, int n_threads) {
+    return constrain_impl(d, kind, sentences, sent_len, B, z, c, rho, nullptr, nullptr, valid, fallback, n_threads);
+}
+
+// The same with the caller's SENTENCE SEGMENTATION for captions whose word tokens depend on it (tokenizer kind 1): sentence b's
+// ranges are ranges[2 i], ranges[2 i + 1] (start, end) for i in [ranges_off[b], ranges_off[b + 1]) -- the spans of nltk's Punkt
+// (PunktSentenceTokenizer.span_tokenize) on the lower-cased caption; a caption without ranges is handled as by leaf_tok_constrain.
+extern "C" int leaf_tok_constrain_ranges(leaf_dict_t d, int kind, const char* const* sentences, const int32_t* sent_len, int B,
+                                         const int32_t* z, const int32_t* c, int rho, const int32_t* ranges,
+                                         const int32_t* ranges_off, uint8_t* valid, uint8_t* fallback, int n_threads) {
+    return constrain_impl(d, kind, sentences, sent_len, B, z, c, rho, ranges, ranges_off, valid, fallback, n_threads);
 }
 
 // Debug / test hook: word tokens of `text` under tokenizer `kind` (0 regex stand-in, 1 nltk.word_tokenize), joined by '\n' into

@@ -103,8 +103,19 @@ class NativeTokenizer(SimpleTokenizer):
         zz = np.ascontiguousarray(z, dtype=np.int32)
         cc = np.ascontiguousarray(c, dtype=np.int32)
         kind = {"regex": 0, "nltk": 1}[dictionary.kind]
-        rc = self._lib.leaf_tok_constrain(dictionary.native_handle(), kind, arr, blen.ctypes.data, B, zz.ctypes.data, cc.ctypes.data,
-                                          rho, valid.ctypes.data, fb.ctypes.data, self.n_threads)
+        spans = dictionary.sentence_spans(sentences) if kind == 1 and hasattr(dictionary, "sentence_spans") else None
+        if spans is not None and any(spans):
+            # captions whose tokens depend on where sentences end: nltk's Punkt was asked once per caption (not once per
+            # candidate); the native code tokenises them sentence by sentence
+            off = np.zeros(B + 1, dtype=np.int32)
+            np.cumsum([len(sp) for sp in spans], out=off[1:])
+            flat = np.ascontiguousarray([x for sp in spans for se in sp for x in se], dtype=np.int32)
+            rc = self._lib.leaf_tok_constrain_ranges(dictionary.native_handle(), kind, arr, blen.ctypes.data, B, zz.ctypes.data,
+                                                     cc.ctypes.data, rho, flat.ctypes.data, off.ctypes.data, valid.ctypes.data,
+                                                     fb.ctypes.data, self.n_threads)
+        else:
+            rc = self._lib.leaf_tok_constrain(dictionary.native_handle(), kind, arr, blen.ctypes.data, B, zz.ctypes.data, cc.ctypes.data,
+                                              rho, valid.ctypes.data, fb.ctypes.data, self.n_threads)
         if rc not in (0, 3):
             raise _lib.LeafHipError(f"leaf_tok_constrain failed ({rc})")
         for b, (s_, r_) in enumerate(zip(sentences, raw)):      # byte offsets == character offsets only for ASCII sentences

@@ -124,6 +124,18 @@ SELF_CHECK_STRINGS = [
 ]
 
 
+# multi-sentence texts for the run-time check of "Punkt spans + restated Treebank step == word_tokenize" (Dictionary.from_nltk)
+SPAN_CHECK_STRINGS = [
+    "a cat. a dog.", "the end. (really.) yes", "dr. smith went home. he slept", "what? yes! no. maybe", "e.g. this one, and that. done",
+    "first sentence here. second one, with a comma. third!", "she said \"go.\" then left", "price: 3.50 dollars. cheap",
+]
+
+
+def spans_word_tokenize(text: str, spans) -> List[str]:
+    """``nltk.word_tokenize(text)`` given the sentence spans its Punkt step produces: the Treebank step sentence by sentence."""
+    return [w for a, b in spans for w in treebank_tokenize(text[a:b])]
+
+
 def self_check(real_word_tokenize) -> bool:
     """Compare this restatement with the installed nltk on a fixed battery (run once when a Dictionary is built from nltk):
     False -> the caller must not use the native / restated tokenizer (a different nltk generation)."""

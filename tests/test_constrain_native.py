@@ -151,6 +151,76 @@ def test_nltk_mode_native_equals_the_treebank_tokenizer_on_random_edits(tok, kat
     assert decided > 25000 and declined < 0.15 * (decided + declined)
 
 
+_ABBR = {"e.g", "dr", "mr", "vs", "no", "st"}
+
+
+def _fake_punkt_spans(text):
+    """A stand-in for nltk's Punkt with the same KIND of dependence: whether a period (+ closing quotes / brackets) that ends a
+    chunk also ends a sentence depends on the token that carries it (abbreviation list) and on the token after it (no break in
+    front of a digit or an opening bracket) -- and '?' / '!' in front of a blank always end one.  Spans as span_tokenize gives them."""
+    closers = "])}>\"'"
+    n = len(text.rstrip())
+    spans, start, i = [], 0, 0
+    while i < n:
+        ch = text[i]
+        if ch in ".?!":
+            j = i + 1
+            while j < n and text[j] == '.':
+                j += 1
+            lone = ch != '.' or (j - i == 1 and (i == 0 or text[i - 1] != '.'))
+            k = j
+            while k < n and text[k] in closers:
+                k += 1
+            if lone and k < n and text[k].isspace():
+                q = k
+                while q < n and text[q].isspace():
+                    q += 1
+                tok0 = text[:i].split()[-1] if text[:i].split() else ""
+                nxt = text[q] if q < n else ""
+                brk = ch in "?!" or (tok0.strip(closers + "([{<") not in _ABBR and not nxt.isdigit() and nxt not in "([{<")
+                if brk and q < n:
+                    spans.append((start, k))
+                    start = q
+            i = max(j, i + 1)
+        else:
+            i += 1
+    spans.append((start, n))
+    return spans
+
+
+def test_multi_sentence_captions_are_decided_natively_from_the_callers_sentence_spans(tok, kat):
+    """Captions whose word tokens depend on where sentences end ("vintage chair. free shipping."): nltk's Punkt is asked ONCE per
+    caption for its sentence spans and leaf_tok_constrain_ranges tokenises sentence by sentence; a candidate is decided natively
+    only when its edit cannot change a sentence-break decision (no '.', '?', '!' in its window, not the token right behind one).
+    Checked against tokenising the WHOLE candidate with the splitter re-run on it, for a stand-in splitter of Punkt's kind."""
+    from leaf_amd.treebank import punkt_free, spans_word_tokenize
+    words = kat["stub_words"] + ["can", "not", "it", "s", "do", "end", "hi", "b", "chair", "free", "shipping", "dr", "st", "no"]
+    D = attacks.Dictionary(words, tokenize=lambda s: spans_word_tokenize(s, _fake_punkt_spans(s)), kind="nltk")
+    D.span_tokenize = _fake_punkt_spans
+    rng = random.Random(11)
+    vocab = kat["stub_words"] + ["chair.", "shipping.", "dr.", "e.g.", "no.", "st.", "5", "(new)", "what?", "wow!", "cat,", "it's", "\"go.\"", "end.)",
+                                 "zebra", "42", "don't", "a,b", "free", "hi"]
+    decided = declined = multi = 0
+    for trial in range(150):
+        sents = [" ".join(rng.choice(vocab) for _ in range(rng.randint(2, 9))) for _ in range(5)]
+        rho = 40
+        z = np.stack([np.array([rng.randrange(2 * len(S) + 1) for _ in range(rho)]) for S in sents]).astype(np.int32)
+        c = np.array([[rng.choice(attacks.DEFAULT_V) for _ in range(rho)] for _ in sents], dtype=np.int32)
+        valid, fb = tok.constrain_mask(D, sents, z, c)
+        for b, S in enumerate(sents):
+            multi += not punkt_free(S.lower())
+            lo = D.count(S)
+            for r in range(rho):
+                if fb[b, r]:
+                    declined += 1
+                    continue
+                decided += 1
+                cand = attacks._apply_edit(S, int(z[b, r]), int(c[b, r]))
+                assert bool(valid[b, r]) == (D.count(cand) < lo), (S, cand, int(z[b, r]), int(c[b, r]))
+    print("multi-sentence constraint: captions needing spans", multi, "of", 150 * 5, "decided", decided, "declined", declined)
+    assert multi > 300 and decided > 0.6 * (decided + declined)
+
+
 def test_stage_candidates_constrained_native_equals_python(tok, kat):
     """attacks._stage_candidates with --constrain: native mask + native mutate/BPE == the all-Python path (same tokens, same
     no-op replacement of invalid candidates)."""
