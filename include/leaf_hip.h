@@ -236,6 +236,11 @@ int leaf_tok_constrain(leaf_dict_t d, int tokenizer_kind, const char* const* sen
 int leaf_tok_constrain_ranges(leaf_dict_t d, int tokenizer_kind, const char* const* sentences, const int32_t* sent_len, int B,
                               const int32_t* z, const int32_t* c, int rho, const int32_t* ranges, const int32_t* ranges_off,
                               uint8_t* valid, uint8_t* fallback, int n_threads);
+/* number of distinct dictionary words of ONE text (utils_attacks.py:135,139), for the strings leaf_tok_constrain* declines: with the
+ * sentence spans of that text from the caller's Punkt (n_ranges pairs; 0 = the text must not depend on sentence boundaries) the count is
+ * native too -- one Punkt call instead of a whole nltk.word_tokenize.  Returns 0; 2 = declined (non-ASCII, or spans missing). */
+int leaf_tok_count_words(leaf_dict_t d, int tokenizer_kind, const char* text, int len, const int32_t* ranges, int n_ranges,
+                         int32_t* count);
 /* test / debug hook: the word tokens of `text` under tokenizer_kind (0 = the regex stand-in of leaf_amd/attacks.py, 1 =
  * nltk.word_tokenize restated: nltk/tokenize/destructive.py's substitution pipeline), '\n'-joined into out[0, cap).
  * Returns 0; 2 when the text is declined (kind 1: non-ASCII, or a lone '.' ends a chunk inside the text, where the result would

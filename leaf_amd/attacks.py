@@ -183,6 +183,25 @@ class Dictionary:
             out.append(sp)
         return out
 
+    def count_fast(self, sentence: str) -> int:
+        """``count`` for the strings the native constraint declines: with a sentence splitter known (nltk's Punkt) the string costs one
+        splitter call and a native count (leaf_tok_count_words) instead of a whole ``word_tokenize``; otherwise ``count``."""
+        if self.kind != "nltk" or self.span_tokenize is None:
+            return self.count(sentence)
+        import ctypes as C
+        from . import _lib
+        from .treebank import punkt_free
+        t = sentence.lower()
+        try:
+            raw = t.encode("ascii")
+        except UnicodeEncodeError:
+            return self.count(sentence)
+        sp = [] if punkt_free(t) else [x for a, b in self.span_tokenize(t) for x in (int(a), int(b))]
+        arr = (C.c_int32 * len(sp))(*sp) if sp else None
+        n = C.c_int32()
+        rc = _lib.lib().leaf_tok_count_words(self.native_handle(), 1, raw, len(raw), arr, len(sp) // 2, C.byref(n))
+        return n.value if rc == 0 else self.count(sentence)
+
     def count(self, sentence: str) -> int:
         return len(self.words.intersection(self.tokenize(sentence.lower())))
 
@@ -242,8 +261,8 @@ def _stage_candidates(tokenizer, sentences, z, c, constrain, trace):
         for i in np.nonzero(fb.reshape(-1))[0]:
             b, r = divmod(int(i), rho)
             if b not in lo:
-                lo[b] = D.count(sentences[b])
-            valid[b, r] = D.count(_apply_edit(sentences[b], int(z[b, r]), int(c[b, r]))) < lo[b]
+                lo[b] = D.count_fast(sentences[b])
+            valid[b, r] = D.count_fast(_apply_edit(sentences[b], int(z[b, r]), int(c[b, r]))) < lo[b]
         z[~valid], c[~valid] = 0, -1                      # the no-op edit: candidate == original sentence
     need_strings = (constrain and not native_constrain) or trace is not None or not native
     SS = None

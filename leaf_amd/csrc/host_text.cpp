@@ -383,20 +383,26 @@ inline char lower(unsigned char c) { return (char)((c >= 'A' && c <= 'Z') ? c + 
 inline bool tb_word(unsigned char c) { return is_alnum(c) || c == '_'; }
 inline bool tb_closer(unsigned char c) { return c == ']' || c == ')' || c == '}' || c == '>' || c == '"' || c == '\''; }
 
-// text[0, n): true when sentence boundaries cannot change the tokens (leaf_amd/treebank.py punkt_free)
+// what may directly follow a sentence-final character for Punkt to consider a break there without whitespace
+// (nltk/tokenize/punkt.py PunktLanguageVars._re_non_word_chars)
+inline bool punkt_nonword(unsigned char c) {
+    return c == '?' || c == '!' || c == ')' || c == '"' || c == ';' || c == '}' || c == ']' || c == '*' || c == ':' || c == '@' ||
+           c == '\'' || c == '(' || c == '{' || c == '[';
+}
+
+// text[0, n): true when sentence boundaries cannot change the tokens (leaf_amd/treebank.py punkt_free): every lone '.' is followed by
+// a character that is neither blank nor in Punkt's NONWORD set, or is the text's final period (closers directly behind it, then blanks)
 bool tb_punkt_free(const char* t, size_t n) {
     size_t i = 0;
     while (i < n) {
         if (t[i] != '.') { ++i; continue; }
         size_t j = i;
         while (j < n && t[j] == '.') ++j;
-        if (j - i == 1) {
-            size_t k = j;
-            while (k < n && tb_closer((unsigned char)t[k])) ++k;
-            if (k == n || is_space((unsigned char)t[k])) {                 // the period ends its chunk ...
-                for (size_t q = k; q < n; ++q)                             // ... and something other than closers / blanks follows
-                    if (!tb_closer((unsigned char)t[q]) && !is_space((unsigned char)t[q])) return false;
-            }
+        if (j - i == 1 && j < n && (is_space((unsigned char)t[j]) || punkt_nonword((unsigned char)t[j]))) {
+            size_t q = j;                                  // the text's final period: closers directly behind it, then only blanks
+            while (q < n && tb_closer((unsigned char)t[q])) ++q;
+            for (; q < n; ++q)
+                if (!is_space((unsigned char)t[q])) return false;
         }
         i = j;
     }
@@ -811,6 +817,32 @@ extern "C" int leaf_tok_constrain_ranges(leaf_dict_t d, int kind, const char* co
                                          const int32_t* z, const int32_t* c, int rho, const int32_t* ranges,
                                          const int32_t* ranges_off, uint8_t* valid, uint8_t* fallback, int n_threads) {
     return constrain_impl(d, kind, sentences, sent_len, B, z, c, rho, ranges, ranges_off, valid, fallback, n_threads);
+}
+
+// Number of DISTINCT dictionary words of one text (utils_attacks.py:135: len(W & set(word_tokenize(text.lower())))), tokenizer kind as
+// above; kind 1 with the caller's sentence spans (n_ranges pairs; 0 = the text must not depend on sentence boundaries).
+// Returns 0, 2 when declined (non-ASCII; kind 1 without spans on a sentence-boundary dependent text), 1 on bad arguments.
+extern "C" int leaf_tok_count_words(leaf_dict_t d, int kind, const char* text, int len, const int32_t* ranges, int n_ranges,
+                                    int32_t* count) {
+    if (!d || !text || !count || len < 0 || (kind != 0 && kind != 1) || n_ranges < 0 || (n_ranges && (!ranges || kind != 1))) return 1;
+    std::unordered_set<std::string> seen;
+    auto emit = [&](const std::string& w) { if (d->words.count(w)) seen.insert(w); };
+    bool ok = true;
+    if (n_ranges) {
+        int prev_end = 0;
+        for (int i = 0; i < n_ranges && ok; ++i) {
+            const int S = ranges[2 * i], E = ranges[2 * i + 1];
+            if (S < prev_end || E < S || E > len) return 1;
+            prev_end = E;
+            ok = tokenize_piece(text + S, (size_t)(E - S), kind, emit);
+        }
+    } else {
+        if (kind == 1 && !tb_punkt_free(text, (size_t)len)) return 2;
+        ok = tokenize_piece(text, (size_t)len, kind, emit);
+    }
+    if (!ok) return 2;
+    *count = (int32_t)seen.size();
+    return 0;
 }
 
 // Debug / test hook: word tokens of `text` under tokenizer `kind` (0 regex stand-in, 1 nltk.word_tokenize), joined by '\n' into

@@ -81,12 +81,17 @@ def treebank_tokenize(text: str) -> List[str]:
 
 
 _CLOSERS = "])}>\"'"
+# what may directly follow a sentence-final character for Punkt to consider a sentence break there WITHOUT whitespace
+# (nltk/tokenize/punkt.py, PunktLanguageVars._re_non_word_chars: (?:[?!)";}\]\*:@'\({\[]))
+_PUNKT_NONWORD = "?!)\";}]*:@'({["
 
 
 def punkt_free(text: str) -> bool:
-    """True when Punkt's sentence boundaries cannot change ``word_tokenize(text)`` (module docstring): every lone '.' is inside
-    a word (followed, within its whitespace-delimited chunk, by a character that is not a closing bracket / quote), part of a
-    '..' run, or the final period of the whole text (only closing brackets / quotes / whitespace behind it)."""
+    """True when Punkt's sentence boundaries cannot change ``word_tokenize(text)`` (module docstring).  Punkt looks for breaks at
+    ``\\S*[.?!](?=NONWORD | \\s+\\S+)``; a break changes the Treebank tokens only through a lone '.', so the text is safe when every
+    lone '.' (not part of a '..' run) is either followed by a character that is neither blank nor in Punkt's NONWORD set (inside a
+    word: "3.50", "a.b"), or is the final period of the whole text (closing brackets / quotes directly behind it, then only blanks).  (Where a '?' or '!' ends
+    a sentence in front of a quote, Punkt can also turn a closing quote token into an opening one -- never a letter-bearing token.)"""
     n = len(text)
     i = 0
     while i < n:
@@ -96,12 +101,13 @@ def punkt_free(text: str) -> bool:
         j = i
         while j < n and text[j] == '.':
             j += 1
-        if j - i == 1:
+        if j - i == 1 and j < n and (text[j].isspace() or text[j] in _PUNKT_NONWORD):
+            # ... unless it is the text's final period: closers directly behind it, then nothing but blanks (closers AFTER a blank do
+            # not count: Treebank would turn a detached '"' into an opening quote before it looks for the final period)
             k = j
             while k < n and text[k] in _CLOSERS:
                 k += 1
-            ends_chunk = k == n or text[k].isspace()
-            if ends_chunk and text[k:].strip(_CLOSERS + " \t\n\r\f\v") != "":
+            if text[k:].strip() != "":
                 return False
         i = j
     return True

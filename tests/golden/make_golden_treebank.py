@@ -42,24 +42,12 @@ SENTS = ["a photo of a cat", "two dogs playing in the park", "the red car on the
 
 
 def ok(s):
-    """strings on which punkt's sentence splitting cannot change the tokens (module docstring)"""
-    t = s.lower()
-    i = 0
-    while i < len(t):
-        if t[i] == '.':
-            j = i
-            while j < len(t) and t[j] == '.':
-                j += 1
-            if j - i == 1:
-                rest = t[i + 1:]
-                chunk_rest = rest.split(None, 1)[0] if rest.strip() and not rest[0].isspace() else ""
-                tail_is_text_end = rest.strip("])}>\"' \t\n") == ""
-                if not tail_is_text_end and (chunk_rest.strip("])}>\"'") == ""):
-                    return False          # a lone period that ends its chunk (a sentence-boundary candidate) inside the text
-            i = j
-        else:
-            i += 1
-    return True
+    """strings on which Punkt's sentence splitting cannot change the letter-bearing tokens (leaf_amd.treebank.punkt_free; checked
+    against the real Punkt code on 44,000 random punctuation-heavy strings when this rule was written)"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from leaf_amd.treebank import punkt_free
+    return punkt_free(s.lower())
 
 
 def mutate(S, z, c):

@@ -221,6 +221,44 @@ def test_multi_sentence_captions_are_decided_natively_from_the_callers_sentence_
     assert multi > 300 and decided > 0.6 * (decided + declined)
 
 
+def test_multi_sentence_known_answers_from_the_real_punkt_code(tok, golden_dir):
+    """The same path against the REAL nltk code: tests/golden/punkt_kat.json holds, for 160 captions (119 multi-sentence), the spans of
+    nltk's PunktSentenceTokenizer and the validity of 4,800 random single edits computed by re-running Punkt + NLTKWordTokenizer on
+    every whole candidate (tests/golden/make_golden_punkt.py).  Given the spans of the CAPTION only, everything the native code
+    decides must agree; what it declines goes to the real tokenizer at run time."""
+    with open(os.path.join(golden_dir, "punkt_kat.json")) as f:
+        k = json.load(f)
+    spans = {c["caption"].lower(): [tuple(s) for s in c["spans"]] for c in k["cases"]}
+    D = attacks.Dictionary(k["words"], tokenize=lambda s: (_ for _ in ()).throw(AssertionError("no whole-string tokenisation here")), kind="nltk")
+    D.span_tokenize = lambda t: spans[t]
+    decided = declined = 0
+    for i in range(0, len(k["cases"]), 8):
+        batch = k["cases"][i:i + 8]
+        sents = [c["caption"] for c in batch]
+        z = np.array([[e[0] for e in c["edits"]] for c in batch], dtype=np.int32)
+        cc = np.array([[e[1] for e in c["edits"]] for c in batch], dtype=np.int32)
+        valid, fb = tok.constrain_mask(D, sents, z, cc)
+        for b, c in enumerate(batch):
+            for r, e in enumerate(c["edits"]):
+                if fb[b, r]:
+                    declined += 1
+                else:
+                    decided += 1
+                    assert bool(valid[b, r]) == bool(e[2]), (c["caption"], e)
+    # the run-time fallback for what was declined (and, here, for every edit): Punkt's spans of the CANDIDATE + a native count
+    cand_spans = {}
+    for c in k["cases"]:
+        for e in c["edits"]:
+            cand_spans[attacks._apply_edit(c["caption"], e[0], e[1]).lower()] = [tuple(s) for s in e[3]]
+    D.span_tokenize = lambda t: spans[t] if t in spans else cand_spans[t]
+    for c in k["cases"]:
+        lo = D.count_fast(c["caption"])
+        for e in c["edits"]:
+            assert (D.count_fast(attacks._apply_edit(c["caption"], e[0], e[1])) < lo) == bool(e[2]), (c["caption"], e[:3])
+    print("real-Punkt known answers: decided", decided, "declined", declined)
+    assert decided > 0.5 * (decided + declined)     # (half of this vocabulary's tokens carry a period: far more than real captions)
+
+
 def test_stage_candidates_constrained_native_equals_python(tok, kat):
     """attacks._stage_candidates with --constrain: native mask + native mutate/BPE == the all-Python path (same tokens, same
     no-op replacement of invalid candidates)."""
