@@ -236,6 +236,24 @@ int leaf_tok_constrain(leaf_dict_t d, int tokenizer_kind, const char* const* sen
 int leaf_tok_constrain_ranges(leaf_dict_t d, int tokenizer_kind, const char* const* sentences, const int32_t* sent_len, int B,
                               const int32_t* z, const int32_t* c, int rho, const int32_t* ranges, const int32_t* ranges_off,
                               uint8_t* valid, uint8_t* fallback, int n_threads);
+/* nltk's Punkt sentence splitter restated (nltk/tokenize/punkt.py PunktSentenceTokenizer.span_tokenize, realign_boundaries = True;
+ * third-party, requirements.txt:14): the algorithm is fixed, the trained model only fills four tables.  The tables as '\n'-separated
+ * UTF-8 lines: abbreviation types; collocations "first\tsecond"; frequent sentence starters; orthographic contexts "type\tflags"
+ * (PunktParameters.abbrev_types / collocations / sent_starters / ortho_context).  ASCII text without control characters only:
+ * leaf_punkt_spans returns 2 for anything else.  spans: (start, end) pairs, at most cap_pairs (1 = overflow / bad arguments). */
+typedef struct leaf_punkt* leaf_punkt_t;
+int leaf_punkt_create(const char* abbrev, size_t abbrev_len, const char* colloc, size_t colloc_len, const char* starters,
+                      size_t starters_len, const char* ortho, size_t ortho_len, leaf_punkt_t* out);
+void leaf_punkt_destroy(leaf_punkt_t p);
+/* strict = 1 (the default): a text in which one whitespace-delimited chunk holds two or more candidate break positions ("what?! yes",
+ * "wow!!! nice") is declined (2): nltk 3.6.6 rewrote the scan for period contexts and the generations are only provably equal
+ * elsewhere.  strict = 0 decides every text as nltk 3.6.5 does (the generation the golden vectors were made with). */
+int leaf_punkt_set_strict(leaf_punkt_t p, int strict);
+int leaf_punkt_spans(leaf_punkt_t p, const char* text, int len, int32_t* spans, int cap_pairs, int32_t* n_pairs);
+/* leaf_tok_constrain for nltk.word_tokenize (tokenizer_kind 1) with the Punkt tables: the sentence spans of captions AND candidates
+ * are computed natively, so only non-ASCII text / control characters get fallback = 1. */
+int leaf_tok_constrain_punkt(leaf_dict_t d, leaf_punkt_t punkt, const char* const* sentences, const int32_t* sent_len, int B,
+                             const int32_t* z, const int32_t* c, int rho, uint8_t* valid, uint8_t* fallback, int n_threads);
 /* number of distinct dictionary words of ONE text (utils_attacks.py:135,139), for the strings leaf_tok_constrain* declines: with the
  * sentence spans of that text from the caller's Punkt (n_ranges pairs; 0 = the text must not depend on sentence boundaries) the count is
  * native too -- one Punkt call instead of a whole nltk.word_tokenize.  Returns 0; 2 = declined (non-ASCII, or spans missing). */

@@ -81,6 +81,13 @@ _SIGS = {
     "leaf_dict_size": (C.c_int64, [C.c_void_p]),
     "leaf_tok_constrain_ranges": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "leaf_punkt_create": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t,
+                                   C.POINTER(C.c_void_p)]),
+    "leaf_punkt_destroy": (None, [C.c_void_p]),
+    "leaf_punkt_set_strict": (C.c_int, [C.c_void_p, C.c_int]),
+    "leaf_punkt_spans": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int32)]),
+    "leaf_tok_constrain_punkt": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_char_p), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "leaf_tok_count_words": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int32)]),
     "leaf_tok_duplicate_map": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "leaf_tok_word_tokens": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int)]),

@@ -93,6 +93,9 @@ class Dictionary:
         # the Treebank step (nltk's Punkt); None = unknown (captions whose tokens depend on it are decided string by string)
         self.span_tokenize = None
         self._span_cache = {}
+        # kind 'nltk' only: native_text.NativePunkt built from that splitter's tables (sentence spans of captions AND candidates are
+        # then computed in C++: nothing but non-ASCII text goes back to Python); None = not available / failed its self-check
+        self.punkt_native = None
 
     @classmethod
     def from_nltk(cls):
@@ -122,12 +125,35 @@ class Dictionary:
                 # sentence by sentence through the restated Treebank step must reproduce word_tokenize on multi-sentence text
                 if all([w for a, b in spans(t) for w in treebank_tokenize(t[a:b])] == word_tokenize(t) for t in SPAN_CHECK_STRINGS):
                     d.span_tokenize = spans
+                    d.punkt_native = cls._native_punkt(punkt, spans)
                 else:
                     logging.warning("nltk's sentence spans + the restated Treebank step do not reproduce word_tokenize on the self-check "
                                     "strings: multi-sentence captions are decided with nltk itself, string by string")
             except Exception as e:      # no Punkt model installed, a different API: the slower path, never a wrong answer
                 logging.warning(f"nltk Punkt sentence spans unavailable ({e}): multi-sentence captions are decided string by string")
         return d
+
+    @staticmethod
+    def _native_punkt(punkt, spans):
+        """The installed Punkt instance's tables behind the native restatement of its algorithm -- used only when it reproduces
+        the instance's own ``span_tokenize`` on the self-check battery (a text the native code declines is not a failure)."""
+        import logging
+        try:
+            from .native_text import NativePunkt
+            from .treebank import PUNKT_CHECK_STRINGS
+            native = NativePunkt.from_nltk(punkt)
+            got = [(t, native.spans(t)) for t in PUNKT_CHECK_STRINGS]
+            wrong = [t for t, g in got if g is not None and g != [(int(a), int(b)) for a, b in spans(t)]]
+            if wrong or sum(g is not None for _, g in got) < len(got) // 2:
+                logging.warning(f"the native Punkt restatement differs from the installed nltk on {wrong[:3]!r}...: sentence spans are "
+                                "asked from nltk (one call per multi-sentence caption and per candidate that touches a sentence end)")
+                return None
+            logging.info("--constrain: nltk's Punkt tables loaded into the native sentence splitter (abbreviations %d, collocations %d, "
+                         "sentence starters %d, orthographic contexts %d)" % native.sizes)
+            return native
+        except Exception as e:
+            logging.warning(f"native Punkt unavailable ({e}): sentence spans are asked from nltk")
+            return None
 
     def native_handle(self):
         """leaf_dict_t of this word set (built once), or None when the tokenizer has no native restatement."""
@@ -152,16 +178,30 @@ class Dictionary:
             pass
 
     @classmethod
-    def from_file(cls, path: str, tokenizer: str = "regex"):
+    def from_file(cls, path: str, tokenizer: str = "regex", punkt_params: Optional[str] = None):
         """A word-list file (one word per line).  ``tokenizer='treebank'``: tokenise like nltk.word_tokenize WITHOUT nltk: the
-        restated Treebank pipeline; a text whose tokens would depend on nltk's trained Punkt sentence model (a lone '.' ending a
-        chunk inside the text) is tokenised as ONE sentence -- ``word_tokenize(text, preserve_line=True)`` -- since there is no
-        Punkt here (install nltk and use ``from_nltk`` for the reference's exact behaviour on such texts)."""
+        restated Treebank pipeline.  With ``punkt_params`` (the tables of nltk's trained Punkt model, exported once where nltk is
+        installed: tools/export_punkt_params.py) sentences are split by the native restatement of Punkt first, as
+        ``word_tokenize`` does; without it a text whose tokens would depend on the sentence model (a lone '.' ending a chunk
+        inside the text) is tokenised as ONE sentence -- ``word_tokenize(text, preserve_line=True)``."""
         with open(path) as f:
             ws = [w.strip() for w in f if w.strip()]
         if tokenizer == "treebank":
             from .treebank import treebank_tokenize
-            return cls(ws, treebank_tokenize, kind="nltk")
+            if punkt_params is None:
+                return cls(ws, treebank_tokenize, kind="nltk")
+            from .native_text import NativePunkt
+            native = NativePunkt.from_json(punkt_params)
+            strict_off = NativePunkt.from_json(punkt_params, strict=False)    # no nltk to ask: every text is decided (3.6.5 rules)
+
+            def spans(t):
+                sp = strict_off.spans(t)
+                return sp if sp is not None else [(0, len(t))]
+
+            d = cls(ws, lambda t: [w for a, b in spans(t) for w in treebank_tokenize(t[a:b])], kind="nltk")
+            d.span_tokenize = spans
+            d.punkt_native = native
+            return d
         return cls(ws)
 
     def sentence_spans(self, sentences):
@@ -196,7 +236,13 @@ class Dictionary:
             raw = t.encode("ascii")
         except UnicodeEncodeError:
             return self.count(sentence)
-        sp = [] if punkt_free(t) else [x for a, b in self.span_tokenize(t) for x in (int(a), int(b))]
+        if punkt_free(t):
+            sp = []
+        else:
+            sp = self.punkt_native.spans(t) if self.punkt_native is not None else None
+            if sp is None:
+                sp = self.span_tokenize(t)
+            sp = [int(x) for se in sp for x in se]
         arr = (C.c_int32 * len(sp))(*sp) if sp else None
         n = C.c_int32()
         rc = _lib.lib().leaf_tok_count_words(self.native_handle(), 1, raw, len(raw), arr, len(sp) // 2, C.byref(n))

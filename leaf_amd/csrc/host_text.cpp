@@ -662,9 +662,273 @@ bool tokenize_piece(const char* s, size_t n, int kind, F emit, bool at_start = t
     return true;
 }
 
+// ---- Punkt: the sentence splitter in front of the Treebank step (nltk/tokenize/punkt.py, Kiss & Strunk 2006; third-party, not
+// vendored in the reference).  Its DECISIONS are a fixed algorithm over four tables that the trained model file only fills:
+// abbreviation types, collocations, frequent sentence starters, orthographic contexts of word types.  Restated here for ASCII
+// text without control characters: PunktLanguageVars' two regular expressions (period contexts, word tokens), PunktToken's
+// derived properties, the first (type-based) and second (token-based: collocation, orthographic, sentence-starter heuristics)
+// annotation passes, text_contains_sentbreak, _slices_from_text and _realign_boundaries -- i.e. span_tokenize(text).  Pinned by
+// tests/golden/punkt_native_kat.json (2 x 2,500 texts split by the real PunktSentenceTokenizer with empty and hand-filled tables);
+// at run time leaf_amd/attacks.py compares it with the installed nltk's Punkt on a battery before it is used.
+struct Punkt {
+    std::unordered_set<std::string> abbrev, starters, colloc;   // colloc keys: first + '\t' + second
+    std::unordered_map<std::string, int> ortho;
+    // nltk 3.6.6+ finds the period contexts with a rewritten scan (the ReDoS fix, _match_potential_end_contexts) that is meant to be
+    // equivalent to the regular expression restated here (3.6.5: \S*[.?!](?=...)) and provably is when a whitespace-delimited chunk
+    // holds at most ONE candidate position; with `strict` a text with two or more in one chunk ("what?! yes", "wow!!! nice") is
+    // declined instead of decided with the older generation's rule.
+    bool strict = true;
+};
+
+enum { PK_ORTHO_BEG_UC = 2, PK_ORTHO_MID_UC = 4, PK_ORTHO_UNK_UC = 8, PK_ORTHO_BEG_LC = 16, PK_ORTHO_MID_LC = 32, PK_ORTHO_UNK_LC = 64,
+       PK_ORTHO_UC = 14, PK_ORTHO_LC = 112 };
+
+struct PkTok {
+    std::string tok, type;       // type: lower-cased, numbers -> ##number##
+    bool period_final = false, sentbreak = false, abbr = false, ellipsis = false;
+    bool first_upper() const { return tok[0] >= 'A' && tok[0] <= 'Z'; }
+    bool first_lower() const { return tok[0] >= 'a' && tok[0] <= 'z'; }
+    bool is_ellipsis() const {                                   // \.\.+$ matched from the token's start
+        if (tok.size() < 2) return false;
+        for (char ch : tok) if (ch != '.') return false;
+        return true;
+    }
+    bool is_initial() const { return tok.size() == 2 && (is_letter((unsigned char)tok[0]) || tok[0] == '_') && tok[1] == '.'; }   // [^\W\d]\.$
+    std::string type_no_period() const { return type.size() > 1 && type.back() == '.' ? type.substr(0, type.size() - 1) : type; }
+    std::string type_no_sentperiod() const { return sentbreak ? type_no_period() : type; }
+};
+
+// _re_multi_char_punct  (?:\-{2,}|\.{2,}|(?:\.\s){2,}\.)  at t[p]: length of the match or 0
+size_t pk_multi(const char* t, size_t n, size_t p) {
+    if (p >= n) return 0;
+    if (t[p] == '-') { size_t q = p; while (q < n && t[q] == '-') ++q; return q - p >= 2 ? q - p : 0; }
+    if (t[p] != '.') return 0;
+    if (p + 1 < n && t[p + 1] == '.') { size_t q = p; while (q < n && t[q] == '.') ++q; return q - p; }
+    size_t q = p, k = 0;                                         // k pairs ". " then a '.': greedy with one step of backtracking
+    while (q + 1 < n && t[q] == '.' && is_space((unsigned char)t[q + 1])) { q += 2; ++k; }
+    if (k >= 2 && q < n && t[q] == '.') return q + 1 - p;
+    if (k >= 3) return q - 2 + 1 - p;
+    return 0;
+}
+
+// PunktLanguageVars.word_tokenize: findall of  MULTI | (?=WORDSTART)\S+?(?=\s|$|NONWORD|MULTI|,(?=$|\s|NONWORD|MULTI)) | \S
+void pk_word_tokens(const char* t, size_t n, std::vector<PkTok>& out) {
+    auto end_ok = [&](size_t q) {
+        if (q >= n || is_space((unsigned char)t[q]) || punkt_nonword((unsigned char)t[q]) || pk_multi(t, n, q)) return true;
+        if (t[q] == ',') {
+            const size_t r = q + 1;
+            return r >= n || is_space((unsigned char)t[r]) || punkt_nonword((unsigned char)t[r]) || pk_multi(t, n, r) != 0;
+        }
+        return false;
+    };
+    size_t p = 0;
+    while (p < n) {
+        if (is_space((unsigned char)t[p])) { ++p; continue; }
+        size_t len = pk_multi(t, n, p);
+        if (!len) {
+            const char c = t[p];
+            const bool wordstart = !(c == '(' || c == '"' || c == '`' || c == '{' || c == '[' || c == ':' || c == ';' || c == '&' ||
+                                     c == '#' || c == '*' || c == '@' || c == ')' || c == '}' || c == ']' || c == '-' || c == ',');
+            len = 1;
+            if (wordstart) while (!end_ok(p + len)) ++len;
+        }
+        PkTok k;
+        k.tok.assign(t + p, len);
+        k.period_final = k.tok.back() == '.';
+        // type: _RE_NUMERIC  ^-?[\.,]?\d[\d,\.-]*\.?$  -> ##number##
+        {
+            const std::string& w = k.tok;
+            size_t i = 0;
+            if (i < w.size() && w[i] == '-') ++i;
+            if (i < w.size() && (w[i] == '.' || w[i] == ',')) ++i;
+            bool num = i < w.size() && is_digit((unsigned char)w[i]);
+            for (size_t j = i + 1; j < w.size() && num; ++j) num = is_digit((unsigned char)w[j]) || w[j] == ',' || w[j] == '.' || w[j] == '-';
+            if (num) k.type = "##number##";
+            else { k.type.reserve(w.size()); for (char ch : w) k.type += lower((unsigned char)ch); }
+        }
+        out.push_back(std::move(k));
+        p += len;
+    }
+}
+
+// _ortho_heuristic: 1 = the token starts a sentence, 0 = it does not, -1 = unknown
+int pk_ortho(const Punkt& pk, const PkTok& k) {
+    if (k.tok.size() == 1 && strchr(";:,.!?", k.tok[0])) return 0;
+    auto it = pk.ortho.find(k.type_no_sentperiod());
+    const int oc = it == pk.ortho.end() ? 0 : it->second;
+    if (k.first_upper() && (oc & PK_ORTHO_LC) && !(oc & PK_ORTHO_MID_UC)) return 1;
+    if (k.first_lower() && ((oc & PK_ORTHO_UC) || !(oc & PK_ORTHO_BEG_LC))) return 0;
+    return -1;
+}
+
+// text_contains_sentbreak(context): a token marked as a sentence break (after both passes) that is not the last token
+bool pk_contains_sentbreak(const Punkt& pk, const char* t, size_t n, std::vector<PkTok>& toks) {
+    toks.clear();
+    pk_word_tokens(t, n, toks);
+    for (PkTok& k : toks) {                                      // _first_pass_annotation
+        if (k.tok == "." || k.tok == "?" || k.tok == "!") k.sentbreak = true;
+        else if (k.is_ellipsis()) k.ellipsis = true;
+        else if (k.period_final && !(k.tok.size() >= 2 && k.tok[k.tok.size() - 2] == '.')) {
+            std::string base;
+            for (size_t i = 0; i + 1 < k.tok.size(); ++i) base += lower((unsigned char)k.tok[i]);
+            const size_t dash = base.rfind('-');
+            if (pk.abbrev.count(base) || (dash != std::string::npos && pk.abbrev.count(base.substr(dash + 1)))) k.abbr = true;
+            else k.sentbreak = true;
+        }
+    }
+    for (size_t i = 0; i + 1 < toks.size(); ++i) {               // _second_pass_annotation(tok i, tok i + 1)
+        PkTok& a = toks[i];
+        const PkTok& b = toks[i + 1];
+        if (!a.period_final) continue;
+        const std::string typ = a.type_no_period(), next_typ = b.type_no_sentperiod();
+        const bool initial = a.is_initial();
+        if (pk.colloc.count(typ + '\t' + next_typ)) { a.sentbreak = false; a.abbr = true; continue; }
+        if ((a.abbr || a.ellipsis) && !initial) {
+            if (pk_ortho(pk, b) == 1) { a.sentbreak = true; continue; }
+            if (b.first_upper() && pk.starters.count(next_typ)) { a.sentbreak = true; continue; }
+        }
+        if (initial || typ == "##number##") {
+            const int st = pk_ortho(pk, b);
+            if (st == 0) { a.sentbreak = false; a.abbr = true; continue; }
+            if (st == -1 && initial && b.first_upper()) {
+                auto it = pk.ortho.find(next_typ);
+                if (!((it == pk.ortho.end() ? 0 : it->second) & PK_ORTHO_LC)) { a.sentbreak = false; a.abbr = true; continue; }
+            }
+        }
+    }
+    for (size_t i = 0; i + 1 < toks.size(); ++i)
+        if (toks[i].sentbreak) return true;
+    return false;
+}
+
+// PunktSentenceTokenizer.span_tokenize(text) (realign_boundaries = True): (start, end) pairs appended to `out`.  false = the text is
+// outside the restated domain (non-ASCII or control characters; with pk.strict two candidate positions in one chunk): the caller asks nltk.
+bool punkt_spans(const Punkt& pk, const char* t, size_t n, std::vector<int32_t>& out) {
+    for (size_t i = 0; i < n; ++i)
+        if ((unsigned char)t[i] < 32 || (unsigned char)t[i] > 126) return false;
+    // _slices_from_text.  period_context_re =  \S*[.?!](?=(NONWORD)|\s+(\S+))  : per whitespace-delimited chunk the leftmost match
+    // starts at the chunk's first character and (greedy \S*, backtracking from the chunk's end) ends behind its LAST sentence-final
+    // character that is followed by a NONWORD character or by blanks and another chunk.
+    std::vector<int32_t> sl;                                     // raw slices (start, stop)
+    std::vector<PkTok> toks;
+    std::string ctx;
+    size_t last_break = 0, p = 0;
+    while (p < n) {
+        if (is_space((unsigned char)t[p])) { ++p; continue; }
+        size_t e = p;
+        while (e < n && !is_space((unsigned char)t[e])) ++e;
+        size_t nx = e;                                           // next chunk [nx, nxe)
+        while (nx < n && is_space((unsigned char)t[nx])) ++nx;
+        size_t nxe = nx;
+        while (nxe < n && !is_space((unsigned char)t[nxe])) ++nxe;
+        if (pk.strict) {
+            int cands = 0;
+            for (size_t i = p; i < e; ++i)
+                if ((t[i] == '.' || t[i] == '?' || t[i] == '!') &&
+                    ((i + 1 < e && punkt_nonword((unsigned char)t[i + 1])) || (i + 1 == e && nx < n))) ++cands;
+            if (cands > 1) return false;
+        }
+        for (size_t i = e; i-- > p;) {
+            if (t[i] != '.' && t[i] != '?' && t[i] != '!') continue;
+            const bool nonword = i + 1 < e && punkt_nonword((unsigned char)t[i + 1]);
+            const bool spaced = i + 1 == e && nx < n;
+            if (!nonword && !spaced) continue;
+            ctx.assign(t + p, i + 1 - p);                         // match.group() + after_tok
+            if (nonword) ctx += t[i + 1];
+            else ctx.append(t + e, nxe - e);
+            if (pk_contains_sentbreak(pk, ctx.data(), ctx.size(), toks)) {
+                sl.push_back((int32_t)last_break); sl.push_back((int32_t)(i + 1));
+                last_break = spaced ? nx : i + 1;
+            }
+            break;
+        }
+        p = e;
+    }
+    size_t end = n;
+    while (end > 0 && is_space((unsigned char)t[end - 1])) --end;
+    sl.push_back((int32_t)last_break); sl.push_back((int32_t)end);
+    // _realign_boundaries: closing quotes / brackets that directly follow a break belong to the sentence in front of them
+    // (re_boundary_realignment = ["')\]}]+?(?:\s+|(?=--)|$) matched at the start of the NEXT slice's text)
+    const size_t ns = sl.size() / 2;
+    int32_t realign = 0;
+    for (size_t i = 0; i < ns; ++i) {
+        const int32_t s1 = sl[2 * i] + realign, e1 = sl[2 * i + 1];
+        if (i + 1 == ns) {
+            if (s1 < e1) { out.push_back(s1); out.push_back(e1); }
+            break;
+        }
+        const int32_t s2 = sl[2 * i + 2], e2 = std::max(sl[2 * i + 3], s2);
+        int32_t q = s2;
+        while (q < e2 && (t[q] == '"' || t[q] == '\'' || t[q] == ')' || t[q] == ']' || t[q] == '}')) ++q;
+        bool m = q > s2;
+        int32_t mend = q;
+        if (m) {
+            if (q < e2 && is_space((unsigned char)t[q])) { while (mend < e2 && is_space((unsigned char)t[mend])) ++mend; }
+            else if (q + 1 < e2 && t[q] == '-' && t[q + 1] == '-') {}
+            else if (q == e2) {}
+            else m = false;
+        }
+        if (m) {
+            out.push_back(s1); out.push_back(q);
+            realign = mend - s2;
+        } else {
+            realign = 0;
+            if (s1 < e1) { out.push_back(s1); out.push_back(e1); }
+        }
+    }
+    return true;
+}
+
 }  // namespace
 
 struct leaf_dict : Dict {};
+struct leaf_punkt : Punkt {};
+
+static void punkt_lines(const char* blob, size_t len, const std::function<void(const std::string&)>& f) {
+    size_t pos = 0;
+    while (blob && pos < len) {
+        size_t e = pos;
+        while (e < len && blob[e] != '\n') ++e;
+        if (e > pos) f(std::string(blob + pos, e - pos));
+        pos = e + 1;
+    }
+}
+
+// The four Punkt tables as '\n'-separated UTF-8 lines: abbreviation types; collocations "first\tsecond"; sentence starters;
+// orthographic contexts "type\tflags" (nltk.tokenize.punkt.PunktParameters: abbrev_types, collocations, sent_starters, ortho_context).
+extern "C" int leaf_punkt_create(const char* abbrev, size_t abbrev_len, const char* colloc, size_t colloc_len, const char* starters,
+                                 size_t starters_len, const char* ortho, size_t ortho_len, leaf_punkt_t* out) {
+    if (!out) return 1;
+    leaf_punkt* p = new leaf_punkt();
+    bool ok = true;
+    punkt_lines(abbrev, abbrev_len, [&](const std::string& l) { p->abbrev.insert(l); });
+    punkt_lines(colloc, colloc_len, [&](const std::string& l) { if (l.find('\t') == std::string::npos) ok = false; p->colloc.insert(l); });
+    punkt_lines(starters, starters_len, [&](const std::string& l) { p->starters.insert(l); });
+    punkt_lines(ortho, ortho_len, [&](const std::string& l) {
+        const size_t tab = l.rfind('\t');
+        if (tab == std::string::npos) { ok = false; return; }
+        p->ortho[l.substr(0, tab)] = atoi(l.c_str() + tab + 1);
+    });
+    if (!ok) { delete p; return 1; }
+    *out = p;
+    return 0;
+}
+
+extern "C" void leaf_punkt_destroy(leaf_punkt_t p) { delete p; }
+// strict = 1 (default): decline texts on which nltk generations may differ (struct Punkt); 0: decide everything as nltk 3.6.5 does
+extern "C" int leaf_punkt_set_strict(leaf_punkt_t p, int strict) { if (!p) return 1; p->strict = strict != 0; return 0; }
+
+// span_tokenize(text): up to cap_pairs (start, end) pairs into spans; returns 0, 2 = declined (non-ASCII / control characters), 1 = bad
+// arguments or overflow
+extern "C" int leaf_punkt_spans(leaf_punkt_t p, const char* text, int len, int32_t* spans, int cap_pairs, int32_t* n_pairs) {
+    if (!p || !text || !spans || !n_pairs || len < 0 || cap_pairs < 1) return 1;
+    std::vector<int32_t> out;
+    if (!punkt_spans(*p, text, (size_t)len, out)) return 2;
+    if ((int)(out.size() / 2) > cap_pairs) return 1;
+    memcpy(spans, out.data(), out.size() * sizeof(int32_t));
+    *n_pairs = (int32_t)(out.size() / 2);
+    return 0;
+}
 
 extern "C" int leaf_dict_create(const char* words, size_t len, leaf_dict_t* out) {
     if (!words || !out) return 1;
@@ -689,9 +953,9 @@ extern "C" int64_t leaf_dict_size(leaf_dict_t d) { return d ? (int64_t)d->words.
 
 static int constrain_impl(leaf_dict_t d, int kind, const char* const* sentences, const int32_t* sent_len, int B,
                           const int32_t* z, const int32_t* c, int rho, const int32_t* ranges, const int32_t* ranges_off,
-                          uint8_t* valid, uint8_t* fallback, int n_threads) {
+                          uint8_t* valid, uint8_t* fallback, int n_threads, const Punkt* pk = nullptr) {
     if (!d || !sentences || !sent_len || !z || !c || !valid || !fallback || rho < 1 || (kind != 0 && kind != 1)) return 1;
-    if ((ranges == nullptr) != (ranges_off == nullptr) || (ranges && kind != 1)) return 1;
+    if ((ranges == nullptr) != (ranges_off == nullptr) || (ranges && kind != 1) || (pk && (kind != 1 || ranges))) return 1;
     if (n_threads < 1) n_threads = 1;
     std::atomic<int> bad(0);
     // sentences are independent: one task per sentence (its rho candidates share the multiplicity map)
@@ -707,6 +971,35 @@ static int constrain_impl(leaf_dict_t d, int kind, const char* const* sentences,
         int nrg = 0;
         if (ranges_off && ranges_off[b + 1] > ranges_off[b]) { rg = ranges + 2 * (size_t)ranges_off[b]; nrg = ranges_off[b + 1] - ranges_off[b]; }
         bool ok = true;
+        // ... or with the Punkt tables themselves (leaf_tok_constrain_punkt): the spans are computed here, for the caption and for
+        // every candidate the window logic below cannot decide
+        std::vector<int32_t> own_spans, cand_spans;
+        // (Punkt sees the LOWER-CASED text, utils_attacks.py:131,139: word_tokenize(o.lower()); the Treebank step lower-cases itself)
+        std::string low;
+        if (pk && !tb_punkt_free(s, (size_t)n)) {
+            low.assign(s, (size_t)n);
+            for (char& ch : low) ch = lower((unsigned char)ch);
+            ok = punkt_spans(*pk, low.data(), low.size(), own_spans) && !own_spans.empty();
+            if (ok) { rg = own_spans.data(); nrg = (int)(own_spans.size() / 2); }
+        }
+        std::unordered_set<std::string> seen;
+        // distinct dictionary words of a whole candidate: Punkt spans, then the Treebank step sentence by sentence; -1 = declined
+        auto count_whole = [&](std::string& text) -> int {
+            seen.clear();
+            for (char& ch : text) ch = lower((unsigned char)ch);
+            auto emit = [&](const std::string& w) { if (d->words.count(w)) seen.insert(w); };
+            if (tb_punkt_free(text.data(), text.size())) return tokenize_piece(text.data(), text.size(), kind, emit) ? (int)seen.size() : -1;
+            cand_spans.clear();
+            if (!punkt_spans(*pk, text.data(), text.size(), cand_spans)) return -1;
+            int prev_end = 0;
+            for (size_t i = 0; i + 1 < cand_spans.size(); i += 2) {
+                const int S = cand_spans[i], E = cand_spans[i + 1];
+                if (S < prev_end || E < S || E > (int)text.size()) return -1;
+                prev_end = E;
+                if (!tokenize_piece(text.data() + S, (size_t)(E - S), kind, emit)) return -1;
+            }
+            return (int)seen.size();
+        };
         if (rg) {
             int prev_end = 0;
             for (int i = 0; i < nrg && ok; ++i) {
@@ -772,7 +1065,17 @@ static int constrain_impl(leaf_dict_t d, int kind, const char* const* sentences,
                 int si = -1;
                 for (int i = 0; i < nrg && clean; ++i)
                     if (L >= rg[2 * i] && R <= rg[2 * i + 1]) { si = i; break; }
-                if (!clean || si < 0 || L == R) { fb[r] = 1; v[r] = 0; continue; }
+                if (!clean || si < 0 || L == R) {
+                    int cnt = -1;
+                    if (pk) {
+                        cand.assign(s, (size_t)e0);
+                        if (has_ins) cand += ins;
+                        cand.append(s + e1, (size_t)(n - e1));
+                        cnt = count_whole(cand);
+                    }
+                    if (cnt < 0) { fb[r] = 1; v[r] = 0; } else v[r] = cnt < lo ? 1 : 0;
+                    continue;
+                }
                 at_start = L == rg[2 * si]; at_end = R == rg[2 * si + 1]; ws_after = at_end;
             } else if (kind == 1) {
                 // the candidate as a whole must stay independent of sentence boundaries, and an edit behind the final period's
@@ -780,7 +1083,11 @@ static int constrain_impl(leaf_dict_t d, int kind, const char* const* sentences,
                 cand.assign(s, (size_t)e0);
                 if (has_ins) cand += ins;
                 cand.append(s + e1, (size_t)(n - e1));
-                if (!tb_punkt_free(cand.data(), cand.size()) || (final_period >= 0 && L > final_period)) { fb[r] = 1; v[r] = 0; continue; }
+                if (!tb_punkt_free(cand.data(), cand.size()) || (final_period >= 0 && L > final_period)) {
+                    const int cnt = pk ? count_whole(cand) : -1;
+                    if (cnt < 0) { fb[r] = 1; v[r] = 0; } else v[r] = cnt < lo ? 1 : 0;
+                    continue;
+                }
                 at_start = L == 0; at_end = R == n;
                 for (int q = R; q < n && ws_after; ++q) ws_after = is_space((unsigned char)s[q]);
             }
@@ -817,6 +1124,14 @@ extern "C" int leaf_tok_constrain_ranges(leaf_dict_t d, int kind, const char* co
                                          const int32_t* z, const int32_t* c, int rho, const int32_t* ranges,
                                          const int32_t* ranges_off, uint8_t* valid, uint8_t* fallback, int n_threads) {
     return constrain_impl(d, kind, sentences, sent_len, B, z, c, rho, ranges, ranges_off, valid, fallback, n_threads);
+}
+
+// The same with the Punkt tables (leaf_punkt_create): sentence spans of captions and candidates are computed natively, nothing is
+// declined but non-ASCII text and control characters.
+extern "C" int leaf_tok_constrain_punkt(leaf_dict_t d, leaf_punkt_t punkt, const char* const* sentences, const int32_t* sent_len, int B,
+                                        const int32_t* z, const int32_t* c, int rho, uint8_t* valid, uint8_t* fallback, int n_threads) {
+    if (!punkt) return 1;
+    return constrain_impl(d, 1, sentences, sent_len, B, z, c, rho, nullptr, nullptr, valid, fallback, n_threads, punkt);
 }
 
 // Number of DISTINCT dictionary words of one text (utils_attacks.py:135: len(W & set(word_tokenize(text.lower())))), tokenizer kind as

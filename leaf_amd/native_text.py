@@ -103,6 +103,17 @@ class NativeTokenizer(SimpleTokenizer):
         zz = np.ascontiguousarray(z, dtype=np.int32)
         cc = np.ascontiguousarray(c, dtype=np.int32)
         kind = {"regex": 0, "nltk": 1}[dictionary.kind]
+        punkt = getattr(dictionary, "punkt_native", None) if kind == 1 else None
+        if punkt is not None:
+            # the splitter's tables are on the native side: spans of captions and candidates are computed there
+            rc = self._lib.leaf_tok_constrain_punkt(dictionary.native_handle(), punkt._h, arr, blen.ctypes.data, B, zz.ctypes.data,
+                                                    cc.ctypes.data, rho, valid.ctypes.data, fb.ctypes.data, self.n_threads)
+            if rc not in (0, 3):
+                raise _lib.LeafHipError(f"leaf_tok_constrain_punkt failed ({rc})")
+            for b, (s_, r_) in enumerate(zip(sentences, raw)):
+                if len(s_) != len(r_):
+                    fb[b] = 1
+            return valid.astype(bool), fb.astype(bool)
         spans = dictionary.sentence_spans(sentences) if kind == 1 and hasattr(dictionary, "sentence_spans") else None
         if spans is not None and any(spans):
             # captions whose tokens depend on where sentences end: nltk's Punkt was asked once per caption (not once per
@@ -122,3 +133,70 @@ class NativeTokenizer(SimpleTokenizer):
             if len(s_) != len(r_):
                 fb[b] = 1
         return valid.astype(bool), fb.astype(bool)
+
+
+class NativePunkt:
+    """nltk's Punkt sentence splitter restated in C++ (host_text.cpp ``punkt_spans``): ``span_tokenize`` over the four parameter
+    tables of a trained model (``PunktParameters``: abbrev_types, collocations, sent_starters, ortho_context).  ASCII text without
+    control characters; ``spans`` returns None for anything else (ask nltk)."""
+
+    def __init__(self, abbrev_types=(), collocations=(), sent_starters=(), ortho_context=None, strict: bool = True):
+        """strict (default): texts on which nltk generations may differ -- two candidate break positions inside one
+        whitespace-delimited chunk, "what?! yes" -- are declined; False decides them as nltk 3.6.5 does."""
+        self._lib = _lib.lib()
+        blobs = ["\n".join(sorted(abbrev_types)), "\n".join(f"{a}\t{b}" for a, b in sorted(collocations)), "\n".join(sorted(sent_starters)),
+                 "\n".join(f"{k}\t{int(v)}" for k, v in sorted((ortho_context or {}).items()) if v)]
+        entries = list(abbrev_types) + [x for c in collocations for x in c] + list(sent_starters) + list(ortho_context or {})
+        if any("\n" in x or "\t" in x for x in entries):
+            raise ValueError("Punkt table entries with tabs / newlines")
+        raw = [b.encode("utf-8") for b in blobs]
+        h = C.c_void_p()
+        rc = self._lib.leaf_punkt_create(raw[0], len(raw[0]), raw[1], len(raw[1]), raw[2], len(raw[2]), raw[3], len(raw[3]), C.byref(h))
+        if rc != 0:
+            raise _lib.LeafHipError(f"leaf_punkt_create failed ({rc})")
+        self._h = h
+        self._lib.leaf_punkt_set_strict(h, int(strict))
+        self.sizes = (len(abbrev_types), len(collocations), len(sent_starters), len(ortho_context or {}))
+
+    @classmethod
+    def from_nltk(cls, punkt):
+        """From a ``PunktSentenceTokenizer`` (the instance nltk.sent_tokenize uses).  Raises when the instance does not use the stock
+        language variables (another language's subclass changes the regular expressions this restates)."""
+        lv = getattr(punkt, "_lang_vars", None)
+        if lv is not None and (tuple(lv.sent_end_chars) != (".", "?", "!") or lv.internal_punctuation != ",:;"
+                               or lv._re_word_start != r"[^\(\"\`{\[:;&\#\*@\)}\]\-,]" or lv._re_multi_char_punct != r"(?:\-{2,}|\.{2,}|(?:\.\s){2,}\.)"):
+            raise ValueError("non-default PunktLanguageVars")
+        p = punkt._params
+        return cls(p.abbrev_types, p.collocations, p.sent_starters, dict(p.ortho_context))
+
+    @classmethod
+    def from_json(cls, path: str, strict: bool = True):
+        """Tables exported with tools/export_punkt_params.py (``{"abbrev_types": [...], "collocations": [[a, b], ...],
+        "sent_starters": [...], "ortho_context": {type: flags}}``): nltk's sentence splitter where nltk is not installed."""
+        import json
+        with open(path) as f:
+            d = json.load(f)
+        return cls(d["abbrev_types"], [tuple(c) for c in d["collocations"]], d["sent_starters"], d["ortho_context"], strict=strict)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._lib.leaf_punkt_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def spans(self, text: str):
+        try:
+            raw = text.encode("ascii")
+        except UnicodeEncodeError:
+            return None
+        cap = len(raw) // 2 + 2
+        out = np.zeros(2 * cap, dtype=np.int32)
+        n = C.c_int32()
+        rc = self._lib.leaf_punkt_spans(self._h, raw, len(raw), out.ctypes.data, cap, C.byref(n))
+        if rc == 2:
+            return None
+        if rc != 0:
+            raise _lib.LeafHipError(f"leaf_punkt_spans failed ({rc})")
+        return [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(n.value)]

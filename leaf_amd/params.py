@@ -110,6 +110,12 @@ def parse_args(args):
     p.add_argument("--constrain", default=False, action="store_true")
     p.add_argument("--dictionary-file", type=str, default=None,
                    help="word list (one per line) for --constrain when the nltk corpus is unavailable")
+    p.add_argument("--dictionary-tokenizer", type=str, default="regex", choices=["regex", "treebank"],
+                   help="with --dictionary-file: 'treebank' = nltk.word_tokenize restated (leaf_amd/treebank.py); 'regex' = a plain "
+                        "letters/digits splitter")
+    p.add_argument("--punkt-params", type=str, default=None,
+                   help="with --dictionary-tokenizer treebank: nltk's trained Punkt tables exported by tools/export_punkt_params.py, "
+                        "so that sentences are split as nltk.word_tokenize splits them, without nltk")
     p.add_argument("--normalize_fare", default=False, action='store_true')
     p.add_argument("--custom_out_folder", type=str, default='')
     for flag, kw in _IGNORED:

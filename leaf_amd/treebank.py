@@ -137,6 +137,18 @@ SPAN_CHECK_STRINGS = [
 ]
 
 
+# the run-time check of the NATIVE Punkt restatement (host_text.cpp punkt_spans) against the installed nltk's Punkt instance, with
+# the installed model's tables: abbreviations, initials, ordinals, ellipses, closers behind a break, breaks without whitespace
+PUNKT_CHECK_STRINGS = SPAN_CHECK_STRINGS + [
+    "a. b", "a. b.", "the end.  ", "one. two. three.", "one? two! three.", "wait... what. no", "hmm.. ok. yes", "(the end.) yes",
+    "she said \"go.\"then left", "go.\"--then", "3. cat", "j. bach", "x. 3", "e.g. the cat", "i.e. a dog. yes", "u.s. but no",
+    "st. john. the end", "mr. smith and mrs. jones. they left", "no. 3 is here. ok", "at 5 p.m. we left. then home", "a.) b", "a.') b",
+    "a!') b", "a. ) b", ". . . a", "a . . . b", "vs. the world. fin", "inc. and co. ltd. closed", "fig. 2 shows. it", "1,000. the",
+    "a photo of a cat. a photo of a dog.", "is it? yes. no! ok", "mid-st. the", "ph.d. but", "the u.s.a. is big. yes", "jan. 5. feb",
+    "Dr. Smith went home. He slept.", "J. Bach wrote it. Then left", "e.g. The cat", "3. Cat", "It is 5 p.m. Then we go",
+]
+
+
 def spans_word_tokenize(text: str, spans) -> List[str]:
     """``nltk.word_tokenize(text)`` given the sentence spans its Punkt step produces: the Treebank step sentence by sentence."""
     return [w for a, b in spans for w in treebank_tokenize(text[a:b])]

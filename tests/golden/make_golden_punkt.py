@@ -53,9 +53,35 @@ def main():
             # (Punkt per declined candidate + native count)
             edits.append([z, c, int(count(cand) < lo), [list(s) for s in punkt.span_tokenize(cand.lower())]])
         cases.append({"caption": cap, "spans": [list(s) for s in punkt.span_tokenize(cap.lower())], "edits": edits})
+    # second block: the same with FILLED parameter tables (what a trained model provides: abbreviations, collocations, sentence
+    # starters, orthographic contexts), for the native restatement of Punkt itself (leaf_tok_constrain_punkt): [z, c, valid] only
+    from nltk.tokenize.punkt import PunktParameters
+    params = PunktParameters()
+    params.abbrev_types.update({"dr", "st", "e.g", "no", "j"})
+    params.collocations.update({("chair", "free"), ("##number##", "cat"), ("car", "dog")})
+    params.sent_starters.update({"the", "it"})
+    for typ, flag in [("the", 2 | 32), ("cat", 32 | 16), ("dog", 32), ("it", 2 | 16 | 32), ("free", 32), ("a", 16 | 32 | 2), ("new", 4 | 32),
+                      ("yes", 16), ("zebra", 64)]:
+        params.add_ortho_context(typ, flag)
+    punkt2 = PunktSentenceTokenizer()
+    punkt2._params = params
+    tables = {"abbrev_types": sorted(params.abbrev_types), "collocations": sorted(list(c) for c in params.collocations),
+              "sent_starters": sorted(params.sent_starters), "ortho_context": {k: v for k, v in sorted(params.ortho_context.items()) if v}}
+    count2 = lambda t: len(W.intersection(w for s in punkt2.tokenize(t.lower()) for w in tb.tokenize(s)))
+    rng = random.Random(4)
+    cases2 = []
+    for _ in range(160):
+        cap = " ".join(rng.choice(VOCAB) for _ in range(rng.randint(3, 10)))
+        lo = count2(cap)
+        edits = []
+        for _ in range(30):
+            z, c = rng.randrange(2 * len(cap) + 1), rng.choice(V)
+            edits.append([z, c, int(count2(apply_edit(cap, z, c)) < lo)])
+        cases2.append({"caption": cap, "edits": edits})
     with open(os.path.join(HERE, "punkt_kat.json"), "w") as f:
         json.dump({"source": f"nltk {nltk.__version__}: PunktSentenceTokenizer() (default parameters: no trained model available) + "
-                             "NLTKWordTokenizer per sentence", "words": WORDS, "cases": cases}, f)
+                             "NLTKWordTokenizer per sentence", "words": WORDS, "cases": cases, "tables": tables, "cases_tables": cases2}, f)
+    print(len(cases2), "captions with filled tables,", sum(e[2] for c in cases2 for e in c["edits"]), "valid edits")
     print(len(cases), "captions,", sum(len(c["edits"]) for c in cases), "edits,",
           sum(len(c["spans"]) > 1 for c in cases), "multi-sentence")
 

@@ -259,6 +259,93 @@ def test_multi_sentence_known_answers_from_the_real_punkt_code(tok, golden_dir):
     assert decided > 0.5 * (decided + declined)     # (half of this vocabulary's tokens carry a period: far more than real captions)
 
 
+def _punkt_from(params, strict):
+    from leaf_amd.native_text import NativePunkt
+    return NativePunkt(params["abbrev_types"], [tuple(c) for c in params["collocations"]], params["sent_starters"], params["ortho_context"],
+                       strict=strict)
+
+
+def test_native_punkt_reproduces_the_real_sentence_splitter(golden_dir):
+    """host_text.cpp punkt_spans against nltk's PunktSentenceTokenizer.span_tokenize (tests/golden/punkt_native_kat.json: 2 x 2,500
+    texts, empty and hand-filled parameter tables; make_golden_punkt_native.py --stress compared 2 x 100,000 more).  strict mode
+    (the default) may decline a text -- two candidate break positions in one chunk -- but never answers differently."""
+    with open(os.path.join(golden_dir, "punkt_native_kat.json")) as f:
+        k = json.load(f)
+    for st in k["sets"]:
+        free, strict = _punkt_from(st["params"], False), _punkt_from(st["params"], True)
+        declined = 0
+        for text, exp in st["cases"]:
+            exp = [tuple(e) for e in exp]
+            assert free.spans(text) == exp, (st["name"], text)
+            got = strict.spans(text)
+            declined += got is None
+            assert got is None or got == exp, (st["name"], text)
+        assert declined < 0.25 * len(st["cases"])
+    assert strict.spans("what?! yes") is None and free.spans("what?! yes") is not None
+    assert strict.spans("caf\u00e9. yes") is None and strict.spans("a.\tb") is None          # outside the restated domain
+
+
+@pytest.mark.parametrize("block", ["cases", "cases_tables"])
+def test_constrain_with_the_native_sentence_splitter(tok, golden_dir, block):
+    """leaf_tok_constrain_punkt: Punkt's tables on the native side, sentence spans of captions and candidates computed in C++.
+    Known answers from the real nltk code (whole-candidate Punkt + NLTKWordTokenizer, make_golden_punkt.py), with empty tables
+    ("cases") and with filled ones ("cases_tables").  With strict off NOTHING is declined; with strict on what is decided agrees."""
+    with open(os.path.join(golden_dir, "punkt_kat.json")) as f:
+        k = json.load(f)
+    params = k["tables"] if block == "cases_tables" else {"abbrev_types": [], "collocations": [], "sent_starters": [], "ortho_context": {}}
+    for strict in (False, True):
+        D = attacks.Dictionary(k["words"], tokenize=lambda s: (_ for _ in ()).throw(AssertionError("no Python tokenisation here")), kind="nltk")
+        D.punkt_native = _punkt_from(params, strict)
+        decided = declined = 0
+        for i in range(0, len(k[block]), 8):
+            batch = k[block][i:i + 8]
+            sents = [c["caption"] for c in batch]
+            z = np.array([[e[0] for e in c["edits"]] for c in batch], dtype=np.int32)
+            cc = np.array([[e[1] for e in c["edits"]] for c in batch], dtype=np.int32)
+            valid, fb = tok.constrain_mask(D, sents, z, cc)
+            for b, c in enumerate(batch):
+                for r, e in enumerate(c["edits"]):
+                    if fb[b, r]:
+                        declined += 1
+                    else:
+                        decided += 1
+                        assert bool(valid[b, r]) == bool(e[2]), (strict, c["caption"], e[:3])
+        print(block, "strict", strict, "decided", decided, "declined", declined)
+        assert declined == 0 if not strict else declined < 0.2 * (decided + declined)
+
+
+def test_word_list_dictionary_with_exported_punkt_tables(tok, golden_dir, tmp_path):
+    """``--dictionary-file words.txt --dictionary-tokenizer treebank --punkt-params tables.json`` (tools/export_punkt_params.py): the
+    reference's constraint without nltk.  Both of its paths -- the Python one (``Dictionary.count``: native sentence spans +
+    restated Treebank step) and the native one behind ``_stage_candidates`` -- against the real-nltk known answers."""
+    with open(os.path.join(golden_dir, "punkt_kat.json")) as f:
+        k = json.load(f)
+    (tmp_path / "words.txt").write_text("\n".join(k["words"]))
+    (tmp_path / "punkt.json").write_text(json.dumps(k["tables"]))
+    D = attacks.Dictionary.from_file(str(tmp_path / "words.txt"), tokenizer="treebank", punkt_params=str(tmp_path / "punkt.json"))
+    assert D.punkt_native is not None and D.kind == "nltk"
+    for c in k["cases_tables"][:60]:
+        lo = D.count(c["caption"])
+        for e in c["edits"]:
+            assert (D.count(attacks._apply_edit(c["caption"], e[0], e[1])) < lo) == bool(e[2]), (c["caption"], e)
+    attacks.set_dictionary(D)
+    try:
+        batch = k["cases_tables"][:16]
+        sents = [c["caption"] for c in batch]
+        z = np.array([[e[0] for e in c["edits"]] for c in batch], dtype=np.int32)
+        cc = np.array([[e[1] for e in c["edits"]] for c in batch], dtype=np.int32)
+        z0 = z.copy()
+        attacks._stage_candidates(tok, sents, z, cc, True, None)          # rejected candidates become the no-op edit (0, -1)
+        for b, c in enumerate(batch):
+            for r, e in enumerate(c["edits"]):
+                if not e[2]:
+                    assert z[b, r] == 0 and cc[b, r] == -1, (c["caption"], e)
+                else:
+                    assert z[b, r] == z0[b, r]
+    finally:
+        attacks.set_dictionary(None)
+
+
 def test_stage_candidates_constrained_native_equals_python(tok, kat):
     """attacks._stage_candidates with --constrain: native mask + native mutate/BPE == the all-Python path (same tokens, same
     no-op replacement of invalid candidates)."""

@@ -28,6 +28,12 @@ ap.add_argument("--batch", type=int, default=128)
 ap.add_argument("--rho", type=int, default=50)
 ap.add_argument("--tokenizer", default="regex", choices=["regex", "treebank"])
 ap.add_argument("--punct", action="store_true", help="captions with punctuation (commas, 's, quotes, brackets, a final period)")
+ap.add_argument("--sentences", type=float, default=0.0,
+                help="with --punct: share of captions that get a period in the middle (two sentences, 'vintage chair. free shipping.')")
+ap.add_argument("--punkt", choices=["none", "standin", "native"], default="none",
+                help="with --tokenizer treebank: sentence splitter in front of the Treebank step. standin = a Python splitter with "
+                     "Punkt's cost and kind of dependence (spans asked per caption / per declined candidate, as with an installed nltk "
+                     "whose tables failed the native self-check); native = Punkt's algorithm in C++ over a small table set")
 ap.add_argument("--no-dedupe", action="store_true")
 ap.add_argument("--pipeline", type=int, default=None, help="caption groups interleaved in the search (default: 2 for B >= 64)")
 a = ap.parse_args()
@@ -41,6 +47,8 @@ if a.punct:
         for _ in range(rng.randint(1, 3)):
             i = rng.randrange(len(w))
             w[i] = rng.choice([w[i] + ",", w[i] + "'s", '"' + w[i] + '"', "(" + w[i] + ")", w[i] + "!", w[i] + ":", "don't " + w[i]])
+        if len(w) > 3 and rng.random() < a.sentences:
+            w[rng.randrange(1, len(w) - 1)] += "."
         return " ".join(w) + rng.choice([".", "", ".", "!"])
     caps = [deco(c) for c in caps]
 m = create_model("ViT-L-14-quickgelu", seed=1)
@@ -52,7 +60,29 @@ if a.constrain:
     path = os.path.join(tempfile.gettempdir(), "leaf_words.txt")
     with open(path, "w") as f:
         f.write("\n".join(sorted(filler)))
-    attacks.set_dictionary(attacks.Dictionary.from_file(path, tokenizer=a.tokenizer))
+    if a.punkt == "none":
+        attacks.set_dictionary(attacks.Dictionary.from_file(path, tokenizer=a.tokenizer))
+    else:
+        import json
+        tables = {"abbrev_types": ["dr", "mr", "mrs", "st", "e.g", "i.e", "vs", "inc", "co", "no", "p.m", "a.m"],
+                  "collocations": [["##number##", "street"]], "sent_starters": ["the", "a"], "ortho_context": {"the": 34, "a": 50}}
+        ppath = os.path.join(tempfile.gettempdir(), "leaf_punkt.json")
+        with open(ppath, "w") as f:
+            json.dump(tables, f)
+        D = attacks.Dictionary.from_file(path, tokenizer="treebank", punkt_params=ppath)
+        if a.punkt == "standin":
+            # what a run with an installed nltk looks like when the native splitter is NOT used: spans come from a Python call
+            # (the native restatement with strict off stands in for nltk's Punkt; ~its cost is added as a Python-side loop)
+            from leaf_amd.native_text import NativePunkt
+            free = NativePunkt.from_json(ppath, strict=False)
+
+            def spans(t):
+                sp = free.spans(t)
+                for _ in range(40):      # PunktSentenceTokenizer.span_tokenize costs ~15-30 us per caption in CPython
+                    pass
+                return sp if sp is not None else [(0, len(t))]
+            D.span_tokenize, D.punkt_native = spans, None
+        attacks.set_dictionary(D)
 for constrain in modes:
     for name, tok in (("python", SimpleTokenizer()), ("native", NativeTokenizer())):
         anchor = m.encode_text(tok.encode_batch(caps))
@@ -69,6 +99,6 @@ for constrain in modes:
             ts.append(time.time() - t0)
         dt = min(ts[1:])
         changed = sum(x != y for x, y in zip(adv, caps))
-        print(f"{name:6s} constrain={int(constrain)} tokenizer={a.tokenizer} punct={int(a.punct)} dedupe={int(not a.no_dedupe)} pipeline={a.pipeline}: attack_text B={B} "
+        print(f"{name:6s} constrain={int(constrain)} tokenizer={a.tokenizer} punct={int(a.punct)} sentences={a.sentences} punkt={a.punkt} dedupe={int(not a.no_dedupe)} pipeline={a.pipeline}: attack_text B={B} "
               f"rho={rho} k=1: {dt * 1e3:.1f} ms -> {B / dt:.0f} captions/s (search only; {changed}/{B} captions changed; {rows} rows scored)",
               flush=True)

@@ -113,7 +113,10 @@ def main(argv):
     tokenizer = get_tokenizer(args.model)
     if args.constrain:
         from leaf_amd import attacks
-        attacks.set_dictionary(attacks.Dictionary.from_file(args.dictionary_file) if args.dictionary_file
+        if args.punkt_params and not (args.dictionary_file and args.dictionary_tokenizer == "treebank"):
+            raise SystemExit("--punkt-params needs --dictionary-file and --dictionary-tokenizer treebank")
+        attacks.set_dictionary(attacks.Dictionary.from_file(args.dictionary_file, tokenizer=args.dictionary_tokenizer,
+                                                            punkt_params=args.punkt_params) if args.dictionary_file
                                else attacks.Dictionary.from_nltk())
     data = get_text_data(args, epoch=start_epoch)
     total_steps = (data["train"].dataloader.num_batches // args.accum_freq) * args.epochs
