@@ -71,15 +71,14 @@ if a.constrain:
             json.dump(tables, f)
         D = attacks.Dictionary.from_file(path, tokenizer="treebank", punkt_params=ppath)
         if a.punkt == "standin":
-            # what a run with an installed nltk looks like when the native splitter is NOT used: spans come from a Python call
-            # (the native restatement with strict off stands in for nltk's Punkt; ~its cost is added as a Python-side loop)
+            # the round-3 path before the native splitter: spans come from a Python call per multi-sentence caption and per declined
+            # candidate (here a ctypes call of ~5 us stands in for nltk's PunktSentenceTokenizer.span_tokenize, ~25 us in CPython: a
+            # LOWER bound of that path's host time)
             from leaf_amd.native_text import NativePunkt
             free = NativePunkt.from_json(ppath, strict=False)
 
             def spans(t):
                 sp = free.spans(t)
-                for _ in range(40):      # PunktSentenceTokenizer.span_tokenize costs ~15-30 us per caption in CPython
-                    pass
                 return sp if sp is not None else [(0, len(t))]
             D.span_tokenize, D.punkt_native = spans, None
         attacks.set_dictionary(D)
