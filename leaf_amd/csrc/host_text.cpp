@@ -925,7 +925,7 @@ extern "C" int leaf_punkt_spans(leaf_punkt_t p, const char* text, int len, int32
     std::vector<int32_t> out;
     if (!punkt_spans(*p, text, (size_t)len, out)) return 2;
     if ((int)(out.size() / 2) > cap_pairs) return 1;
-    memcpy(spans, out.data(), out.size() * sizeof(int32_t));
+    if (!out.empty()) memcpy(spans, out.data(), out.size() * sizeof(int32_t));
     *n_pairs = (int32_t)(out.size() / 2);
     return 0;
 }

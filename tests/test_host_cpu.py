@@ -226,3 +226,29 @@ def test_native_tokenizer_from_concurrent_host_threads():
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert not bad
+
+
+def test_host_text_under_sanitizers(tmp_path):
+    """The native host pipeline's text entry points (mutation + BPE, duplicate map, Punkt spans, the three --constrain forms, word
+    counts) built with
+    AddressSanitizer + UndefinedBehaviorSanitizer on the CPU and fuzzed with random captions, control and non-ASCII bytes included
+    (tests/fuzz_host_text.cpp); sanitizers are CPU-only on this pool."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "fuzz_host_text")
+    b = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                        "-fno-omit-frame-pointer", "-pthread", os.path.join(root, "leaf_amd", "csrc", "host_text.cpp"),
+                        os.path.join(root, "tests", "fuzz_host_text.cpp"), "-o", exe], capture_output=True, text=True, timeout=600)
+    if b.returncode != 0 and "sanitize" in b.stderr and "cannot find" in b.stderr:
+        pytest.skip("sanitizer runtime not installed")
+    assert b.returncode == 0, b.stderr[-3000:]
+    import gzip
+    from leaf_amd.tokenizer import _BPE_PATH
+    merges = tmp_path / "merges.txt"
+    with gzip.open(_BPE_PATH) as f:
+        merges.write_bytes(f.read())
+    r = subprocess.run([exe, "4000", str(merges)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "fuzz ok" in r.stdout and "runtime error" not in r.stderr, r.stdout[-1500:] + r.stderr[-3000:]
