@@ -1,6 +1,8 @@
 #!/bin/bash
 # End-to-end throughput of the REAL trainer (strings in, train_one_epoch_text_only): ViT-L, B = 128, rho = 50, k = 1, synthetic captions,
-# with and without --constrain (word-list file + the regex word tokenizer).  Prints the trainer's own samples/s log lines.
+# with and without --constrain (word-list file + the regex word tokenizer), and with --constrain on web-style captions from a file
+# (punctuation, 15 % two-sentence) under the reference's word tokenizer restated (Treebank step + Punkt tables).  Prints the trainer's
+# own samples/s log lines.
 # usage: tools/trainer_bench.sh OUTDIR
 OUT=$(realpath -m $1); mkdir -p $OUT
 W=/tmp/leaf_trainer_bench; rm -rf $W; mkdir -p $W      # checkpoints and the word list stay out of OUT (only logs go there)
@@ -13,9 +15,30 @@ while len(w) < 236736:
     w.add("".join(rng.choice("abcdefghijklmnopqrstuvwxyz") for _ in range(rng.randint(2, 10))))
 print("\n".join(sorted(w)))
 PY
+# web-style captions for the third run: punctuation, some with two sentences ("vintage chair. free shipping!"), and a small Punkt
+# table set in the format of tools/export_punkt_params.py
+python - <<'PY'
+import json, random
+from leaf_amd.train import _SYN_WORDS
+rng = random.Random(1)
+caps = []
+for _ in range(7680):
+    w = [rng.choice(_SYN_WORDS) for _ in range(rng.randint(3, 14))]
+    for _ in range(rng.randint(0, 2)):
+        i = rng.randrange(len(w))
+        w[i] = rng.choice([w[i] + ",", w[i] + "'s", '"' + w[i] + '"', "(" + w[i] + ")", w[i] + "!", w[i] + ":", "dr. " + w[i], "no. 5 " + w[i]])
+    if len(w) > 3 and rng.random() < 0.15:
+        w[rng.randrange(1, len(w) - 1)] += "."
+    caps.append(" ".join(w) + rng.choice([".", "", ".", "!"]))
+open("/tmp/leaf_trainer_bench/captions.txt", "w").write("\n".join(caps))
+json.dump({"abbrev_types": ["dr", "mr", "mrs", "st", "e.g", "i.e", "vs", "inc", "co", "no", "p.m", "a.m"], "collocations": [["##number##", "street"]],
+           "sent_starters": ["the", "a"], "ortho_context": {"the": 34, "a": 50}}, open("/tmp/leaf_trainer_bench/punkt.json", "w"))
+PY
 ROOT=$PWD
-for c in "" "--constrain --dictionary-file $W/words.txt"; do
-  name=run$( [ -n "$c" ] && echo _constrain )
+i=0
+for c in "" "--constrain --dictionary-file $W/words.txt" \
+         "--constrain --dictionary-file $W/words.txt --dictionary-tokenizer treebank --punkt-params $W/punkt.json --dataset-type text --train-data $W/captions.txt"; do
+  i=$((i + 1)); name=run$i
   (cd $W && timeout -k 10 400 python $ROOT/train_AT_text_only.py --model ViT-L-14-quickgelu --random-init --dataset-type synthetic \
      --train-num-samples 7680 --batch-size 128 --epochs 1 --rho 50 --k_adv 1 --lr 1e-5 --wd 1e-4 --warmup 10 --log-every-n-steps 10 \
      --save-frequency 0 --seed 1 --custom_out_folder b_ --logs $W/logs --name $name $c > $OUT/$name.log 2>&1)
