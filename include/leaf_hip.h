@@ -220,7 +220,8 @@ int leaf_tok_mutate_encode(leaf_tok_t tk, const char* const* sentences, const in
  * tokenizer [A-Za-z0-9]+|[^\sA-Za-z0-9] (exact for all ASCII), 1 = nltk.word_tokenize: NLTKWordTokenizer's substitution pipeline
  * (nltk/tokenize/destructive.py, third-party: requirements.txt:14) restated window-locally, exact for ASCII text whose tokens
  * cannot depend on the Punkt sentence model -- a sentence / candidate in which a lone '.' ends a whitespace-delimited chunk
- * before the end of the text gets fallback = 1 and is decided by the caller with the real nltk. */
+ * before the end of the text gets fallback = 1 from THIS entry point and is decided by the caller with the real nltk
+ * (leaf_tok_constrain_ranges / leaf_tok_constrain_punkt below decide those natively too). */
 typedef struct leaf_dict* leaf_dict_t;
 int leaf_dict_create(const char* words, size_t len, leaf_dict_t* out);
 void leaf_dict_destroy(leaf_dict_t d);

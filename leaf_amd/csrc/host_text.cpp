@@ -360,7 +360,9 @@ extern "C" int leaf_tok_mutate_encode(leaf_tok_t tk, const char* const* sentence
 //           span whitespace, so the window logic is exact for every ASCII string;
 //   kind 1  nltk.word_tokenize: the Treebank substitution pipeline restated below (tb_tokenize_piece), exact on any ASCII text
 //           whose tokens cannot depend on Punkt's sentence boundaries; a sentence / candidate in which a lone '.' ends a chunk
-//           before the end of the text is declined (fallback = 1) and decided by the caller with the real tokenizer.
+//           before the end of the text needs sentence spans: from the caller (leaf_tok_constrain_ranges), from the restated
+//           Punkt over the model's tables (leaf_tok_constrain_punkt) -- or it is declined (fallback = 1) and decided by the
+//           caller with the real tokenizer.
 namespace {
 
 struct Dict {
@@ -378,8 +380,9 @@ inline char lower(unsigned char c) { return (char)((c >= 'A' && c <= 'Z') ? c + 
 // piece tokenises as it would inside the whole text once it is told whether it starts at the text's first character
 // (`at_start`: the ^" rule), ends at its last (`at_end`: the ([:,])$ rule) and whether only whitespace follows it (`ws_after`:
 // the two final-period rules, which end in \s*$).  Checked against nltk 3.6.5's own output (tests/golden/treebank_kat.json)
-// and against leaf_amd/treebank.py (tests/test_constrain_native.py).  What Punkt decides is NOT restated: texts in which a
-// lone '.' ends a chunk before the text's end are declined (tb_punkt_free), the caller asks the real nltk.
+// and against leaf_amd/treebank.py (tests/test_constrain_native.py).  Texts in which a lone '.' ends a chunk before the text's end
+// (tb_punkt_free false) tokenise differently depending on where Punkt ends sentences: they need sentence spans -- the caller's
+// (leaf_tok_constrain_ranges), the native Punkt restatement's further down (leaf_tok_constrain_punkt) -- or are declined.
 inline bool tb_word(unsigned char c) { return is_alnum(c) || c == '_'; }
 inline bool tb_closer(unsigned char c) { return c == ']' || c == ')' || c == '}' || c == '>' || c == '"' || c == '\''; }
 

@@ -16,11 +16,13 @@ Pinned by ``tests/golden/treebank_kat.json``: 1,800 strings tokenised by the REA
 /opt/conda; ``tests/golden/make_golden_treebank.py``), and re-checked at run time against whichever nltk is installed where
 training runs (``self_check``; a mismatch switches the native path off).
 
-What is NOT restated is Punkt: its decisions come from a trained model.  They can change the tokens only through the rules that
-are anchored at the end of a sentence string -- the final-period rules -- i.e. only for a lone '.' that ends a whitespace-delimited
-chunk somewhere INSIDE the text ("... cat. a dog ..."): whether "cat." stays one token depends on whether Punkt starts a new
-sentence there.  ``punkt_free(text)`` is False exactly for such texts; they are tokenised with the real ``word_tokenize`` (the
-native code declines them, one candidate at a time).  '?' and '!' are always split off, wherever sentences end.
+Punkt, the sentence splitter in front of this step, is restated natively (csrc/host_text.cpp ``punkt_spans``: the algorithm is
+fixed, the trained model only fills four parameter tables, which ``native_text.NativePunkt`` takes from the installed nltk or from
+a file exported by tools/export_punkt_params.py).  Its decisions can change the tokens only through the rules that are anchored at
+the end of a sentence string -- the final-period rules -- i.e. only for a lone '.' that ends a whitespace-delimited chunk somewhere
+INSIDE the text ("... cat. a dog ..."): whether "cat." stays one token depends on whether a sentence ends there.
+``punkt_free(text)`` is False exactly for such texts; only they need sentence spans at all (``word_tokenize`` below raises for
+them: it has no splitter).  '?' and '!' are always split off, wherever sentences end.
 """
 from __future__ import annotations
 
