@@ -148,8 +148,15 @@ class Dictionary:
                 logging.warning(f"the native Punkt restatement differs from the installed nltk on {wrong[:3]!r}...: sentence spans are "
                                 "asked from nltk (one call per multi-sentence caption and per candidate that touches a sentence end)")
                 return None
+            # texts with several candidate positions in one chunk: decided natively only if THIS nltk answers them like the restated
+            # rule (otherwise the native splitter keeps declining them: strict mode)
+            from .treebank import PUNKT_MULTI_CHECK_STRINGS
+            native.set_strict(False)
+            if not all(native.spans(t) == [(int(a), int(b)) for a, b in spans(t)] for t in PUNKT_MULTI_CHECK_STRINGS):
+                native.set_strict(True)
             logging.info("--constrain: nltk's Punkt tables loaded into the native sentence splitter (abbreviations %d, collocations %d, "
-                         "sentence starters %d, orthographic contexts %d)" % native.sizes)
+                         "sentence starters %d, orthographic contexts %d)" % native.sizes
+                         + ("" if not native.strict else "; texts with several sentence-end candidates in one chunk go to nltk"))
             return native
         except Exception as e:
             logging.warning(f"native Punkt unavailable ({e}): sentence spans are asked from nltk")

@@ -679,7 +679,8 @@ struct Punkt {
     // nltk 3.6.6+ finds the period contexts with a rewritten scan (the ReDoS fix, _match_potential_end_contexts) that is meant to be
     // equivalent to the regular expression restated here (3.6.5: \S*[.?!](?=...)) and provably is when a whitespace-delimited chunk
     // holds at most ONE candidate position; with `strict` a text with two or more in one chunk ("what?! yes", "wow!!! nice") is
-    // declined instead of decided with the older generation's rule.
+    // declined instead of decided with the older generation's rule.  The Python side switches strict off after the installed
+    // nltk has answered a battery of such texts like this rule (attacks.Dictionary._native_punkt).
     bool strict = true;
 };
 

@@ -156,7 +156,12 @@ class NativePunkt:
             raise _lib.LeafHipError(f"leaf_punkt_create failed ({rc})")
         self._h = h
         self._lib.leaf_punkt_set_strict(h, int(strict))
+        self.strict = bool(strict)
         self.sizes = (len(abbrev_types), len(collocations), len(sent_starters), len(ortho_context or {}))
+
+    def set_strict(self, strict: bool):
+        self._lib.leaf_punkt_set_strict(self._h, int(strict))
+        self.strict = bool(strict)
 
     @classmethod
     def from_nltk(cls, punkt):

@@ -151,6 +151,16 @@ PUNKT_CHECK_STRINGS = SPAN_CHECK_STRINGS + [
 ]
 
 
+# texts with TWO OR MORE candidate break positions inside one whitespace-delimited chunk: nltk 3.6.6 rewrote the scan that finds the
+# period contexts (its ReDoS fix); where the installed generation answers these like the 3.6.5 rule the native splitter restates,
+# its strict mode (decline such texts) is switched off (attacks.Dictionary._native_punkt)
+PUNKT_MULTI_CHECK_STRINGS = [
+    "what?! yes", "wow!!! nice", "very bad acting!!! i promise.", "a?\"b. c", "hm?!) ok", "no!? really. yes", "go!!\" she said. ok",
+    "a.) b.) c", "x?'y. z", "really?!?! no way. yes", "(what?!) he said", "stop!!!", "one!!! two??? three...", "e.g.?! no", "3.?) cat",
+    "wait...?! what", "\"no!\"? yes. ok", "a!b?c. d", "end.\"?) next", "ok?!.. fine",
+]
+
+
 def spans_word_tokenize(text: str, spans) -> List[str]:
     """``nltk.word_tokenize(text)`` given the sentence spans its Punkt step produces: the Treebank step sentence by sentence."""
     return [w for a, b in spans for w in treebank_tokenize(text[a:b])]

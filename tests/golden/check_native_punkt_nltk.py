@@ -65,6 +65,7 @@ def main():
     word_tokenize = lambda t: [w for s in punkt.tokenize(t) for w in tb.tokenize(s)]      # nltk.word_tokenize with this model
     native = attacks.Dictionary._native_punkt(punkt, spans)
     assert native is not None, "the native splitter failed its self-check against the trained instance"
+    print("strict mode after the start-up check against this nltk:", native.strict)
     D = attacks.Dictionary(WORDS, word_tokenize, kind="nltk")
     D.span_tokenize, D.punkt_native = spans, native
     tok = NativeTokenizer(n_threads=8)

@@ -285,6 +285,29 @@ def test_native_punkt_reproduces_the_real_sentence_splitter(golden_dir):
     assert strict.spans("caf\u00e9. yes") is None and strict.spans("a.\tb") is None          # outside the restated domain
 
 
+def test_native_punkt_start_up_check_against_the_installed_splitter(golden_dir):
+    """Dictionary._native_punkt (the from_nltk code path) with stand-ins for the installed Punkt instance: tables are taken from
+    the instance; the native splitter is used only if it reproduces the instance on the battery, and texts with several
+    sentence-end candidates in one chunk are decided natively only if the instance answers them like the restated rule."""
+    import types
+    with open(os.path.join(golden_dir, "punkt_kat.json")) as f:
+        tables = json.load(f)["tables"]
+    params = types.SimpleNamespace(abbrev_types=set(tables["abbrev_types"]), collocations={tuple(c) for c in tables["collocations"]},
+                                   sent_starters=set(tables["sent_starters"]), ortho_context=dict(tables["ortho_context"]))
+    punkt = types.SimpleNamespace(_params=params, _lang_vars=None)
+    same = _punkt_from(tables, False)
+    native = attacks.Dictionary._native_punkt(punkt, lambda t: same.spans(t))                 # an instance that follows the 3.6.5 rule
+    assert native is not None and native.strict is False and native.spans("what?! yes") is not None
+    from leaf_amd.treebank import PUNKT_MULTI_CHECK_STRINGS
+    other = lambda t: [(0, len(t.rstrip()))] if t in PUNKT_MULTI_CHECK_STRINGS else same.spans(t)    # differs on the ambiguous class only
+    native = attacks.Dictionary._native_punkt(punkt, other)
+    assert native is not None and native.strict is True and native.spans("what?! yes") is None and native.spans("a cat. a dog") is not None
+    assert attacks.Dictionary._native_punkt(punkt, lambda t: [(0, len(t))]) is None            # a different splitter altogether
+    punkt_de = types.SimpleNamespace(_params=params, _lang_vars=types.SimpleNamespace(
+        sent_end_chars=(".", "?", "!", ";"), internal_punctuation=",:;", _re_word_start="x", _re_multi_char_punct="y"))
+    assert attacks.Dictionary._native_punkt(punkt_de, lambda t: same.spans(t)) is None        # non-default language variables
+
+
 @pytest.mark.parametrize("block", ["cases", "cases_tables"])
 def test_constrain_with_the_native_sentence_splitter(tok, golden_dir, block):
     """leaf_tok_constrain_punkt: Punkt's tables on the native side, sentence spans of captions and candidates computed in C++.
