@@ -383,7 +383,15 @@ def attack_text_leaf(model, tokenizer, sentences, anchor_features, device=None, 
     import torch
     sentences = list(sentences)
     B = len(sentences)
+    def wait_anchor():
+        """the caller computed ``anchor_features`` on a side stream: order the current stream behind it, once"""
+        nonlocal anchor_ready
+        if anchor_ready is not None:
+            torch.cuda.current_stream().wait_event(anchor_ready)
+            anchor_ready = None
+
     if objective in ("dissim", "sim"):
+        wait_anchor()
         anchor_features /= anchor_features.norm(dim=-1, keepdim=True)   # in place, as the reference does
     Varr = np.asarray(V, dtype=np.int32)
     reuse = hasattr(model, "encode_text_kv") and getattr(model, "trim_rows", False)
@@ -412,10 +420,7 @@ def attack_text_leaf(model, tokenizer, sentences, anchor_features, device=None, 
         clean caption: ONE row under prefix reuse), the loss of its first occurrence is copied into it and the arg-max runs over
         the completed [Bg, rho] losses -- first index wins, so the first occurrence beats its copies exactly as in torch.argmax
         over the reference's full loss matrix (utils_attacks.py:348,386)."""
-        nonlocal anchor_ready
-        if anchor_ready is not None:
-            torch.cuda.current_stream().wait_event(anchor_ready)
-            anchor_ready = None
+        wait_anchor()
         Bg = anchor_g.shape[0]
         pl = prefix_lens(toks, base, Bg) if reuse else None
         dup = duplicate_map(toks, Bg, n) if dedupe else None
@@ -504,6 +509,7 @@ def attack_text_leaf(model, tokenizer, sentences, anchor_features, device=None, 
         best_feat = feats[0] if len(feats) == 1 else torch.cat(feats, 0)
         if debug:
             print(sentences[0])
+    wait_anchor()      # k == 0: nothing was scored, but the caller's next use of the anchor is on this stream
     return best_feat, sentences
 
 

@@ -78,7 +78,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const u16* __restrict__ q
     ctx = ctx < vrows ? ctx : vrows;                // never past the LDS image (the host sizes vrows from the true maximum)
     const u16* own = qkv + (size_t)row_s * ld + h * HD;
     const u16* cached = pfx ? kv_base + (size_t)map.base_cu[(sg - map.group_off) / map.group] * ld + h * HD : own;
+#ifdef LEAF_DIAG_ATTN_L2   // diagnostic only (garbage results): every q / k / v row comes out of the first 512 rows of the launch's qkv buffer
+                           // (2.4 MB: resident in every XCD's L2) -- attention as if its operands never left the chip
+    auto rowptr = [&](int pos) { return qkv + (size_t)((row_s + pos) & 511) * ld + h * HD; };
+    (void)cached;
+#else
     auto rowptr = [&](int pos) { return pos < pfx ? cached + (size_t)pos * ld : own + (size_t)(pos - pfx) * ld; };
+#endif
     const int r16 = lane & 15, g = lane >> 4;
     const int nt = (ctx + 15) >> 4;
     // query tiles below the prefix are not needed; with eot_pos (last layer: only the pooled row is consumed downstream)

@@ -55,14 +55,22 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
     // for every round of 32 tiles (the host picks the group size, launch256h).
     auto tile_coords = [&](int v, int& m0_, int& n0_) {
         const int logical = xcd_remap(v, ntiles);
-        const int G = (p.ngroup > 0 && p.ngroup < tiles_n) ? p.ngroup : tiles_n;
-        int g = logical / (tiles_m * G);
-        const int ng = (tiles_n + G - 1) / G;
+        // ngroup < 0: M-super-panel order, the mirror image -- M tiles in groups of P = -ngroup; inside a group N-major / M-minor.
+        // An XCD then sweeps ALL N tiles against P A panels (P x 256 rows x K, L2-resident after the first touch) before it moves
+        // on: the activations leave HBM once, the weight panels are re-fetched per group from the Infinity Cache (which they
+        // always fit).  Same arithmetic with the roles of the two tile dimensions swapped (branch-free: uniform selects).
+        const bool mp = p.ngroup < 0;
+        const int D = mp ? tiles_m : tiles_n, O = mp ? tiles_n : tiles_m;    // grouped dimension / the other one
+        int G = mp ? -p.ngroup : p.ngroup;
+        G = (G > 0 && G < D) ? G : D;
+        int g = logical / (O * G);
+        const int ng = (D + G - 1) / G;
         if (g > ng - 1) g = ng - 1;
-        const int rem = logical - g * tiles_m * G;
-        const int gsz = g == ng - 1 ? tiles_n - g * G : G;
-        m0_ = (rem / gsz) * BM;
-        n0_ = (g * G + rem % gsz) * BN;
+        const int rem = logical - g * O * G;
+        const int gsz = g == ng - 1 ? D - g * G : G;
+        const int oth = rem / gsz, din = g * G + rem % gsz;
+        m0_ = (mp ? din : oth) * BM;
+        n0_ = (mp ? oth : din) * BN;
     };
     int v = blockIdx.x;
     int m0, n0;
@@ -423,6 +431,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
                     fv[it] = *(const u32x4_t*)(sl + row * 128 + (pc << 4));
                 }
                 const int m = mb + 64 * pass + row;
+#ifdef LEAF_DIAG_NOQKVSTORE   // diagnostic only (garbage results): the QKV GEMM computes and stages its tile but never stores it -- with
+                              // LEAF_DIAG_ATTN_L2 an upper bound on what fusing QKV GEMM -> attention could save
+                if constexpr (EPI == EPI_LNFOLD_T) { asm volatile("" ::"v"(fv[it]), "v"(m)); } else
+#endif
                 if (m < p.M)
                     __builtin_nontemporal_store(fv[it], (u32x4_t*)(dst + (size_t)m * p.ldc + nb + ((pc ^ (row & 7)) << 3)));
             }
@@ -505,6 +517,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
     if (!has_next) break;
     // exactly NSTORE stores behind the prefetch: a full tile without the optional pre-activation stash
     counted = (m0 + BM <= p.M) && !(EPI == EPI_ACT_T && p.aux);
+#ifdef LEAF_DIAG_NOQKVSTORE
+    if constexpr (EPI == EPI_LNFOLD_T) counted = false;
+#endif
     first = false;
     v = v_next; m0 = m0_next; n0 = n0_next;
   }
@@ -544,6 +559,11 @@ static int pick_ngroup(const GemmArgs& p) {
     static int forced = -2;
     if (forced == -2) { const char* e = getenv("LEAF_GEMM_NGROUP"); forced = e ? atoi(e) : -1; }
     const int tiles_n = p.N / BN, tiles_m = (p.M + BM - 1) / BM;
+    // LEAF_GEMM_MPANEL = P: M-super-panel order with P M tiles per group for every launch with more than one N tile and more
+    // than P M tiles (returned as -P); 0 / unset = the N-group order below
+    static int mpanel = -2;
+    if (mpanel == -2) { const char* e = getenv("LEAF_GEMM_MPANEL"); mpanel = e ? atoi(e) : 0; }
+    if (mpanel > 0 && tiles_n > 1 && tiles_m > mpanel) return -mpanel;
     if (forced >= 0) return forced < tiles_n ? forced : 0;
     const double a_bytes = (double)p.M * p.K * 2, b_tile = (double)BN * p.K * 2;
     const double rounds = (double)tiles_m * tiles_n / 256.0;    // rounds of 32 tiles per XCD

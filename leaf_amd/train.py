@@ -193,14 +193,55 @@ def _expand_braces(pattern: str) -> List[str]:
     return out
 
 
+def _scan_tar_captions(path: str) -> Iterator[str]:
+    """The .txt members of an uncompressed ustar archive, read WITHOUT materialising the other members: a 512-byte header at a
+    time, image / json payloads skipped with one seek each (the reference decodes every image and throws it away,
+    data_AT.py:499-503).  Anything this scan does not understand -- compression, GNU long names, pax records, base-256 sizes --
+    raises _NotPlainTar before a single caption has been yielded and the shard goes through ``tarfile`` instead."""
+    with open(path, "rb") as f:
+        first = True
+        while True:
+            hdr = f.read(512)
+            if len(hdr) < 512 or hdr.count(0) == 512:
+                if first and len(hdr) < 512:
+                    raise _NotPlainTar(path)
+                return
+            if first and hdr[257:262] != b"ustar":
+                raise _NotPlainTar(path)
+            typeflag, size_field = hdr[156:157], hdr[124:136]
+            if typeflag not in (b"0", b"\0", b"5") or size_field[0] & 0x80:
+                if first:
+                    raise _NotPlainTar(path)
+                raise tarfile.TarError(f"unsupported member type {typeflag!r} in the middle of a plain shard")
+            first = False
+            size = int(size_field.rstrip(b"\0 ") or b"0", 8)
+            padded = (size + 511) & ~511
+            if typeflag != b"5" and hdr[:100].rstrip(b"\0").endswith(b".txt"):
+                data = f.read(padded)
+                if len(data) < size:
+                    raise tarfile.TarError("unexpected end of data")
+                yield data[:size].decode("utf-8", errors="replace").strip()
+            else:
+                f.seek(padded, 1)
+
+
+class _NotPlainTar(Exception):
+    pass
+
+
 def _iter_tar_captions(paths: List[str]) -> Iterator[str]:
     for path in paths:
         try:
+            try:
+                yield from _scan_tar_captions(path)
+                continue
+            except _NotPlainTar:
+                pass
             with tarfile.open(path) as tf:
                 for member in tf:
                     if member.isfile() and member.name.endswith(".txt"):
                         yield tf.extractfile(member).read().decode("utf-8", errors="replace").strip()
-        except (tarfile.TarError, OSError) as e:   # data_AT.py:285-288 log_and_continue
+        except (tarfile.TarError, OSError, ValueError) as e:   # data_AT.py:285-288 log_and_continue
             logging.warning(f"skipping shard {path}: {e}")
 
 
@@ -209,12 +250,13 @@ class TextLoader:
     discarded at utils_AT.py:290).  Sharded across ranks by stride; reshuffled per epoch with seed + epoch."""
 
     def __init__(self, captions: Optional[List[str]], shards: Optional[List[str]], batch_size, num_samples, rank, world,
-                 seed):
+                 seed, prefetch: int = 4):
         self.captions, self.shards = captions, shards
         self.batch_size, self.rank, self.world, self.seed = batch_size, rank, world, seed
         self.epoch = 0
         self.num_samples = num_samples
         self.num_batches = max(1, math.ceil(num_samples / (batch_size * world)))
+        self.prefetch = prefetch          # batches read ahead by the background reader (0: synchronous)
 
     def set_epoch(self, epoch):
         self.epoch = epoch
@@ -246,10 +288,57 @@ class TextLoader:
                     raise RuntimeError(f"rank {self.rank}: no caption (.txt member) found in a full pass over {len(mine)} shard(s), "
                                        f"first: {mine[0] if mine else '<none>'} -- check --train-data")
 
-    def __iter__(self):
+    def _batches(self):
         it = self._stream()
         for _ in range(self.num_batches):
             yield None, [next(it) for _ in range(self.batch_size)]
+
+    def __iter__(self):
+        """The epoch's batches, read AHEAD of the training step by one background thread through a bounded queue (the
+        reference overlaps loading with worker processes: data_AT.py:455-503, --workers).  The training thread spends its time
+        inside ctypes calls and device waits, which release the interpreter lock, so one thread keeps up (tools/loader_bench.py:
+        captions/s out of image-sized shards).  ``prefetch = 0`` reads synchronously.  The consumer may stop early: the
+        finally block stops and joins the reader."""
+        if self.prefetch <= 0:
+            yield from self._batches()
+            return
+        import queue
+        import threading
+        q = queue.Queue(maxsize=self.prefetch)
+        stop = threading.Event()
+        END = object()
+
+        def put(item):
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.05)
+                    return True
+                except queue.Full:
+                    pass
+            return False
+
+        def reader():
+            try:
+                for b in self._batches():
+                    if not put(b):
+                        return
+                put(END)
+            except BaseException as e:     # surfaces in the training thread (an empty pass must not hang the other ranks)
+                put(e)
+
+        t = threading.Thread(target=reader, name="leaf-text-loader", daemon=True)
+        t.start()
+        try:
+            while True:
+                item = q.get()
+                if item is END:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                yield item
+        finally:
+            stop.set()
+            t.join(timeout=10)
 
     def __len__(self):
         return self.num_batches
@@ -289,7 +378,9 @@ def get_text_data(args, epoch=0):
     n = args.train_num_samples or (len(captions) if captions is not None else None)
     if n is None:
         raise ValueError("--train-num-samples is required for webdataset shards (data_AT.py:455-465)")
-    loader = TextLoader(captions, shards, args.batch_size, n, rank, world, args.seed)
+    # --workers 0 is the reference's "load in the training process" (data_AT.py:487-494): no read-ahead thread then
+    loader = TextLoader(captions, shards, args.batch_size, n, rank, world, args.seed,
+                        prefetch=4 if getattr(args, "workers", 1) > 0 else 0)
     loader.set_epoch(epoch)
     return {"train": DataInfo(loader)}
 
@@ -312,7 +403,17 @@ def train_one_epoch_text_only(model, model_frozen, tokenizer, V, data, loss, epo
     batch_time_m, data_time_m = AverageMeter(), AverageMeter()
     log_data = {}
     end = time.time()
-    for i, batch in enumerate(dataloader):
+    load_time_m = AverageMeter()       # time this loop WAITED for the loader's next batch (the reference's "Data (t)" also
+    batches = iter(dataloader)         # spans the attack and the forward, utils_AT.py:324, and is kept as it is)
+    i = -1
+    while True:
+        t_load = time.time()
+        try:
+            batch = next(batches)
+        except StopIteration:
+            break
+        load_time_m.update(time.time() - t_load)
+        i += 1
         i_accum = i // args.accum_freq
         step = num_batches_per_epoch * epoch + i_accum
         if not args.skip_scheduler:
@@ -324,6 +425,11 @@ def train_one_epoch_text_only(model, model_frozen, tokenizer, V, data, loss, epo
         # the search's first scoring launch waits for its event (as leaf_amd/step.py does for the token-id step)
         from .step import _side_stream
         cur_stream, side = torch.cuda.current_stream(device), _side_stream(device)
+        if i == 0:
+            # once per epoch: whatever the caller queued on this stream before the loop (copy_from / pack of the frozen model's
+            # 16-bit weights, a checkpoint load) is finished before the side stream first reads it; later steps need no such
+            # ordering (the frozen weights never change), which is what lets the anchor overlap the previous step's tail
+            side.wait_stream(cur_stream)
         with torch.cuda.stream(side):
             anchor = model_frozen.encode_text(tokenizer.encode_batch(texts), normalize=normalize_fare)
             anchor_ready = torch.cuda.Event()
@@ -361,20 +467,20 @@ def train_one_epoch_text_only(model, model_frozen, tokenizer, V, data, loss, epo
                 losses_m.setdefault(key, AverageMeter()).update(float(val), batch_size)
             gs = unwrap_model(model).grad_scaler_state()      # float(val) above already synchronised
             skipped = gs["skipped"]
-            if skipped != getattr(train_one_epoch_text_only, "_skipped_seen", 0):
+            if skipped != getattr(model, "_skipped_seen", 0):      # per model, not per process
                 logging.warning(f"non-finite gradient norm: {skipped} optimizer step(s) skipped so far ({gs['skipped_saturated']} of them "
                                 f"because a 16-bit gradient tensor saturated at the current loss scale); weights and AdamW moments "
                                 f"left untouched for those steps and the loss scale halved, as torch.cuda.amp.GradScaler does "
                                 f"(persistent loss-scale factor now {gs['loss_scale_factor']:g})")
-                train_one_epoch_text_only._skipped_seen = skipped
+                model._skipped_seen = skipped
             loss_log = " ".join(f"{n.capitalize()}: {m.val:#.5g} ({m.avg:#.5g})" for n, m in losses_m.items())
             sps = args.accum_freq * args.batch_size * args.world_size / batch_time_m.val
             sps_gpu = args.accum_freq * args.batch_size / batch_time_m.val
             logging.info(
                 f"Train Epoch: {epoch} [{num_samples:>{sample_digits}}/{dataloader.num_samples} ({percent_complete:.0f}%)] "
                 f"Data (t): {data_time_m.avg:.3f} Batch (t): {batch_time_m.avg:.3f}, {sps:#g}/s, {sps_gpu:#g}/s/gpu "
-                f"LR: {optimizer.param_groups[0]['lr']:5f} " + loss_log)
-            log_data = {"data_time": data_time_m.val, "batch_time": batch_time_m.val, "samples_per_second": sps,
+                f"LR: {optimizer.param_groups[0]['lr']:5f} " + loss_log + f" Load (t): {load_time_m.avg:.4f}")
+            log_data = {"data_time": data_time_m.val, "batch_time": batch_time_m.val, "load_time": load_time_m.avg, "samples_per_second": sps,
                         "samples_per_second_per_gpu": sps_gpu, "lr": optimizer.param_groups[0]["lr"]}
             log_data.update({name: val.val for name, val in losses_m.items()})
             log_data = {"train/" + name: val for name, val in log_data.items()}
@@ -383,6 +489,7 @@ def train_one_epoch_text_only(model, model_frozen, tokenizer, V, data, loss, epo
                     tb_writer.add_scalar(name, val, step)
             batch_time_m.reset()
             data_time_m.reset()
+            load_time_m.reset()
         if (i + 1) % args.accum_freq == 0:
             losses_accum = {}
     if is_master(args):  # the reference rewrites this file every step (utils_AT.py:311); same content at epoch end

@@ -106,3 +106,62 @@ def test_lr_schedules_match_the_reference_known_answers(golden_dir):
         T.make_scheduler(args(lr_scheduler="linear"), Opt(), 200, nb)
     with pytest.raises(AssertionError, match="cooldown epochs"):
         T.make_scheduler(args(lr_scheduler="const-cooldown"), Opt(), 200, nb)
+
+
+def _write_shard(path, n, fmt=tarfile.USTAR_FORMAT, mode="w", long_names=False, img_bytes=3000):
+    with tarfile.open(path, mode, format=fmt) as tf:
+        for i in range(n):
+            key = ("very_long_directory_name_" * 6 + f"/s{i:03d}") if long_names else f"s{i:03d}"
+            for ext, payload in ((".jpg", os.urandom(img_bytes)), (".txt", f"  caption {i} of {os.path.basename(str(path))} \n".encode()),
+                                 (".json", b"{}")):
+                ti = tarfile.TarInfo(key + ext)
+                ti.size = len(payload)
+                tf.addfile(ti, io.BytesIO(payload))
+
+
+def test_header_scan_reader_equals_tarfile_and_falls_back(tmp_path):
+    """The .txt-only header scan returns what tarfile returns; archives it does not understand (gzip, pax /
+    GNU long names) take the tarfile path; truncated and missing shards are skipped with a warning (data_AT.py:285-288)."""
+    plain, gz, pax, gnu = (tmp_path / n for n in ("a.tar", "b.tar.gz", "c.tar", "d.tar"))
+    _write_shard(plain, 7)
+    _write_shard(gz, 3, mode="w:gz")
+    _write_shard(pax, 3, fmt=tarfile.PAX_FORMAT, long_names=True)
+    _write_shard(gnu, 3, fmt=tarfile.GNU_FORMAT, long_names=True)
+    assert list(T._scan_tar_captions(str(plain))) == [f"caption {i} of a.tar" for i in range(7)]
+    for p in (gz, pax, gnu):
+        with pytest.raises(T._NotPlainTar):
+            list(T._scan_tar_captions(str(p)))
+    want = [f"caption {i} of {p.name}" for p, n in ((plain, 7), (gz, 3), (pax, 3), (gnu, 3)) for i in range(n)]
+    assert list(T._iter_tar_captions([str(plain), str(gz), str(pax), str(gnu)])) == want
+    cut = tmp_path / "cut.tar"
+    cut.write_bytes(plain.read_bytes()[:5 * 512 + 100])      # ends inside the second sample
+    got = list(T._iter_tar_captions([str(cut), str(tmp_path / "missing.tar"), str(plain)]))
+    assert got[-7:] == want[:7] and len(got) <= 9
+
+
+def test_prefetching_loader_yields_the_synchronous_batches(tmp_path):
+    """one background reader + bounded queue; same batches in the same order as the synchronous loader, an early
+    break stops the reader thread, and a reader-side error surfaces in the consumer instead of hanging it."""
+    import threading
+    shards = []
+    for s in range(3):
+        p = tmp_path / f"{s:08d}.tar"
+        _write_shard(p, 11)
+        shards.append(str(p))
+    sync = T.TextLoader(None, shards, 4, 40, 0, 1, seed=3, prefetch=0)
+    pre = T.TextLoader(None, shards, 4, 40, 0, 1, seed=3, prefetch=2)
+    a, b = list(sync), list(pre)
+    assert a == b and len(a) == 10 and all(len(t) == 4 for _, t in a)
+    pre.set_epoch(1); sync.set_epoch(1)
+    assert list(pre) == list(sync) and list(pre) != a          # reshuffled per epoch (seed + epoch), still identical
+    before = threading.active_count()
+    it = iter(pre)
+    next(it)
+    it.close()                                                  # consumer leaves early: the finally block joins the reader
+    assert threading.active_count() == before
+    empty = T.TextLoader(None, [str(tmp_path / "nothing.tar")], 4, 8, 0, 1, seed=0, prefetch=2)
+    with pytest.raises(RuntimeError, match="no caption"):
+        list(empty)
+    args = P.parse_args(["--train-data", shards[0], "--dataset-type", "webdataset", "--train-num-samples", "8", "--batch-size", "4", "--workers", "0"])
+    args.rank, args.world_size = 0, 1
+    assert T.get_text_data(args)["train"].dataloader.prefetch == 0

@@ -2,8 +2,9 @@
 # What the data-parallel machinery costs with ONE rank through RCCL on one GPU (no transfer happens): bench.py without a process
 # group, with the flat all-reduce (LEAF_DP_OVERLAP=0) and with the per-bucket collectives behind the backward, then a kernel trace
 # of the last form.  usage (on the GPU box): bash tools/dp_probe.sh   -> gpurun_out/dp_*.json, gpurun_out/dp_prof/
-cd /tmp && export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
+set -e
+export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:?}" && mkdir -p gpurun_out
 for mode in nodist flat overlap; do
   case $mode in
     nodist) export LEAF_BENCH_FORCE_DIST=0; unset LEAF_DP_OVERLAP;;

@@ -16,7 +16,7 @@ def main():
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     d = int(os.environ.get("WIDTH", "768"))
     shapes = [("qkv", 0, 3 * d, d), ("out", 2, d, d), ("fc", 1, 4 * d, d), ("proj", 2, d, 4 * d), ("dgrad_fc", 3, d, 4 * d), ("dgrad_qkv", 3, d, 3 * d)]
-    for M in (800, 1600, 3219, 4800, 6400, 9600, 12800):
+    for M in [int(x) for x in os.environ.get("MS", "800,1600,3219,4800,6400,9600,12800").split(",")]:
         for name, epi, N, K in shapes:
             A = (torch.randn(M, K, device=dev) * 0.5).half()
             B = (torch.randn(N, K, device=dev) * 0.05).half()

@@ -70,12 +70,22 @@ def main(argv):
     log_base = os.path.join(args.logs, args.name)
     args.checkpoint_path = os.path.join(log_base, "checkpoints")
     handlers = [logging.StreamHandler()]
+    exists = [False]
     if is_master(args):
         os.makedirs(args.checkpoint_path, exist_ok=True)
         log_path = os.path.join(log_base, "out.log")
-        if os.path.exists(log_path) and args.resume != "latest":
+        exists[0] = os.path.exists(log_path) and args.resume != "latest"
+    if args.distributed:
+        # the master alone looks at the folder (train_AT_text_only.py:133-137), but EVERY rank has to leave: one that walked on
+        # would wait in the next collective for ever
+        torch.distributed.broadcast_object_list(exists, src=0)
+    if exists[0]:
+        if is_master(args):
             print("Error. Experiment already exists. Use --name {} to specify a new experiment.")
-            return -1
+        if args.distributed:
+            torch.distributed.destroy_process_group()
+        return -1
+    if is_master(args):
         handlers.append(logging.FileHandler(log_path))
     logging.basicConfig(level=logging.INFO, format="%(asctime)s | %(levelname)s | %(message)s", handlers=handlers)
     out_dir = f'./results/{args.custom_out_folder}text_only_k{args.k_adv}_rho{args.rho}_seed{args.seed}'
