@@ -38,7 +38,8 @@ sys.path.insert(0, ROOT)
 PEAK_TFLOPS_16BIT = 2500.0  # MI355X dense bf16/fp16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_HBM_GBS = 8000.0       # HBM3E spec peak (same table; ~6.3 TB/s achievable)
 TRAFFIC_FILE = "r03_traffic.json"   # PMC summary of the dominant kernel (tools/pmc_passes.sh, tools/pmc_summary.py)
-FAMILY = {0: "gemm_nt_kernel", 1: "gemm_nt256_kernel", 4: "gemm_nt256_half_kernel", 6: "gemm_nt64_ring_kernel", 7: "gemm_nt128pp_kernel"}
+FAMILY = {0: "gemm_nt_kernel", 1: "gemm_nt256_kernel", 4: "gemm_nt256_half_kernel", 6: "gemm_nt64_ring_kernel", 7: "gemm_nt128pp_kernel",
+          8: "qkv_attn_kernel"}
 EPI_NAMES = {0: "store16", 1: "act16", 2: "resid32", 3: "store32", 4: "actgrad16", 5: "lnfold16", 6: "lnfold_act16", 7: "resid32+x16+stats"}
 
 
@@ -179,7 +180,19 @@ def main():
     ap.add_argument("--pgd-eps", type=float, default=0.05)
     ap.add_argument("--pgd-alpha", type=float, default=0.02)
     ap.add_argument("--pgd-norm", default="linf", choices=["linf", "l2"])
+    ap.add_argument("--config", type=int, default=0, choices=[0, 1, 2, 3, 4],
+                    help="BASELINE.json configs[i] verbatim (model, k, per-GPU batch, accum): 1 = ViT-L k=1 B=128 (the default), "
+                         "2 = ViT-L k=5 B=128, 3 = ViT-H k=2 B=128 as accum 4 x 32, 4 = ViT-bigG k=1 B=256; explicit flags still win")
     args = ap.parse_args()
+    if args.config:
+        preset = {1: dict(model="ViT-L-14-quickgelu", k_adv=1, batch=128, accum_freq=1),
+                  2: dict(model="ViT-L-14-quickgelu", k_adv=5, batch=128, accum_freq=1),
+                  3: dict(model="ViT-H-14", k_adv=2, batch=32, accum_freq=4),
+                  4: dict(model="ViT-bigG-14", k_adv=1, batch=256, accum_freq=1)}[args.config]
+        given = {a.split("=")[0] for a in sys.argv[1:] if a.startswith("--")}
+        for k, v in preset.items():
+            if "--" + k.replace("_", "-") not in given:
+                setattr(args, k, v)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args, sys.argv[1:]))
@@ -364,7 +377,7 @@ def main():
                                    (f"CLIP {args.model} text encoder, OPTIONAL embedding-space PGD mode (SURVEY 8a row a12, NOT "
                                     f"the reference's text attack): k={args.k_adv} steps, {args.pgd_norm} eps={args.pgd_eps} "
                                     f"alpha={args.pgd_alpha}, B={B} per GPU, seq=77"),
-                       "attack": args.attack, "accum_freq": args.accum_freq,
+                       "attack": args.attack, "accum_freq": args.accum_freq, "baseline_config_index": args.config or None,
                        "global_batch": B * world, "seq_len": cfg.context_length, "rho": args.rho, "k": args.k_adv,
                        "parallelism": f"dp{world}", "candidate_forwards_per_step_per_gpu": 2 * args.rho * args.k_adv * B},
             "roofline": {

@@ -165,8 +165,8 @@ int leaf_adamw_step(float* params, const float* grads, float* exp_avg, float* ex
  * utils_AT.py:79-83,339-362).  The fp16 gradient path multiplies the loss gradient by a power of two S chosen on the device
  * each step (max|d loss / d feat| * S in [8, 16)) and its 16-bit conversions SATURATE at +-65504 instead of producing inf, so
  * an overflow would clip silently.  With a scaler state attached (leaf_text_set_grad_scaler) the backward checks every 16-bit
- * gradient tensor of every block for saturated / non-finite values; a hit poisons gradient element 0 with NaN (the padding row
- * of the token-embedding table: untouched otherwise), so the guarded optimizer step below -- after the data-parallel all-reduce,
+ * gradient tensor of every block for saturated / non-finite values; a hit poisons gradient element 0 with NaN (the first element
+ * of the token-embedding gradient: every later writer only adds to it, and it is reduced with the last data-parallel bucket), so the guarded optimizer step below -- after the data-parallel all-reduce,
  * hence on every rank alike -- skips the step, and halves S for the following steps (state[LEAF_SC_BACKOFF] -= 1); after
  * state[LEAF_SC_INTERVAL] (default 2000, GradScaler's growth_interval) applied steps in a row the back-off is taken back by
  * one halving.  The state is the head of the clip_ws buffer of leaf_adamw_step_clip: device fp32 [LEAF_SC_WORDS + 2048],
@@ -296,6 +296,20 @@ int leaf_op_gemm_resid_ln(int dtype, const void* A, const void* B, float* C, con
 int leaf_op_ln_finalize(const void* stat, int ld, int rows, int ngroups, float eps, void* rowstat, leaf_stream_t s);
 int leaf_op_gemm_lnfold(int dtype, int act, const void* A, const void* Bp, void* C16, const float* c_vec, const float* s_vec,
                         const void* rowstat, int M, int N, int K, leaf_stream_t s);
+/* LN-folded QKV projection + causal attention in ONE launch (leaf_amd/csrc/qkv_attn.hip; nn.MultiheadAttention's in_proj ->
+ * softmax(q k^T / 8 + causal mask) v, src/open_clip/transformer.py:225,239-252): out[rows, width] (eot_pos: [n_seq, width]) from the
+ * 16-bit residual copy x16 [rows, width], Wp = 16-bit(gamma * in_proj_weight) [3 width, width] with its c / s vectors and the rows'
+ * (mean, rstd).  lens (HOST) = rows per sequence, cu (device) their exclusive prefix sum; prefix / base_cu / kv (device, or all
+ * NULL) = cached-prefix mode as in leaf_score_candidates_prefix with candidates grouped `group` per caption; tile_seq = device
+ * scratch [n_seq + 1].  Kernel hook for tools/qkv_attn_bench.py; the scoring passes call the same launch internally. */
+int leaf_op_qkv_attn(int dtype, const void* x16, const void* Wp, const float* c_vec, const float* s_vec, const void* rowstat,
+                     void* out, const void* kv, const int32_t* lens, const int32_t* cu, const int32_t* prefix,
+                     const int32_t* base_cu, const int32_t* eot_pos, int32_t* tile_seq, int n_seq, int rows, int group,
+                     int ctx, int heads, int width, leaf_stream_t s);
+/* host-side cut of a pass's sequences into the M tiles of the fused QKV + attention launch (leaf_amd/csrc/qkv_attn.hip): whole
+ * sequences, <= 256 rows, prefixed sequences of <= 3 consecutive captions; out [n + 1] receives the first sequence of every
+ * tile and n behind the last, returns the number of tiles (test hook, tests/test_host_cpu.py) */
+int leaf_debug_qkv_attn_plan(const int32_t* lens, int ctx, int s0, int n, int prefixed, int group, int group_off, int32_t* out);
 int leaf_debug_gemm_stamps(void* buf);
 /* dispatch tuning (tools/small_gemm_sweep.py): fewest 256 x 256 tiles for which the half-stage ring kernel takes a launch */
 int leaf_debug_gemm_min_tiles(int n);

@@ -107,6 +107,8 @@ _SIGS = {
     "leaf_op_ln_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "leaf_op_gemm_lnfold": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "leaf_op_qkv_attn": (C.c_int, [C.c_int] + [C.c_void_p] * 13 + [C.c_int] * 6 + [C.c_void_p]),
+    "leaf_debug_qkv_attn_plan": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "leaf_debug_gemm_stamps": (C.c_int, [C.c_void_p]),
     "leaf_debug_gemm_min_tiles": (C.c_int, [C.c_int]),
     "leaf_op_attention_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -11,6 +11,7 @@ over the WHOLE CLIP, image tower included, because the reference freezes ``model
 """
 from __future__ import annotations
 
+import re
 import os
 from typing import Dict
 
@@ -106,6 +107,27 @@ _BUFFER_SUFFIXES = ("running_mean", "running_var", "num_batches_tracked", "attn_
 def _exclude(name: str, ndim: int) -> bool:
     """The reference's ``exclude`` lambda (train_AT_text_only.py:326): no weight decay for gains, biases, logit_scale."""
     return ndim < 2 or "bn" in name or "ln" in name or "bias" in name or "logit_scale" in name
+
+
+# Parameter names of the image towers of open_clip's CLIP class whose parameter / buffer split is known here: VisionTransformer
+# (src/open_clip/transformer.py:468-537 + the residual blocks :224-237) and ModifiedResNet (src/open_clip/modified_resnet.py:
+# 17-36,61-65,109-128).  A key outside these patterns may be a buffer of another tower (a timm trunk's relative_position_index,
+# ...) that named_parameters() would not list: the ids of a full-CLIP optimizer layout built from it would be shifted.
+_KNOWN_VISUAL = re.compile(
+    r"^(logit_bias|visual\.(class_embedding|positional_embedding|proj|conv1\.weight|ln_(pre|post)\.(weight|bias)"
+    r"|transformer\.resblocks\.\d+\.(ln_[12]\.(weight|bias)|ls_[12]\.gamma|attn\.(in_proj_(weight|bias)|out_proj\.(weight|bias))"
+    r"|mlp\.(c_fc|c_proj)\.(weight|bias))"
+    r"|attn_pool(_contrastive)?\.(query|ln_[qk]\.(weight|bias)|attn\.(in_proj_(weight|bias)|[qkv]_proj_weight|out_proj\.(weight|bias)))"
+    r"|(conv[123]\.weight|bn[123]\.(weight|bias))"
+    r"|layer[1-4]\.\d+\.(conv[123]\.weight|bn[123]\.(weight|bias)|downsample\.(0\.weight|1\.(weight|bias)))"
+    r"|attnpool\.(positional_embedding|[kqvc]_proj\.(weight|bias)))"
+    r"|.*\.(running_mean|running_var|num_batches_tracked)|.*attn_mask)$")
+
+
+def image_tower_is_known(extra) -> bool:
+    """True when every carried-through non-text tensor is a parameter or buffer of an image tower whose named_parameters()
+    order can be reproduced from the checkpoint keys alone; {} / None (no image tower) counts as known."""
+    return all(_KNOWN_VISUAL.match(k) for k in (extra or {}))
 
 
 def non_text_parameters(extra) -> list:

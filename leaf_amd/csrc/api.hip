@@ -41,6 +41,7 @@ extern "C" int leaf_text_create(const leaf_text_cfg* cfg, int fwd_dtype, leaf_te
     h->streams = 1;   // 2 measured no faster on MI355X: the option stays for A/B runs
     { const char* e = getenv("LEAF_LAST_TRIM"); h->last_trim = (e && e[0] == '0') ? 0 : 1; }
     { const char* e = getenv("LEAF_LN_FOLD"); h->ln_fold = (e && e[0] == '0') ? 0 : 1; }
+    { const char* e = getenv("LEAF_FUSE_ATTN"); h->fuse_attn = (e && e[0] == '0') ? 0 : 1; }
     {   // gradient path: fp16 + per-step power-of-two loss scale unless LEAF_GRAD_DTYPE=bf16
         const char* e = getenv("LEAF_GRAD_DTYPE");
         h->grad_dtype = (e && (e[0] == 'b' || e[0] == 'B')) ? LEAF_DTYPE_BF16 : LEAF_DTYPE_FP16;
@@ -90,6 +91,10 @@ extern "C" void leaf_text_destroy(leaf_text_t h) {
     if (h->side) (void)hipStreamDestroy(h->side);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    for (int i = 0; i < leaf_text::PLAN_RING; ++i) {
+        if (h->plan_ev[i]) { (void)hipEventSynchronize(h->plan_ev[i]); (void)hipEventDestroy(h->plan_ev[i]); }
+        if (h->plan_host[i]) (void)hipHostFree(h->plan_host[i]);
+    }
     delete h;
 }
 
@@ -106,6 +111,7 @@ extern "C" int leaf_text_set_option(leaf_text_t h, const char* name, int value) 
     if (!strcmp(name, "streams")) { h->streams = value >= 2 ? 2 : 1; return 0; }
     if (!strcmp(name, "normalize_fare")) { h->normalize_fare = value ? 1 : 0; return 0; }
     if (!strcmp(name, "ln_fold")) { h->ln_fold = (value && h->cfg.width % 64 == 0) ? 1 : 0; return 0; }
+    if (!strcmp(name, "fuse_attn")) { h->fuse_attn = value ? 1 : 0; return 0; }
     leaf_set_error("unknown option '%s'", name);
     return 1;
 }
@@ -204,6 +210,24 @@ int leaf_gemm(int dtype, int epi, const void* A, int lda, const void* B, int ldb
     return rc;
 }
 
+// the fused QKV + attention launch, accounted like a GEMM launch (family 8, epilogue id of the LN-folded QKV GEMM): FLOPs = the
+// projection's 2 M 3d K (the attention's own products are not counted), bytes = A + weights + attention output
+int leaf_qkv_attn(const QkvAttnArgs& a, int dtype, hipStream_t s) {
+    if (!g_prof_on) return leaf_check(leaf_launch_qkv_attn(a, dtype, s), "qkv_attn");
+    ProfRec r;
+    r.key = 8 * 16 + dtype * 8 + EPI_LNFOLD_T;
+    r.M = a.M; r.N = 3 * a.d; r.K = a.K;
+    r.flops = 2.0 * (double)a.M * (3.0 * a.d) * (double)a.K;
+    r.bytes = 2.0 * ((double)a.M * a.K + 3.0 * a.d * a.K) + 2.0 * (double)(a.eot_pos ? a.n_seq : a.M) * a.d + 8.0 * a.M;
+    LEAF_TRY(hipEventCreate(&r.a));
+    LEAF_TRY(hipEventCreate(&r.b));
+    LEAF_TRY(hipEventRecord(r.a, s));
+    int rc = leaf_check(leaf_launch_qkv_attn(a, dtype, s), "qkv_attn");
+    LEAF_TRY(hipEventRecord(r.b, s));
+    g_prof.push_back(r);
+    return rc;
+}
+
 extern "C" int leaf_prof_begin(void) {
     for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     g_prof.clear();
@@ -266,13 +290,14 @@ struct FwdBuf {
     uint16_t* x16; // [rows,d]   LN folding: 16-bit copy of the residual stream (A operand of the QKV / c_fc GEMMs)
     float2* stat;  // [d/64][rows] LN folding: (sum, M2) per row and 64-column group
     float2* rowstat; // [rows]     LN folding: (mean, rstd) per row
+    int32_t* tile_seq; // [seqs + 1] fused QKV + attention: first sequence of every M tile (a sequence has >= 1 row)
 };
 
 size_t fwd_chunk_bytes(const leaf_text* h, int cs) {
     const size_t rows = (size_t)cs * h->cfg.context_length, d = h->cfg.width;
     Carver c(nullptr, 0);
     c.take(rows * d * 4); c.take(rows * d * 2); c.take(rows * 3 * d * 2); c.take(rows * 4 * d * 2); c.take(rows * 4);
-    c.take(rows * d * 2); c.take(rows * (d / 64) * 8); c.take(rows * 8);
+    c.take(rows * d * 2); c.take(rows * (d / 64) * 8); c.take(rows * 8); c.take((rows + 2) * 4);
     return align_up(c.off, 256);
 }
 
@@ -287,6 +312,7 @@ FwdBuf carve_fwd(const leaf_text* h, Carver& c, int cs) {
     b.x16 = (uint16_t*)c.take(rows * d * 2);
     b.stat = (float2*)c.take(rows * (d / 64) * 8);
     b.rowstat = (float2*)c.take(rows * 8);
+    b.tile_seq = (int32_t*)c.take((rows + 2) * 4);
     return b;
 }
 
@@ -301,6 +327,8 @@ struct KvPlan {
     // candidates' attention reads their K/V from the chunk's own qkv buffer, and every layer's rows are copied to kv_copy
     uint16_t* kv_copy = nullptr;
     size_t kv_self_rows = 0;
+    // fused QKV + attention launches (qkv_attn.hip): number of M tiles cut for this chunk (b.tile_seq holds them); 0 = two kernels
+    int attn_tiles = 0;
 };
 
 int forward_chunk(const leaf_text* h, const float* P, const uint16_t* W, const int32_t* tokens, int cs, int rows,
@@ -351,9 +379,33 @@ int forward_chunk(const leaf_text* h, const float* P, const uint16_t* W, const i
         const bool last = l == c.layers - 1;
         if (l > 0 && !fold) LEAF_TRY(leaf_launch_layernorm(b.x, P + o.ln1_w, P + o.ln1_b, c.ln_eps, b.a, rows, d, dt, s));
         if (kv.kv_write) b.qkv = kv.kv_write + (size_t)l * kv.kv_stride;
-        if (qkv_gemm(l, rows, ln, b.a)) return 1;
         const void* kvl = kv.kv_read ? kv.kv_read + (size_t)l * kv.kv_stride : nullptr;
-        if (kv.kv_self_rows) {
+        // QKV GEMM -> attention in one launch (qkv_attn.hip): q|k|v stay on chip, b.a receives the attention output.  In the fused
+        // first stage the captions' q|k|v rows -- which their candidates' attention reads as cached prefix and the second stage
+        // reads again -- come from a small GEMM of their own straight into the cache (the same bits as from any other kernel).
+        const bool fused_attn = kv.attn_tiles > 0;
+        if (fused_attn) {
+            if (kv.kv_self_rows) {
+                uint16_t* dst = kv.kv_copy + (size_t)l * kv.kv_stride;
+                uint16_t* keep = b.qkv;
+                b.qkv = dst;
+                const int rc = qkv_gemm(l, (int)kv.kv_self_rows, ln, b.a);
+                b.qkv = keep;
+                if (rc) return 1;
+                kvl = dst;
+            }
+            const bool trim = last && h->last_trim && out;
+            if (trim) LEAF_TRY(leaf_launch_eot_positions(tokens, b.eot, cs, map, s));
+            if (last && !out) break;
+            QkvAttnArgs qa;
+            qa.A = ln.x16; qa.B = W + h->w16_fold_qkv(l); qa.bias = h->fold_c_qkv(W, l); qa.ln_s = h->fold_s_qkv(W, l);
+            qa.rowstat = ln.rowstat; qa.out = b.a; qa.kv_base = kvl; qa.eot_pos = trim ? b.eot : nullptr; qa.tile_seq = b.tile_seq;
+            qa.map = map; qa.M = rows; qa.K = d; qa.lda = d; qa.ldb = d; qa.heads = c.heads; qa.d = d; qa.n_tiles = kv.attn_tiles;
+            qa.n_seq = cs; qa.kv_ld = 3 * d; qa.stamps = nullptr;
+            if (leaf_qkv_attn(qa, dt, s)) return 1;
+        } else
+        if (qkv_gemm(l, rows, ln, b.a)) return 1;
+        if (!fused_attn && kv.kv_self_rows) {
             kvl = b.qkv;
 #ifdef LEAF_COPY_MEMCPY   // A/B build: the runtime's copy (three dispatches per 15-MB copy)
             LEAF_TRY(hipMemcpyAsync(kv.kv_copy + (size_t)l * kv.kv_stride, b.qkv, (size_t)kv.kv_self_rows * 3 * d * 2, hipMemcpyDeviceToDevice, s));
@@ -369,8 +421,10 @@ int forward_chunk(const leaf_text* h, const float* P, const uint16_t* W, const i
             // dead; the gathered residual rows xg (fp32 [cs,d]) and the MLP hidden rows hb (16-bit [cs,4d]) need
             // 12*d*cs <= 14*d*rows bytes.  With folding the chunk's x16 / statistics buffers (dead after the QKV GEMM above)
             // take the pooled rows' 16-bit copy and statistics (row stride cs).
-            LEAF_TRY(leaf_launch_eot_positions(tokens, b.eot, cs, map, s));
-            LEAF_TRY(leaf_launch_attention_fwd(b.qkv, kvl, b.a, cs, map, c.heads, d, dt, s, b.eot, max_len));
+            if (!fused_attn) {
+                LEAF_TRY(leaf_launch_eot_positions(tokens, b.eot, cs, map, s));
+                LEAF_TRY(leaf_launch_attention_fwd(b.qkv, kvl, b.a, cs, map, c.heads, d, dt, s, b.eot, max_len));
+            }
             float* xg = (float*)b.qkv;
             uint16_t* hb = (uint16_t*)((char*)b.qkv + align_up((size_t)cs * d * 4, 256));
             LEAF_TRY(leaf_launch_gather_rows(b.x, b.eot, xg, cs, map, d, s));
@@ -389,7 +443,7 @@ int forward_chunk(const leaf_text* h, const float* P, const uint16_t* W, const i
                                               nullptr, cs, map, d, c.embed_dim, normalize, s, /*rows_are_pooled=*/1));
             return 0;
         }
-        LEAF_TRY(leaf_launch_attention_fwd(b.qkv, kvl, b.a, cs, map, c.heads, d, dt, s, nullptr, max_len));
+        if (!fused_attn) LEAF_TRY(leaf_launch_attention_fwd(b.qkv, kvl, b.a, cs, map, c.heads, d, dt, s, nullptr, max_len));
         if (resid_gemm(b.a, d, h->w16_out(l), P + o.out_b, b.x, rows, &ln)) return 1;
         if (!fold) LEAF_TRY(leaf_launch_layernorm(b.x, P + o.ln2_w, P + o.ln2_b, c.ln_eps, b.a, rows, d, dt, s));
         if (fc_gemm(l, rows, ln, b.a, b.hh)) return 1;
@@ -490,6 +544,29 @@ int forward_all(leaf_text* h, const float* P, const void* W, const int32_t* toke
         kv.kv_self_rows = pp.kv_self_rows;
         if (s1 == s0) { leaf_set_error("a sequence does not fit the row budget"); return 1; }
         const int set = nsets == 2 ? (ci & 1) : 0;
+        // fused QKV + attention for the big passes: cut the chunk's sequences into M tiles of whole sequences on the host and send
+        // the cut points behind the work already queued (a pinned ring slot; its event keeps a slot from being rewritten early)
+        if (h->fuse_attn && h->ln_fold && leaf_qkv_attn_eligible(h->cfg.width, h->cfg.heads, ctx, h->cfg.width, max_len) &&
+            rows / 256 * (size_t)h->cfg.heads >= 256) {
+            const size_t need = (size_t)(s1 - s0) + 2;
+            if (h->plan_cap < need) {
+                for (int i = 0; i < leaf_text::PLAN_RING; ++i) {
+                    if (h->plan_ev[i]) LEAF_TRY(hipEventSynchronize(h->plan_ev[i]));
+                    if (h->plan_host[i]) { LEAF_TRY(hipHostFree(h->plan_host[i])); h->plan_host[i] = nullptr; }
+                }
+                h->plan_cap = need * 2;
+            }
+            const int k = h->plan_next;
+            h->plan_next = (k + 1) % leaf_text::PLAN_RING;
+            if (!h->plan_host[k]) LEAF_TRY(hipHostMalloc((void**)&h->plan_host[k], h->plan_cap * sizeof(int32_t), hipHostMallocDefault));
+            if (!h->plan_ev[k]) LEAF_TRY(hipEventCreateWithFlags(&h->plan_ev[k], hipEventDisableTiming));
+            else LEAF_TRY(hipEventSynchronize(h->plan_ev[k]));
+            kv.attn_tiles = leaf_qkv_attn_plan(lens ? lens + s0 : nullptr, ctx, s0, s1 - s0, pp.prefix_dev != nullptr, pp.group, pp.group_off,
+                                               h->plan_host[k]);
+            hipStream_t cs_ = set ? h->side : s;
+            LEAF_TRY(hipMemcpyAsync(bufs[set].tile_seq, h->plan_host[k], (size_t)(kv.attn_tiles + 1) * sizeof(int32_t), hipMemcpyHostToDevice, cs_));
+            LEAF_TRY(hipEventRecord(h->plan_ev[k], cs_));
+        }
         if (forward_chunk(h, P, (const uint16_t*)W, tokens, s1 - s0, (int)rows, map, out + (size_t)s0 * h->cfg.embed_dim,
                           normalize, bufs[set], set ? h->side : s, kv, max_len))
             return 1;
@@ -667,6 +744,28 @@ extern "C" int leaf_op_gemm_lnfold(int dtype, int act, const void* A, const void
     ln.ln_s = s_vec; ln.rowstat = (const float2*)rowstat;
     return leaf_gemm(dtype, act < 0 ? EPI_LNFOLD_T : EPI_LNFOLD_ACT_T, A, K, Bp, K, C16, N, c_vec, nullptr, M, N, K, act < 0 ? 0 : act,
                      (hipStream_t)s, 0.f, 0, nullptr, &ln);
+}
+// The fused QKV + attention launch alone (tools/qkv_attn_bench.py): lens (host) = rows per sequence, cu / prefix / base_cu device
+// arrays as in leaf_score_candidates_prefix (prefix / base_cu / kv may be null: no cached prefix), tile_seq = device scratch
+// [n_seq + 1].  Synchronous plan upload: a measuring / test hook, not a step of the pipeline.
+extern "C" int leaf_op_qkv_attn(int dtype, const void* x16, const void* Wp, const float* c_vec, const float* s_vec, const void* rowstat,
+                                void* out, const void* kv, const int32_t* lens, const int32_t* cu, const int32_t* prefix,
+                                const int32_t* base_cu, const int32_t* eot_pos, int32_t* tile_seq, int n_seq, int rows, int group,
+                                int ctx, int heads, int width, leaf_stream_t s) {
+    if (!leaf_qkv_attn_eligible(width, heads, ctx, width, 0)) { leaf_set_error("qkv_attn: unsupported shape"); return 1; }
+    std::vector<int32_t> plan((size_t)n_seq + 2);
+    QkvAttnArgs qa;
+    qa.n_tiles = leaf_qkv_attn_plan(lens, ctx, 0, n_seq, prefix != nullptr, group, 0, plan.data());
+    LEAF_TRY(hipMemcpy(tile_seq, plan.data(), (size_t)(qa.n_tiles + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+    qa.A = x16; qa.B = Wp; qa.bias = c_vec; qa.ln_s = s_vec; qa.rowstat = (const float2*)rowstat; qa.out = out; qa.kv_base = kv;
+    qa.eot_pos = eot_pos; qa.tile_seq = tile_seq;
+    qa.map = RowMap{cu, 0, 0, ctx, prefix, base_cu, group > 0 ? group : 1, 0};
+    qa.M = rows; qa.K = width; qa.lda = width; qa.ldb = width; qa.heads = heads; qa.d = width; qa.n_seq = n_seq; qa.kv_ld = 3 * width;
+    qa.stamps = nullptr;
+    return leaf_check(leaf_launch_qkv_attn(qa, dtype, (hipStream_t)s), "qkv_attn");
+}
+extern "C" int leaf_debug_qkv_attn_plan(const int32_t* lens, int ctx, int s0, int n, int prefixed, int group, int group_off, int32_t* out) {
+    return leaf_qkv_attn_plan(lens, ctx, s0, n, prefixed, group, group_off, out);
 }
 extern "C" int leaf_debug_gemm_stamps(void* buf) { leaf_gemm_set_stamps(buf); return 0; }
 extern "C" int leaf_debug_gemm_min_tiles(int n) { leaf_gemm256h_set_min_tiles(n); return 0; }

@@ -246,7 +246,11 @@ static int backward_impl(leaf_text_t h, const float* P, const void* w16_bwd, con
             // the five 16-bit gradient tensors of this block, before ln1's backward overwrites dx16
             const void* bufs[5] = {b.dx16, b.big16, b.dx16b, b.do16, b.dqkv};
             const size_t numel[5] = {rd, 4 * rd, rd, rd, 3 * rd};
-            LEAF_TRY(leaf_launch_sat_check16(bufs, numel, 5, h->scaler, G, s));
+            // poison target: the first element of the token-embedding gradient.  Everything that still touches it after this
+            // launch only ADDS to it (the embedding scatter's atomics: NaN stays NaN), and it travels in the LAST bucket of the
+            // data-parallel reduction (step.bucket_plan: offset 0, behind the last block's event), so no rank can ship a clean
+            // element 0 before another rank's poison exists (tests/test_dp_gloo.py pins both facts)
+            LEAF_TRY(leaf_launch_sat_check16(bufs, numel, 5, h->scaler, G + h->tok_emb, s));
         }
         if (leaf_gemm(gk, EPI_STORE_F32, b.dqkv, 3 * d, WT + h->w16_qkv(l), 3 * d, b.dxn, d, nullptr, nullptr, rows, d,
                  3 * d, 0, s)) return 1;
@@ -278,6 +282,7 @@ static int backward_impl(leaf_text_t h, const float* P, const void* w16_bwd, con
 
 extern "C" int leaf_text_set_grad_scaler(leaf_text_t h, float* state) {
     if (!h) { leaf_set_error("null handle"); return 1; }
+    if (state && h->tok_emb != 0) { leaf_set_error("gradient scaler: the poison element must be offset 0 of the flat buffer"); return 1; }
     h->scaler = state;
     return 0;
 }

@@ -30,6 +30,15 @@ struct leaf_text {
     // residual epilogues) and grid tails overlap the other chunk's MFMA-bound K loops.  Measured: kernels of the two
     // streams do run concurrently, but the search pass is no faster (57.4 vs 56.0 ms), so the default is streams = 1.
     int streams;
+    // QKV GEMM -> attention as one launch in the big forward-only passes (qkv_attn.hip); option 'fuse_attn' / LEAF_FUSE_ATTN=0
+    // restores the two kernels around the [rows, 3d] buffer.  The M-tile plan of a pass (first sequence of every tile) is cut on
+    // the host and travels through a small ring of pinned buffers (an event per slot guards its re-use).
+    int fuse_attn = 1;
+    static constexpr int PLAN_RING = 8;
+    int32_t* plan_host[PLAN_RING] = {};
+    hipEvent_t plan_ev[PLAN_RING] = {};
+    size_t plan_cap = 0;      // ints per slot
+    int plan_next = 0;
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<TensorInfo> tensors;
@@ -74,6 +83,7 @@ struct GemmLn {
 int leaf_gemm(int dtype, int epi, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias,
               void* aux, int M, int N, int K, int act, hipStream_t s, float beta = 0.f, int aux_f16 = 0,
               const float* alpha = nullptr, const GemmLn* ln = nullptr);
+int leaf_qkv_attn(const QkvAttnArgs& a, int dtype, hipStream_t s);   // leaf_launch_qkv_attn + profiler accounting
 void leaf_set_error(const char* fmt, ...);
 int leaf_check(hipError_t e, const char* what);
 

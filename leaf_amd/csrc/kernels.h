@@ -63,6 +63,27 @@ hipError_t leaf_launch_gemm128pp(const GemmArgs& p, int dtype, int epi, hipStrea
 bool leaf_gemm64_eligible(const GemmArgs& p);
 hipError_t leaf_launch_gemm64(const GemmArgs& p, int dtype, int epi, hipStream_t s);
 
+// ---- QKV projection + causal attention in one launch (qkv_attn.hip): the scoring passes' q|k|v rows never reach HBM
+#define LEAF_QKVATTN_NCAP 3        // clean captions whose cached prefix K/V one M tile may need (LDS images)
+#define LEAF_QKVATTN_CAPROWS 80    // rows per caption image = longest sequence the fused kernel takes (CLIP: 77)
+struct QkvAttnArgs {
+    const void* A;            // [M, K] 16-bit copy of the residual stream (row stride lda)
+    const void* B;            // [3 d, K] gamma-scaled in_proj weights, standard [q; k; v] row order (row stride ldb)
+    const float* bias;        // [3 d] c = W . ln_beta + in_proj_bias
+    const float* ln_s;        // [3 d] row sums of B
+    const float2* rowstat;    // [M] (mean, rstd) of the A rows
+    void* out;                // attention output [M, d] 16-bit (eot_pos: [n_seq, d], one row per sequence)
+    const void* kv_base;      // this layer's cached q|k|v rows of the clean captions (row stride kv_ld), or null
+    const int32_t* eot_pos;   // last-layer mode: pooled position per sequence of the launch, or null
+    const int32_t* tile_seq;  // [n_tiles + 1] first sequence (launch-relative) of every M tile (leaf_qkv_attn_plan)
+    RowMap map;
+    int M, K, lda, ldb, heads, d, n_tiles, n_seq, kv_ld;
+    void* stamps;             // diagnostic builds only (-DLEAF_GEMM_STAMPS)
+};
+int leaf_qkv_attn_plan(const int32_t* lens, int ctx, int s0, int n, int prefixed, int group, int group_off, int32_t* out);
+bool leaf_qkv_attn_eligible(int d, int heads, int ctx, int K, int max_len);
+hipError_t leaf_launch_qkv_attn(const QkvAttnArgs& a, int dtype, hipStream_t s);
+
 // ---- forward elementwise / reduction kernels (elementwise.hip)
 // x[r,:] = tok_emb[tokens[r],:] + pos_emb[r % ctx,:]   and   xn = LN(x) (16-bit)
 hipError_t leaf_launch_embed_ln(const int32_t* tokens, const float* tok_emb, const float* pos_emb, const float* g,

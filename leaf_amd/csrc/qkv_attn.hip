@@ -1,0 +1,438 @@
+// QKV projection -> causal attention in ONE launch: the q|k|v rows of the scoring passes never reach HBM.
+//
+// Reference op: nn.MultiheadAttention = in_proj -> per-head softmax(q k^T / sqrt(64) + causal mask) v (-> out_proj, a separate
+// GEMM here), src/open_clip/transformer.py:225,239-252, with the LayerNorm in front of it folded into the in_proj GEMM (lnfold.h).
+//
+// Round 3 ran this as two kernels around a [rows, 3d] 16-bit buffer: the LN-folded QKV GEMM wrote 6d bytes per row (541 MB per
+// launch of a ViT-L scoring stage) that attn_fwd_kernel read straight back.  A diagnostic build that never stores that buffer
+// and lets the attention read an L2-resident window bounded the round trip at 3.5-4.0 of 41.4 ms per step
+// (profiles/r04_run1_tileorder_fusebound.txt).  Here a workgroup computes, for ONE head h and a 256-row M tile made of WHOLE
+// sequences (packed rows, RowMap), the tile's [q_h | k_h | v_h] = 192 columns with the half-stage LDS-DMA ring of gemm256h.hip
+// (same K order, same MFMA, same LN-fold epilogue arithmetic: a row has the same bits as from the stand-alone GEMM), stages
+// them as fp16 in the now idle ring (Q, K, V: 32 KiB each), pulls the cached prefix K/V of the tile's <= 3 clean captions into
+// LDS by LDS-DMA (once per tile instead of once per candidate), and then its eight waves run attn_fwd_kernel's MFMA body per
+// sequence with every operand out of LDS.  Only the attention output (2d bytes per row) is written.
+//
+// LDS map (160 KiB): [0, 96 K) ring slots 0-2 = Q | K | V staging, 256 rows x 128 B each (after the K loop); [96 K, 156 K) three
+// caption images (K rows then V rows, 80 x 128 B each); [156 K, 160 K) row statistics, sequence table, a zero line.
+#include "common.h"
+#include "kernels.h"
+#include "lnfold.h"
+
+namespace {
+
+constexpr int BM = 256, BNH = 192, BK = 64, NSLOT = 5, HD = 64;
+constexpr int HALF = BM * BK * 2;            // 32 KiB: one ring slot (an A panel; a B panel uses 24 KiB of it)
+constexpr int RING = NSLOT * HALF;           // 160 KiB
+constexpr int NCAP = LEAF_QKVATTN_NCAP, CAPROWS = LEAF_QKVATTN_CAPROWS;
+constexpr int MAXT = CAPROWS / 16;           // 16-row key / query tiles per sequence
+constexpr int CAP_OFF = 3 * HALF;
+constexpr int CAP_IMG = CAPROWS * 128;       // one K (or V) image of a caption
+constexpr int MISC_OFF = CAP_OFF + NCAP * 2 * CAP_IMG;
+constexpr int STAT_OFF = MISC_OFF;           // float2[256]: (mean, rstd) of the tile's rows
+constexpr int SEQ_OFF = STAT_OFF + 2048;     // u32[256]: row | len << 9 | prefix << 16 | slot << 23 per sequence of the tile
+constexpr int EOT_OFF = SEQ_OFF + 1024;      // u8[256]: pooled position per sequence (last-layer mode)
+constexpr int ZERO_OFF = EOT_OFF + 256;      // 128 zero bytes: V rows beyond a sequence's end
+static_assert(ZERO_OFF + 128 <= RING, "LDS map");
+static_assert(MAXT * 16 == CAPROWS && CAPROWS <= 96, "caption image rows");
+
+// In-kernel stamps (diagnostic builds only: -DLEAF_GEMM_STAMPS): s_memtime at phase boundaries, one 8-slot record per workgroup
+#ifdef LEAF_GEMM_STAMPS
+#define STAMP(i)                                                                                          \
+    if (p.stamps && tid == 0) {                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        ((unsigned long long*)p.stamps)[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime();    \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+    }
+#else
+#define STAMP(i)
+#endif
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+typedef __attribute__((address_space(3))) char lds_char_t;
+
+__device__ __forceinline__ int lds_off_h(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+__device__ __forceinline__ int vswz(int row) { return 2 * ((row >> 1) & 3); }     // attention.hip's V image swizzle
+
+template <class TT>
+__global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QkvAttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+    // work item = (M tile, head); the heads of a tile are consecutive logical ids, an XCD owns a contiguous range: the tile's A
+    // panel is fetched from beyond L2 once and shared by its 12-20 heads
+    const int logical = xcd_remap(blockIdx.x, p.n_tiles * p.heads);
+    const int tile = logical / p.heads, h = logical - tile * p.heads;
+    const int s_b = p.tile_seq[tile], s_e = p.tile_seq[tile + 1];      // sequences of this tile (indices inside the launch)
+    const int nseq = s_e - s_b;
+    const int r0 = seq_row(p.map, p.map.s0 + s_b);                      // first row of the tile (launch-local)
+    const int d = p.d;
+
+    // ---- per-sequence facts and row statistics: requested now, consumed in the epilogue (registers across the K loop)
+    unsigned my_seq = 0;
+    int my_eot = 0;
+    if (tid < nseq) {
+        const int sg = p.map.s0 + s_b + tid;
+        const int row = seq_row(p.map, sg) - r0, len = seq_len(p.map, sg), pfx = seq_prefix(p.map, sg);
+        int slot = 0;
+        if (pfx > 0) {
+            const int first = p.map.s0 + s_b > p.map.group_off ? p.map.s0 + s_b : p.map.group_off;
+            slot = (sg - p.map.group_off) / p.map.group - (first - p.map.group_off) / p.map.group;
+            slot = slot < 0 ? 0 : (slot > NCAP - 1 ? NCAP - 1 : slot);
+        }
+        my_seq = (unsigned)row | ((unsigned)len << 9) | ((unsigned)pfx << 16) | ((unsigned)slot << 23);
+        if (p.eot_pos) my_eot = p.eot_pos[s_b + tid];
+    }
+    float2 my_rowstat = float2{0.f, 0.f};
+    if (tid < BM && r0 + tid < p.M) my_rowstat = p.rowstat[r0 + tid];
+    // caption images: rows of the tile's captions inside the cache (uniform: scalar loads)
+    int cap_row0[NCAP], cap_rows[NCAP];
+    {
+        const int first = p.map.s0 + s_b > p.map.group_off ? p.map.s0 + s_b : p.map.group_off;
+        const int last = p.map.s0 + s_e - 1;
+#pragma unroll
+        for (int c = 0; c < NCAP; ++c) {
+            cap_row0[c] = 0; cap_rows[c] = 0;
+            if (p.map.prefix && p.kv_base && last >= p.map.group_off) {
+                const int cap = (first - p.map.group_off) / p.map.group + c;
+                if (cap <= (last - p.map.group_off) / p.map.group) {
+                    cap_row0[c] = p.map.base_cu[cap];
+                    const int n = p.map.base_cu[cap + 1] - cap_row0[c];
+                    cap_rows[c] = n < CAPROWS ? n : CAPROWS;
+                }
+            }
+        }
+    }
+
+    // ---- DMA sources (gemm256h.hip): wave w moves pieces 4w..4w+3 of an A panel, 3w..3w+2 of a B panel (8 rows x 128 B each)
+    const char* __restrict__ A = (const char*)p.A;
+    const char* __restrict__ B = (const char*)p.B;
+    unsigned a0, a1, a2, a3, b0, b1, b2;
+    {
+        const int prow = lane >> 3;
+        const int schunk = (lane & 7) ^ prow;
+        auto arow = [&](int j) { int r = r0 + wid * 32 + 8 * j + prow; return r < p.M ? r : p.M - 1; };
+        a0 = (unsigned)arow(0) * (unsigned)p.lda * 2u + schunk * 16;
+        a1 = (unsigned)arow(1) * (unsigned)p.lda * 2u + schunk * 16;
+        a2 = (unsigned)arow(2) * (unsigned)p.lda * 2u + schunk * 16;
+        a3 = (unsigned)arow(3) * (unsigned)p.lda * 2u + schunk * 16;
+        // B panel row r (0..191) = weight row (r / 64) * d + h * 64 + r % 64 of the standard [q; k; v] layout
+        auto brow = [&](int q) { const int pc = 3 * wid + q; return (pc >> 3) * d + h * HD + (pc & 7) * 8 + prow; };
+        b0 = (unsigned)brow(0) * (unsigned)p.ldb * 2u + schunk * 16;
+        b1 = (unsigned)brow(1) * (unsigned)p.ldb * 2u + schunk * 16;
+        b2 = (unsigned)brow(2) * (unsigned)p.ldb * 2u + schunk * 16;
+    }
+    const int apiece = wid * 4096, bpiece = wid * 3072;
+#define DMA16(src, dst) __builtin_amdgcn_global_load_lds((glb_void_t*)(src), (lds_void_t*)(dst), 16, 0, 0)
+#define ISSUE_A(so, kt, q) DMA16(A + (size_t)((kt) * (BK * 2)) + ((q) == 0 ? a0 : (q) == 1 ? a1 : (q) == 2 ? a2 : a3), smem + (so) + apiece + (q) * 1024)
+#define ISSUE_B(so, kt, q) DMA16(B + (size_t)((kt) * (BK * 2)) + ((q) == 0 ? b0 : (q) == 1 ? b1 : b2), smem + (so) + bpiece + (q) * 1024)
+#define ISSUE_HALF_A(so, kt) ISSUE_A(so, kt, 0); ISSUE_A(so, kt, 1); ISSUE_A(so, kt, 2); ISSUE_A(so, kt, 3);
+#define ISSUE_HALF_B(so, kt) ISSUE_B(so, kt, 0); ISSUE_B(so, kt, 1); ISSUE_B(so, kt, 2);
+
+    f32x4 acc[8][3];
+    const int frow = lane & 15, fkc = lane >> 4;
+    const int fo0 = lds_off_h(frow, fkc), fo1 = lds_off_h(frow, 4 + fkc);
+    const int xbase = wm * 128 * 128, wbase = wn * 48 * 128;
+    typedef typename TT::vec8 frag_t;
+    frag_t Fx0, Fx1, Fx2, Fx3, Fx4, Fx5, Fx6, Fx7, Fw0, Fw1, Fw2;
+    frag_t Gx0, Gx1, Gx2, Gx3, Gx4, Gx5, Gx6, Gx7, Gw0, Gw1, Gw2;
+#define LD(ptr) (*(const frag_t*)(ptr))
+#define READ_FRAGS(P, sa, sb, fo)                                                                            \
+    {                                                                                                        \
+        const char* sa_ = smem + (sa) + xbase + (fo);                                                        \
+        const char* sb_ = smem + (sb) + wbase + (fo);                                                        \
+        P##w0 = LD(sb_); P##w1 = LD(sb_ + 2048); P##w2 = LD(sb_ + 4096);                                     \
+        P##x0 = LD(sa_); P##x1 = LD(sa_ + 2048); P##x2 = LD(sa_ + 4096); P##x3 = LD(sa_ + 6144);             \
+        P##x4 = LD(sa_ + 8192); P##x5 = LD(sa_ + 10240); P##x6 = LD(sa_ + 12288); P##x7 = LD(sa_ + 14336);   \
+    }
+#define MF(P, i, j) acc[i][j] = TT::mfma(P##w##j, P##x##i, acc[i][j]);
+#define MROW(P, i) MF(P, i, 0) MF(P, i, 1) MF(P, i, 2)
+#define RDX(P, n) P##x##n = LD(sa_ + (n) * 2048);
+#define RDW(P, n) P##w##n = LD(sb_ + (n) * 2048);
+#define SB __builtin_amdgcn_sched_barrier(0);
+#define SYNC_TILE(cnt)                                                                                       \
+    SB                                                                                                       \
+    asm volatile("s_waitcnt vmcnt(" #cnt ") lgkmcnt(0)" ::: "memory");                                       \
+    __builtin_amdgcn_s_barrier();                                                                            \
+    asm volatile("" ::: "memory");
+    // one 32-deep k-step (24 MFMAs, 11 fragment reads), software-pipelined as in gemm256h.hip: CUR's reads are issued one at a
+    // time in the shadow of PREV's rows 4-7 and CUR's own rows 0-1, the DMA pieces of a half-stage between the MFMA rows
+#define KSTEP(PREV, CUR, sa, sb, fo, IS0, IS1, IS2, IS3)                                                     \
+    {                                                                                                        \
+        const char* sa_ = smem + (sa) + xbase + (fo);                                                        \
+        const char* sb_ = smem + (sb) + wbase + (fo);                                                        \
+        SB MF(PREV, 4, 0) SB RDW(CUR, 0) SB MF(PREV, 4, 1) SB RDW(CUR, 1) SB MF(PREV, 4, 2) SB RDW(CUR, 2) SB IS0 \
+        SB MF(PREV, 5, 0) SB RDX(CUR, 0) SB MF(PREV, 5, 1) SB RDX(CUR, 1) SB MF(PREV, 5, 2) SB IS1           \
+        SB MF(PREV, 6, 0) SB RDX(CUR, 2) SB MF(PREV, 6, 1) SB RDX(CUR, 3) SB MF(PREV, 6, 2) SB IS2           \
+        SB MROW(PREV, 7) SB IS3                                                                              \
+        SB MF(CUR, 0, 0) SB RDX(CUR, 4) SB MF(CUR, 0, 1) SB RDX(CUR, 5) SB MF(CUR, 0, 2)                     \
+        SB MF(CUR, 1, 0) SB RDX(CUR, 6) SB MF(CUR, 1, 1) SB RDX(CUR, 7) SB MF(CUR, 1, 2)                     \
+        SB MROW(CUR, 2) MROW(CUR, 3) SB                                                                      \
+    }
+#define NOP_
+#define ADV(x) { x += 2 * HALF; if (x >= RING) x -= RING; }
+    const int nt = p.K / BK;   // >= 4 (host-checked)
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int sa = 0, sb = HALF;
+    int i0 = 3 * HALF, i1 = 4 * HALF;
+    STAMP(0)
+    ISSUE_HALF_A(0, 0) ISSUE_HALF_B(HALF, 0) ISSUE_HALF_A(2 * HALF, 1)
+    SYNC_TILE(4)
+    STAMP(1)
+    READ_FRAGS(G, sa, sb, fo0)
+    SB ISSUE_B(i0, 1, 0); ISSUE_B(i0, 1, 1); SB
+    MROW(G, 0) MROW(G, 1) SB ISSUE_B(i0, 1, 2); SB MROW(G, 2) MROW(G, 3)
+    KSTEP(G, F, sa, sb, fo1, ISSUE_A(i1, 2, 0);, ISSUE_A(i1, 2, 1);, ISSUE_A(i1, 2, 2);, ISSUE_A(i1, 2, 3);)
+    ADV(sa) ADV(sb) ADV(i0) ADV(i1)
+    int T = 1;
+    for (; T <= nt - 3; ++T) {
+        SYNC_TILE(4)
+        KSTEP(F, G, sa, sb, fo0, ISSUE_B(i0, T + 1, 0);, ISSUE_B(i0, T + 1, 1);, ISSUE_B(i0, T + 1, 2);, NOP_)
+        KSTEP(G, F, sa, sb, fo1, ISSUE_A(i1, T + 2, 0);, ISSUE_A(i1, T + 2, 1);, ISSUE_A(i1, T + 2, 2);, ISSUE_A(i1, T + 2, 3);)
+        ADV(sa) ADV(sb) ADV(i0) ADV(i1)
+    }
+    SYNC_TILE(4)
+    KSTEP(F, G, sa, sb, fo0, ISSUE_B(i0, T + 1, 0);, ISSUE_B(i0, T + 1, 1);, ISSUE_B(i0, T + 1, 2);, NOP_)
+    KSTEP(G, F, sa, sb, fo1, NOP_, NOP_, NOP_, NOP_)
+    ADV(sa) ADV(sb)
+    SYNC_TILE(0)
+    KSTEP(F, G, sa, sb, fo0, NOP_, NOP_, NOP_, NOP_)
+    KSTEP(G, F, sa, sb, fo1, NOP_, NOP_, NOP_, NOP_)
+    SB MROW(F, 4) MROW(F, 5) MROW(F, 6) MROW(F, 7) SB
+    STAMP(2)
+
+    // ================================================================ epilogue: the ring is idle after this barrier
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (tid < BM) *(float2*)(smem + STAT_OFF + tid * 8) = my_rowstat;
+    if (tid < nseq) {
+        *(unsigned*)(smem + SEQ_OFF + tid * 4) = my_seq;
+        *(unsigned char*)(smem + EOT_OFF + tid) = (unsigned char)my_eot;
+    }
+    if (tid < 32) *(unsigned*)(smem + ZERO_OFF + tid * 4) = 0u;
+    // LN-fold operands of this lane's columns: tile column cb + 4 fq + e, cb = wn * 48 + 16 j, belongs to part cb / 64 (q, k, v)
+    const int fq = lane >> 4, efrow = lane & 15;
+    float4 bias4[3], s4[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int cb = wn * 48 + 16 * j;
+        const int gn = (cb >> 6) * d + h * HD + (cb & 63) + 4 * fq;
+        bias4[j] = *(const float4*)(p.bias + gn);
+        s4[j] = *(const float4*)(p.ln_s + gn);
+    }
+    __syncthreads();
+    float2 rs_all[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rs_all[i] = *(const float2*)(smem + STAT_OFF + (wm * 128 + 16 * i + efrow) * 8);
+    // everything loaded so far is retired before the caption DMAs go out: with LDS-DMAs in flight the compiler would drain
+    // vmcnt(0) in front of the first use of any ordinary load, and in front of any LDS access it can see (the staging below is asm)
+    __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0)
+    // ---- cached prefix K / V of the tile's captions -> LDS images (waves 0..2 NCAP - 1: wave = 2 slot + (0: K, 1: V))
+    if (wid < 2 * NCAP) {
+        const int slot = wid >> 1, isv = wid & 1;
+        int rows = 0, row0 = 0;
+#pragma unroll
+        for (int c = 0; c < NCAP; ++c) if (c == slot) { rows = cap_rows[c]; row0 = cap_row0[c]; }
+        const int vr = lane >> 3, vc = lane & 7;
+        const u16* src0 = (const u16*)p.kv_base + (size_t)row0 * p.kv_ld + (1 + isv) * d + h * HD;
+        char* img = smem + CAP_OFF + (2 * slot + isv) * CAP_IMG;
+        for (int pc = 0; 8 * pc < rows; ++pc) {
+            const int r = 8 * pc + vr;
+            const int sw = isv ? vswz(r) : (r & 7);
+            if (r < rows) DMA16(src0 + (size_t)r * p.kv_ld + ((vc ^ sw) << 3), img + pc * 1024);
+        }
+    }
+    // ---- this wave's 128 x 48 accumulators -> LN-fold -> 16 bit -> staging (inline-asm stores: see above)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = wm * 128 + 16 * i + efrow;
+        const float2 rs = rs_all[i];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int cb = wn * 48 + 16 * j, part = cb >> 6;
+            const f32x2 v0 = lnfold_apply2(f32x2{acc[i][j][0], acc[i][j][1]}, rs.x, rs.y, f32x2{s4[j].x, s4[j].y}, f32x2{bias4[j].x, bias4[j].y});
+            const f32x2 v1 = lnfold_apply2(f32x2{acc[i][j][2], acc[i][j][3]}, rs.x, rs.y, f32x2{s4[j].z, s4[j].w}, f32x2{bias4[j].z, bias4[j].w});
+            const uint2 pk = uint2{TT::pack2(v0), TT::pack2(v1)};
+            const int chunk = ((cb & 63) >> 3) + (fq >> 1);
+            const int sw = part == 2 ? vswz(row) : (row & 7);
+            char* dst = smem + part * HALF + row * 128 + ((chunk ^ sw) << 4) + (fq & 1) * 8;
+            const unsigned off = (unsigned)(uintptr_t)(lds_char_t*)dst;
+            const unsigned long long pk64 = __builtin_bit_cast(unsigned long long, pk);
+            asm volatile("ds_write_b64 %0, %1" ::"v"(off), "v"(pk64) : "memory");
+        }
+    }
+    STAMP(3)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    STAMP(4)
+
+    // ================================================================ attention: one wave per sequence, attn_fwd_kernel's body
+    const int r16 = lane & 15, g = lane >> 4;
+    for (int si = wid; si < nseq; si += 8) {
+        const unsigned sq = *(const unsigned*)(smem + SEQ_OFF + si * 4);
+        const int row_s = sq & 511, len = (sq >> 9) & 127, pfx = (sq >> 16) & 127, slot = (sq >> 23) & 3;
+        const int ctx = pfx + len;
+        const int eot = p.eot_pos ? (int)*(const unsigned char*)(smem + EOT_OFF + si) : -1;
+        const char* capK = smem + CAP_OFF + 2 * slot * CAP_IMG;
+        const char* capV = capK + CAP_IMG;
+        const int ntl = (ctx + 15) >> 4;
+        const int qt0 = eot >= 0 ? eot >> 4 : pfx >> 4;
+        const int qt1 = eot >= 0 ? eot >> 4 : ntl - 1;
+        // position pos of this sequence -> its K (or Q) row image, chunk-swizzled by the row's index inside that image
+        auto krow = [&](int pos, int chunk) -> const char* {
+            if (pos < pfx) return capK + pos * 128 + ((chunk ^ (pos & 7)) << 4);
+            const int r = row_s + pos - pfx;
+            return smem + HALF + r * 128 + ((chunk ^ (r & 7)) << 4);
+        };
+        typename TT::vec8 kf[MAXT][2];
+#pragma unroll
+        for (int kt = 0; kt < MAXT; ++kt) {
+            if (kt < ntl) {
+                int row = kt * 16 + r16; row = row < ctx ? row : ctx - 1;
+                kf[kt][0] = *(const typename TT::vec8*)krow(row, g);
+                kf[kt][1] = *(const typename TT::vec8*)krow(row, g + 4);
+            }
+        }
+#pragma unroll
+        for (int qt = 0; qt < MAXT; ++qt) {
+            if (qt < ntl && qt >= qt0 && qt <= qt1) {
+                const int qidx = qt * 16 + r16;
+                int qv = qidx < ctx ? qidx : ctx - 1;
+                qv = qv < pfx ? pfx : qv;
+                const int qr = row_s + qv - pfx;
+                const typename TT::vec8 qf0 = *(const typename TT::vec8*)(smem + qr * 128 + ((g ^ (qr & 7)) << 4));
+                const typename TT::vec8 qf1 = *(const typename TT::vec8*)(smem + qr * 128 + (((g + 4) ^ (qr & 7)) << 4));
+                f32x4 sc[MAXT];
+                float m = -INFINITY;
+#pragma unroll
+                for (int kt = 0; kt <= qt; ++kt) {
+                    f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+                    a = TT::mfma(kf[kt][0], qf0, a);
+                    a = TT::mfma(kf[kt][1], qf1, a);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float s = a[e] * 0.18033688011112042f;   // 1/sqrt(64) * log2(e)
+                        if (kt == qt) s = (kt * 16 + 4 * g + e) > qv ? -INFINITY : s;
+                        a[e] = s;
+                        m = __builtin_fmaxf(m, s);
+                    }
+                    sc[kt] = a;
+                }
+                m = __builtin_fmaxf(m, __shfl_xor(m, 16, 64));
+                m = __builtin_fmaxf(m, __shfl_xor(m, 32, 64));
+                float sum = 0.f;
+#pragma unroll
+                for (int kt = 0; kt <= qt; ++kt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float pe = __builtin_amdgcn_exp2f(sc[kt][e] - m);
+                        sc[kt][e] = pe;
+                        sum += pe;
+                    }
+                sum += __shfl_xor(sum, 16, 64);
+                sum += __shfl_xor(sum, 32, 64);
+                const float inv = 1.0f / sum;
+                f32x4 o[4];
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kt = 0; kt < MAXT; ++kt) {
+                    if (kt <= qt) {
+                        const s16x4 pf = __builtin_bit_cast(
+                            s16x4, pack4_bounded<TT>(sc[kt][0] * inv, sc[kt][1] * inv, sc[kt][2] * inv, sc[kt][3] * inv));
+                        // V^T fragment (attention.hip load_vt_frag): lane 4 q + pp of a 16-lane group supplies key kt 16 + 4 g + q,
+                        // dims dim0 + 4 pp .. + 3; keys beyond the sequence read the zero line (P is zero there; 0 x anything must stay +0)
+                        const int q4 = r16 >> 2, pp = r16 & 3;
+                        const int pos = kt * 16 + 4 * g + q4;
+                        const char* vrow;
+                        int vr;
+                        if (pos >= ctx) { vrow = smem + ZERO_OFF; vr = 0; }
+                        else if (pos < pfx) { vrow = capV + pos * 128; vr = pos; }
+                        else { vr = row_s + pos - pfx; vrow = smem + 2 * HALF + vr * 128; }
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt) {
+                            typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+                            const int chunk = (pos >= ctx) ? (2 * dt + (pp >> 1)) & 7 : ((2 * dt + (pp >> 1)) ^ vswz(vr));
+                            const s16x4 vf = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vrow + (chunk << 4) + (pp & 1) * 8));
+                            o[dt] = TT::mfma16(vf, pf, o[dt]);
+                        }
+                    }
+                }
+                if (eot >= 0 ? qidx == eot : (qidx < ctx && qidx >= pfx)) {
+                    u16* op = (u16*)p.out + (eot >= 0 ? (size_t)(s_b + si) : (size_t)r0 + row_s + qidx - pfx) * d + h * HD + 4 * g;
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt)
+                        *(uint2*)(op + dt * 16) = pack4_bounded<TT>(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
+                }
+            }
+        }
+    }
+#ifdef LEAF_GEMM_STAMPS
+    __syncthreads();      // the stamp below then is the end of the SLOWEST wave's sequences
+#endif
+    STAMP(5)
+#undef ADV
+#undef DMA16
+#undef ISSUE_A
+#undef ISSUE_B
+#undef ISSUE_HALF_A
+#undef ISSUE_HALF_B
+#undef READ_FRAGS
+#undef MROW
+#undef SYNC_TILE
+#undef KSTEP
+#undef MF
+#undef RDW
+#undef RDX
+#undef NOP_
+#undef SB
+#undef LD
+}
+
+}  // namespace
+
+// Greedy cut of the launch's sequences into M tiles of whole sequences: <= 256 rows, and (prefix mode) the prefixed sequences of a
+// tile belong to <= NCAP consecutive captions (sequence s >= group_off belongs to caption (s - group_off) / group).
+// lens[i] = rows sequence s0 + i computes; out[0..n_tiles] = first sequence (launch-relative) of each tile, out[n_tiles] = n.
+int leaf_qkv_attn_plan(const int32_t* lens, int ctx, int s0, int n, int prefixed, int group, int group_off, int32_t* out) {
+    int nt = 0, rows = 0, first_cap = -1;
+    out[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        const int L = lens ? lens[i] : ctx;
+        const int sg = s0 + i;
+        const int cap = (prefixed && sg >= group_off && group > 0) ? (sg - group_off) / group : -1;
+        const bool cut = i > out[nt] && (rows + L > BM || (cap >= 0 && first_cap >= 0 && cap - first_cap >= NCAP));
+        if (cut) { out[++nt] = i; rows = 0; first_cap = -1; }
+        rows += L;
+        if (cap >= 0 && first_cap < 0) first_cap = cap;
+    }
+    out[++nt] = n;
+    return nt;
+}
+
+bool leaf_qkv_attn_eligible(int d, int heads, int ctx, int K, int max_len) {
+    return d == heads * HD && d % 64 == 0 && K % BK == 0 && K >= 4 * BK && ctx <= CAPROWS && (max_len <= 0 || max_len <= CAPROWS) &&
+           (unsigned long long)3 * d * K * 2ull < (1ull << 32);
+}
+
+hipError_t leaf_launch_qkv_attn(const QkvAttnArgs& a_in, int dtype, hipStream_t s) {
+    QkvAttnArgs a = a_in;
+    a.stamps = leaf_gemm_get_stamps();
+    if (a.n_tiles < 1 || a.heads < 1 || (unsigned long long)a.M * a.lda * 2ull >= (1ull << 32)) return hipErrorInvalidValue;
+    const dim3 grid(a.n_tiles * a.heads), blk(512);
+#define LEAF_QA(TT)                                                                                                    \
+    {                                                                                                                  \
+        static bool attr = false;                                                                                      \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)qkv_attn_kernel<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, RING); attr = true; } \
+        hipLaunchKernelGGL((qkv_attn_kernel<TT>), grid, blk, RING, s, a);                                              \
+    }
+    if (dtype == LEAF_F16) LEAF_QA(F16) else LEAF_QA(BF16)
+#undef LEAF_QA
+    return hipGetLastError();
+}

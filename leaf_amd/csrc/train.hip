@@ -602,7 +602,8 @@ __global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict_
 // Saturation check of the 16-bit gradient tensors of one transformer block (fp16 gradient path): a stored value of magnitude
 // >= 65504 (0x7BFF: the conversions saturate there; 0x7C00.. = inf / NaN) means the loss scale was too large for this step.
 // The reference's GradScaler finds that as an inf in the unscaled gradients; here the kernel raises scaler[LEAF_SC_SAT_FLAG] and
-// POISONS gradient element 0 with NaN -- the padding row of the token-embedding table, which no kept row ever touches -- so
+// POISONS gradient element 0 with NaN -- the first element of the token-embedding gradient (token id 0 is the BPE token '!', not
+// padding: what matters is that every later writer of that element only adds to it, and NaN + x stays NaN) -- so
 // that the non-finite guard of the optimizer step skips the step on THIS rank and, through the gradient all-reduce, on every rank.
 struct SatArgs { const uint16_t* buf[5]; unsigned long long n8[5]; };   // element counts in units of 8 (16-byte chunks)
 __global__ __launch_bounds__(256) void sat_check16_kernel(SatArgs a, float* __restrict__ scaler, float* __restrict__ poison) {

@@ -145,9 +145,16 @@ class LeafAdamW:
     def state_dict(self):
         """torch.optim.AdamW.state_dict() of the reference's optimizer (two groups in its parameter order, per-parameter
         step / exp_avg / exp_avg_sq views of the flat moments): what --resume of the reference loads (train_AT_text_only.py:366)."""
-        from .checkpoint import non_text_parameters, optimizer_state_to_torch
+        from .checkpoint import image_tower_is_known, non_text_parameters, optimizer_state_to_torch
         m, g = self.model, self.param_groups[1]
         extra = None if self.lock_image else m.extra_state
+        if extra and not image_tower_is_known(extra):
+            # e.g. a timm trunk: which of its tensors are parameters cannot be told from the names, and a wrong guess would
+            # SHIFT the parameter ids of the full-CLIP layout silently
+            unknown = [k for k in extra if not image_tower_is_known({k: 0})][:3]
+            logging.warning(f"optimizer state_dict: the start checkpoint's image tower is not one of open_clip's ViT / ModifiedResNet "
+                            f"(e.g. {unknown}); writing the TEXT-ONLY groups, which the reference resumes only with --lock-image")
+            extra = None
         n_vis = len(non_text_parameters(extra))
         logging.info("optimizer state_dict: " + (f"the reference's groups over the whole CLIP ({n_vis} carried-through non-text parameters "
                                                  "hold ids without state)" if n_vis else
@@ -439,6 +446,9 @@ def train_one_epoch_text_only(model, model_frozen, tokenizer, V, data, loss, epo
         _, adv_texts = attack_text(model, tokenizer, texts, anchor, device, objective='l2', n=args.rho, k=args.k_adv,
                                    V=V, constrain=args.constrain, debug=False, anchor_ready=anchor_ready)
         times.append(time.time() - t0)
+        if i == 0 and os.environ.get("LEAF_DEBUG_DUMP_ADV"):   # test hook: this rank's first adversarial batch of the epoch
+            with open(os.path.join(os.environ["LEAF_DEBUG_DUMP_ADV"], f"adv_epoch{epoch}_rank{getattr(args, 'rank', 0)}.txt"), "w") as f:
+                f.write("\n".join(f"{a}\t{b}" for a, b in zip(texts, adv_texts)) + "\n")
         adv_tokens = tokenizer.encode_batch(adv_texts)
         model.train()
         feat = model.forward_train(adv_tokens, normalize=normalize_fare)

@@ -213,3 +213,20 @@ def test_non_text_tensors_are_carried_through():
     extra = CK.non_text_tensors({"epoch": 3, "state_dict": sd})
     assert sorted(extra) == ["visual.conv1.weight", "visual.proj"]
     assert CK.non_text_tensors({"text_model.embeddings.token_embedding.weight": torch.zeros(2, 2)}) == {}
+
+
+def test_unknown_image_tower_is_not_guessed_into_the_optimizer_layout():
+    """which carried-through tensors are parameters can only be told for open_clip's own ViT / ModifiedResNet towers; a
+    timm trunk's buffers (relative_position_index, ...) would shift the ids of a full-CLIP optimizer layout, so such a
+    checkpoint gets the text-only layout (with a warning) instead of a silently wrong one."""
+    from leaf_amd.checkpoint import image_tower_is_known
+    vit = ["visual.class_embedding", "visual.positional_embedding", "visual.proj", "visual.conv1.weight", "visual.ln_pre.weight",
+           "visual.transformer.resblocks.23.attn.in_proj_weight", "visual.transformer.resblocks.0.mlp.c_proj.bias",
+           "visual.transformer.resblocks.3.ls_1.gamma", "visual.ln_post.bias", "logit_bias"]
+    rn = ["visual.conv2.weight", "visual.bn1.running_var", "visual.bn3.num_batches_tracked", "visual.layer3.5.conv2.weight",
+          "visual.layer1.0.downsample.0.weight", "visual.layer4.0.downsample.1.bias", "visual.attnpool.c_proj.bias",
+          "visual.attnpool.positional_embedding"]
+    assert image_tower_is_known({}) and image_tower_is_known(None)
+    assert image_tower_is_known({k: 0 for k in vit + rn})
+    for k in ("visual.trunk.blocks.0.attn.relative_position_index", "visual.trunk.patch_embed.proj.weight", "visual.head.proj.weight"):
+        assert not image_tower_is_known({**{v: 0 for v in vit}, k: 0}), k

@@ -106,6 +106,10 @@ def test_bucket_plan_partitions_the_gradient_buffer(name):
             assert inside == (ev <= blk <= hi_layer and k.endswith("weight") and "ln_" not in k), k
         hi_layer = ev - 1
     assert hi_layer == -1
+    # the fp16 backward's saturation poison (NaN in gradient element 0 = token_embedding.weight[0, 0], api_train.hip) must ride in
+    # the LAST collective: a bucket launched earlier would ship a clean element 0 while another rank skips the step
+    assert layout["token_embedding.weight"][0] == 0
+    assert any(off == 0 and m > 0 for off, m in plan[-1][1]) and not any(off <= 0 < off + m for _, rs in plan[:-1] for off, m in rs)
     # one block per bucket when asked for
     assert [ev for ev, _ in bucket_plan(layout, n, cfg.layers, min_bytes=1)] == list(reversed(range(cfg.layers))) + [cfg.layers]
 

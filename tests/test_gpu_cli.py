@@ -144,3 +144,52 @@ def test_train_cli_normalize_fare_and_grad_clip(tmp_path, monkeypatch):
     hdr, vals = rows[0].split(","), rows[1].split(",")
     loss = float(vals[hdr.index("loss")])
     assert np.isfinite(loss) and 0.0 <= loss <= 4.0        # squared distance of two unit vectors
+
+
+def test_train_cli_two_ranks_under_torch_distributed_run(tmp_path):
+    """The trainer itself at world size 2: `python -m torch.distributed.run --nproc-per-node 2 train_AT_text_only.py
+    --dist-backend gloo` with both ranks on this box's one GPU (RCCL needs a device per rank: the driver's scaling run), two epochs,
+    --constrain and --accum-freq 2.  One checkpoint, the replicas' weights identical after every epoch (the CLI all-gathers a
+    checksum), different captions and different search randomness per rank (seed + rank: train_AT_text_only.py:60-63,281), and a
+    second launch into the same experiment folder ends on EVERY rank instead of hanging in the first collective."""
+    import socket
+    import subprocess
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    words = tmp_path / "words.txt"
+    words.write_text("\n".join("a photo of the small red car on wet street with two people near old house in sunny park at night "
+                               "dog cat bird tree river bridge mountain snow beach city table chair".split()) + "\n")
+    dump = tmp_path / "adv"
+    dump.mkdir()
+
+    def launch():
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        env["LEAF_DEBUG_DUMP_ADV"] = str(dump)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(root, "train_AT_text_only.py"), "--dist-backend", "gloo",
+               "--model", "tiny-test-quickgelu", "--dataset-type", "synthetic", "--train-num-samples", "64", "--batch-size", "8",
+               "--accum-freq", "2", "--lr", "1e-4", "--wd", "1e-4", "--warmup", "2", "--rho", "6", "--k_adv", "1", "--seed", "5",
+               "--epochs", "2", "--constrain", "--dictionary-file", str(words), "--dictionary-tokenizer", "treebank",
+               "--custom_out_folder", "d_", "--logs", str(tmp_path / "logs"), "--name", "run2", "--log-every-n-steps", "1"]
+        return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=tmp_path)
+
+    p = launch()
+    assert p.returncode == 0, (p.stdout + p.stderr)[-4000:]
+    out = tmp_path / "results" / "d_text_only_k1_rho6_seed5"
+    assert sorted(f.name for f in out.iterdir()) == ["epoch_latest.pt", "results.csv"]
+    ck = torch.load(out / "epoch_latest.pt", map_location="cpu", weights_only=False)
+    assert ck["epoch"] == 2 and float(ck["optimizer"]["state"][1]["step"]) == 4         # 64 / (8 * 2 ranks) / accum 2 = 2 steps per epoch
+    log = p.stdout + p.stderr
+    assert log.count("weights identical on 2 ranks") == 2, log[-3000:]
+    a0, a1 = ((dump / f"adv_epoch0_rank{r}.txt").read_text().splitlines() for r in (0, 1))
+    assert len(a0) == len(a1) == 8
+    assert [l.split("\t")[0] for l in a0] != [l.split("\t")[0] for l in a1], "ranks must read different captions"
+    assert any(l.split("\t")[0] != l.split("\t")[1] for l in a0 + a1), "the search changed nothing on either rank"
+    # the same command again: the experiment exists -> the master says so and BOTH ranks leave (no hang, non-zero exit)
+    p2 = launch()
+    assert p2.returncode != 0 and "Experiment already exists" in p2.stdout + p2.stderr

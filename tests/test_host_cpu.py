@@ -252,3 +252,23 @@ def test_host_text_under_sanitizers(tmp_path):
         merges.write_bytes(f.read())
     r = subprocess.run([exe, "4000", str(merges)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "fuzz ok" in r.stdout and "runtime error" not in r.stderr, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def test_fused_qkv_attention_tile_plan_properties():
+    """The host-side cut into M tiles (leaf_qkv_attn_plan, through its test hook): whole sequences, <= 256 rows, <= 3 captions."""
+    import ctypes as C
+    from leaf_amd import _lib
+    lib = _lib.lib()
+    rng = np.random.default_rng(0)
+    for trial in range(20):
+        B, rho = int(rng.integers(1, 40)), int(rng.integers(1, 60))
+        goff = B if trial % 2 else 0
+        lens = np.concatenate([rng.integers(2, 78, goff), rng.integers(1, 78 if trial % 3 else 3, B * rho)]).astype(np.int32)
+        out = np.zeros(lens.size + 2, dtype=np.int32)
+        nt = lib.leaf_debug_qkv_attn_plan(lens.ctypes.data_as(C.c_void_p), 77, 0, lens.size, 1, rho, goff, out.ctypes.data_as(C.c_void_p))
+        cut = out[: nt + 1]
+        assert cut[0] == 0 and cut[-1] == lens.size and (np.diff(cut) > 0).all()
+        for a, b in zip(cut[:-1], cut[1:]):
+            assert lens[a:b].sum() <= 256
+            caps = [(s - goff) // rho for s in range(a, b) if s >= goff]
+            assert not caps or caps[-1] - caps[0] < 3

@@ -39,6 +39,10 @@ def init_distributed_device(args):
     args.distributed, args.world_size, args.rank, args.local_rank = False, 1, 0, 0
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         args.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        ndev = torch.cuda.device_count()
+        if args.dist_backend == "gloo" and ndev and args.local_rank >= ndev:
+            # rehearsal on a box with fewer GPUs than ranks (gloo moves CUDA tensors through the host; RCCL wants a device per rank)
+            args.local_rank %= ndev
         torch.cuda.set_device(args.local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.distributed.init_process_group(backend=args.dist_backend)
@@ -160,6 +164,15 @@ def main(argv):
             logging.info(f'Start epoch {epoch}')
         log = train_one_epoch_text_only(model, frozen, tokenizer, V, data, None, epoch, optimizer, None, scheduler, args)
         completed = epoch + 1
+        if args.distributed:
+            # every rank applied the same summed gradient to the same weights: they must still be the same bits (one small
+            # all-gather per epoch; a replica that drifted would otherwise only show up as a slowly diverging loss)
+            chk = [None] * args.world_size
+            torch.distributed.all_gather_object(chk, (float(model.flat.double().sum()), float(model.flat.double().abs().sum())))
+            if any(c != chk[0] for c in chk):
+                raise RuntimeError(f"epoch {completed}: replicas differ across ranks (weight checksums {chk})")
+            if is_master(args):
+                logging.info(f"epoch {completed}: weights identical on {args.world_size} ranks (checksum {chk[0][0]:.9g})")
         if is_master(args):
             results.append({"epoch": completed, **{k.replace("train/", ""): v for k, v in log.items()}})
             import pandas as pd
