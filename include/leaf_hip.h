@@ -301,18 +301,11 @@ int leaf_op_gemm_lnfold(int dtype, int act, const void* A, const void* Bp, void*
  * 16-bit residual copy x16 [rows, width], Wp = 16-bit(gamma * in_proj_weight) [3 width, width] with its c / s vectors and the rows'
  * (mean, rstd).  lens (HOST) = rows per sequence, cu (device) their exclusive prefix sum; prefix / base_cu / kv (device, or all
  * NULL) = cached-prefix mode as in leaf_score_candidates_prefix with candidates grouped `group` per caption; tile_seq = device
- * scratch [n_seq + 1].  Kernel hook for tools/qkv_attn_bench.py; the scoring passes call the same launch internally. */
+ * scratch [2 (n_seq + 1)].  Kernel hook for tools/qkv_attn_bench.py; the scoring passes call the same launch internally. */
 int leaf_op_qkv_attn(int dtype, const void* x16, const void* Wp, const float* c_vec, const float* s_vec, const void* rowstat,
                      void* out, const void* kv, const int32_t* lens, const int32_t* cu, const int32_t* prefix,
                      const int32_t* base_cu, const int32_t* eot_pos, int32_t* tile_seq, int n_seq, int rows, int group,
                      int ctx, int heads, int width, leaf_stream_t s);
-/* host-side cut of a pass's sequences into the M tiles of the fused QKV + attention launch (leaf_amd/csrc/qkv_attn.hip): whole
- * sequences, <= 256 rows, prefixed sequences of <= 3 consecutive captions; out [n + 1] receives the first sequence of every
- * tile and n behind the last, returns the number of tiles (test hook, tests/test_host_cpu.py) */
-int leaf_debug_qkv_attn_plan(const int32_t* lens, int ctx, int s0, int n, int prefixed, int group, int group_off, int32_t* out);
-int leaf_debug_gemm_stamps(void* buf);
-/* dispatch tuning (tools/small_gemm_sweep.py): fewest 256 x 256 tiles for which the half-stage ring kernel takes a launch */
-int leaf_debug_gemm_min_tiles(int n);
 int leaf_op_attention_fwd(const void* qkv, void* out, int n_seq, int ctx, int heads, int width, int dtype,
                           leaf_stream_t s);
 int leaf_op_layernorm(const float* x, const float* g, const float* b, float eps, void* out16, int rows, int width,

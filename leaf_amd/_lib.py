@@ -108,9 +108,6 @@ _SIGS = {
     "leaf_op_gemm_lnfold": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "leaf_op_qkv_attn": (C.c_int, [C.c_int] + [C.c_void_p] * 13 + [C.c_int] * 6 + [C.c_void_p]),
-    "leaf_debug_qkv_attn_plan": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
-    "leaf_debug_gemm_stamps": (C.c_int, [C.c_void_p]),
-    "leaf_debug_gemm_min_tiles": (C.c_int, [C.c_int]),
     "leaf_op_attention_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "leaf_op_layernorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int,
                                     C.c_int, C.c_void_p]),
@@ -132,6 +129,14 @@ SC_COEF, SC_NORM, SC_SKIPPED, SC_BACKOFF, SC_GOOD, SC_SAT_FLAG, SC_SAT_STEPS, SC
 SC_WORDS = 16
 
 EXPORTS = tuple(_SIGS)
+# include/leaf_hip_diag.h: exported only by the diagnostic builds under tools/diag/ (make -C leaf_amd/csrc variants, stamps, ...);
+# bound when the loaded library (LEAF_HIP_LIB) has them, absent from libleaf_hip.so
+DIAG_SIGS = {
+    "leaf_debug_qkv_attn_plan": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "leaf_debug_gemm_stamps": (C.c_int, [C.c_void_p]),
+    "leaf_debug_gemm_min_tiles": (C.c_int, [C.c_int]),
+}
+VARIANTS_LIB = os.path.join(os.path.dirname(_HERE), "tools", "diag", "libleaf_hip_variants.so")
 _lib = None
 
 
@@ -147,11 +152,30 @@ def lib():
             raise LeafHipError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
                                f"g.build()'` or `make -C leaf_amd/csrc` (the HIP extension is mandatory)")
         l = C.CDLL(LIB_PATH)
-        for name, (res, args) in _SIGS.items():
-            fn = getattr(l, name)
-            fn.restype, fn.argtypes = res, args
+        _bind(l, _SIGS)
+        _bind(l, DIAG_SIGS, optional=True)
         _lib = l
     return _lib
+
+
+def _bind(l, sigs, optional=False):
+    for name, (res, args) in sigs.items():
+        fn = getattr(l, name, None)
+        if fn is None:
+            if optional:
+                continue
+            raise LeafHipError(f"{name} missing from {LIB_PATH}")
+        fn.restype, fn.argtypes = res, args
+
+
+def diag_lib():
+    """The diagnostic build with the kept experiments and the leaf_debug_* exports (make -C leaf_amd/csrc variants), loaded beside
+    the product library: host-side hooks only (the tile-plan test); GPU tools select it for the whole process with LEAF_HIP_LIB."""
+    if not os.path.exists(VARIANTS_LIB):
+        raise LeafHipError(f"{VARIANTS_LIB} not found: make -C leaf_amd/csrc variants (or __graft_entry__.build())")
+    l = C.CDLL(VARIANTS_LIB)
+    _bind(l, DIAG_SIGS)
+    return l
 
 
 def check(rc: int, what: str):

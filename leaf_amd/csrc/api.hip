@@ -290,14 +290,14 @@ struct FwdBuf {
     uint16_t* x16; // [rows,d]   LN folding: 16-bit copy of the residual stream (A operand of the QKV / c_fc GEMMs)
     float2* stat;  // [d/64][rows] LN folding: (sum, M2) per row and 64-column group
     float2* rowstat; // [rows]     LN folding: (mean, rstd) per row
-    int32_t* tile_seq; // [seqs + 1] fused QKV + attention: first sequence of every M tile (a sequence has >= 1 row)
+    int32_t* tile_seq; // [seqs + 1][2] fused QKV + attention: (first sequence, first row) of every M tile (a sequence has >= 1 row)
 };
 
 size_t fwd_chunk_bytes(const leaf_text* h, int cs) {
     const size_t rows = (size_t)cs * h->cfg.context_length, d = h->cfg.width;
     Carver c(nullptr, 0);
     c.take(rows * d * 4); c.take(rows * d * 2); c.take(rows * 3 * d * 2); c.take(rows * 4 * d * 2); c.take(rows * 4);
-    c.take(rows * d * 2); c.take(rows * (d / 64) * 8); c.take(rows * 8); c.take((rows + 2) * 4);
+    c.take(rows * d * 2); c.take(rows * (d / 64) * 8); c.take(rows * 8); c.take((rows + 2) * 8);
     return align_up(c.off, 256);
 }
 
@@ -312,7 +312,7 @@ FwdBuf carve_fwd(const leaf_text* h, Carver& c, int cs) {
     b.x16 = (uint16_t*)c.take(rows * d * 2);
     b.stat = (float2*)c.take(rows * (d / 64) * 8);
     b.rowstat = (float2*)c.take(rows * 8);
-    b.tile_seq = (int32_t*)c.take((rows + 2) * 4);
+    b.tile_seq = (int32_t*)c.take((rows + 2) * 8);
     return b;
 }
 
@@ -329,6 +329,7 @@ struct KvPlan {
     size_t kv_self_rows = 0;
     // fused QKV + attention launches (qkv_attn.hip): number of M tiles cut for this chunk (b.tile_seq holds them); 0 = two kernels
     int attn_tiles = 0;
+    int attn_max_len = 0;     // longest sequence (prefix + computed rows) the plan was cut for: sizes the caption images
 };
 
 int forward_chunk(const leaf_text* h, const float* P, const uint16_t* W, const int32_t* tokens, int cs, int rows,
@@ -402,6 +403,7 @@ int forward_chunk(const leaf_text* h, const float* P, const uint16_t* W, const i
             qa.rowstat = ln.rowstat; qa.out = b.a; qa.kv_base = kvl; qa.eot_pos = trim ? b.eot : nullptr; qa.tile_seq = b.tile_seq;
             qa.map = map; qa.M = rows; qa.K = d; qa.lda = d; qa.ldb = d; qa.heads = c.heads; qa.d = d; qa.n_tiles = kv.attn_tiles;
             qa.n_seq = cs; qa.kv_ld = 3 * d; qa.stamps = nullptr;
+            leaf_qkv_attn_lds_plan(kv.attn_max_len, &qa.ncap, &qa.caprows);
             if (leaf_qkv_attn(qa, dt, s)) return 1;
         } else
         if (qkv_gemm(l, rows, ln, b.a)) return 1;
@@ -547,8 +549,8 @@ int forward_all(leaf_text* h, const float* P, const void* W, const int32_t* toke
         // fused QKV + attention for the big passes: cut the chunk's sequences into M tiles of whole sequences on the host and send
         // the cut points behind the work already queued (a pinned ring slot; its event keeps a slot from being rewritten early)
         if (h->fuse_attn && h->ln_fold && leaf_qkv_attn_eligible(h->cfg.width, h->cfg.heads, ctx, h->cfg.width, max_len) &&
-            rows / 256 * (size_t)h->cfg.heads >= 256) {
-            const size_t need = (size_t)(s1 - s0) + 2;
+            rows / 256 * (size_t)h->cfg.heads >= 256) {      // at least a chip's worth of (256-row tile, head) items
+            const size_t need = 2 * ((size_t)(s1 - s0) + 2);
             if (h->plan_cap < need) {
                 for (int i = 0; i < leaf_text::PLAN_RING; ++i) {
                     if (h->plan_ev[i]) LEAF_TRY(hipEventSynchronize(h->plan_ev[i]));
@@ -562,9 +564,10 @@ int forward_all(leaf_text* h, const float* P, const void* W, const int32_t* toke
             if (!h->plan_ev[k]) LEAF_TRY(hipEventCreateWithFlags(&h->plan_ev[k], hipEventDisableTiming));
             else LEAF_TRY(hipEventSynchronize(h->plan_ev[k]));
             kv.attn_tiles = leaf_qkv_attn_plan(lens ? lens + s0 : nullptr, ctx, s0, s1 - s0, pp.prefix_dev != nullptr, pp.group, pp.group_off,
-                                               h->plan_host[k]);
+                                               leaf_qkv_attn_tile_rows(), leaf_qkv_attn_ncap(max_len), h->plan_host[k]);
+            kv.attn_max_len = max_len;
             hipStream_t cs_ = set ? h->side : s;
-            LEAF_TRY(hipMemcpyAsync(bufs[set].tile_seq, h->plan_host[k], (size_t)(kv.attn_tiles + 1) * sizeof(int32_t), hipMemcpyHostToDevice, cs_));
+            LEAF_TRY(hipMemcpyAsync(bufs[set].tile_seq, h->plan_host[k], (size_t)(kv.attn_tiles + 1) * 2 * sizeof(int32_t), hipMemcpyHostToDevice, cs_));
             LEAF_TRY(hipEventRecord(h->plan_ev[k], cs_));
         }
         if (forward_chunk(h, P, (const uint16_t*)W, tokens, s1 - s0, (int)rows, map, out + (size_t)s0 * h->cfg.embed_dim,
@@ -753,10 +756,11 @@ extern "C" int leaf_op_qkv_attn(int dtype, const void* x16, const void* Wp, cons
                                 const int32_t* base_cu, const int32_t* eot_pos, int32_t* tile_seq, int n_seq, int rows, int group,
                                 int ctx, int heads, int width, leaf_stream_t s) {
     if (!leaf_qkv_attn_eligible(width, heads, ctx, width, 0)) { leaf_set_error("qkv_attn: unsupported shape"); return 1; }
-    std::vector<int32_t> plan((size_t)n_seq + 2);
+    std::vector<int32_t> plan(2 * ((size_t)n_seq + 2));
     QkvAttnArgs qa;
-    qa.n_tiles = leaf_qkv_attn_plan(lens, ctx, 0, n_seq, prefix != nullptr, group, 0, plan.data());
-    LEAF_TRY(hipMemcpy(tile_seq, plan.data(), (size_t)(qa.n_tiles + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+    leaf_qkv_attn_lds_plan(ctx, &qa.ncap, &qa.caprows);
+    qa.n_tiles = leaf_qkv_attn_plan(lens, ctx, 0, n_seq, prefix != nullptr, group, 0, leaf_qkv_attn_tile_rows(), qa.ncap, plan.data());
+    LEAF_TRY(hipMemcpy(tile_seq, plan.data(), (size_t)(qa.n_tiles + 1) * 2 * sizeof(int32_t), hipMemcpyHostToDevice));
     qa.A = x16; qa.B = Wp; qa.bias = c_vec; qa.ln_s = s_vec; qa.rowstat = (const float2*)rowstat; qa.out = out; qa.kv_base = kv;
     qa.eot_pos = eot_pos; qa.tile_seq = tile_seq;
     qa.map = RowMap{cu, 0, 0, ctx, prefix, base_cu, group > 0 ? group : 1, 0};
@@ -764,11 +768,16 @@ extern "C" int leaf_op_qkv_attn(int dtype, const void* x16, const void* Wp, cons
     qa.stamps = nullptr;
     return leaf_check(leaf_launch_qkv_attn(qa, dtype, (hipStream_t)s), "qkv_attn");
 }
-extern "C" int leaf_debug_qkv_attn_plan(const int32_t* lens, int ctx, int s0, int n, int prefixed, int group, int group_off, int32_t* out) {
-    return leaf_qkv_attn_plan(lens, ctx, s0, n, prefixed, group, group_off, out);
+// ---- diagnostic exports (include/leaf_hip_diag.h): only in the builds of `make variants` / `make stamps` ... under tools/diag/
+#ifdef LEAF_VARIANTS
+extern "C" int leaf_debug_qkv_attn_plan(const int32_t* lens, int ctx, int s0, int n, int prefixed, int group, int group_off, int tile_rows,
+                                        int ncap, int32_t* out) {
+    return leaf_qkv_attn_plan(lens, ctx, s0, n, prefixed, group, group_off, tile_rows > 0 ? tile_rows : leaf_qkv_attn_tile_rows(),
+                              ncap > 0 ? ncap : leaf_qkv_attn_ncap(ctx), out);
 }
 extern "C" int leaf_debug_gemm_stamps(void* buf) { leaf_gemm_set_stamps(buf); return 0; }
 extern "C" int leaf_debug_gemm_min_tiles(int n) { leaf_gemm256h_set_min_tiles(n); return 0; }
+#endif
 extern "C" int leaf_op_attention_fwd(const void* qkv, void* out, int n_seq, int ctx, int heads, int width, int dtype,
                                      leaf_stream_t s) {
     return leaf_check(leaf_launch_attention_fwd(qkv, nullptr, out, n_seq, RowMap{nullptr, 0, 0, ctx, nullptr, nullptr, 1}, heads, width, dtype,

@@ -50,8 +50,6 @@ struct BwdBuf {
     uint16_t* big16;  // [rows,4d] bf16
     uint16_t* dqkv;   // [rows,3d] bf16
     uint16_t* do16;   // [rows,d] bf16
-    uint16_t* tA;     // [4d,rpad] bf16
-    uint16_t* tB;     // [4d,rpad] bf16
     float* dout;      // [n,D]
     float* gscale;    // {S, 1/S}
     float* lnpart;    // [2 layers][leaf_ln_bwd_grid][2][d] per-workgroup partial sums of the LayerNorm parameter gradients
@@ -59,7 +57,6 @@ struct BwdBuf {
 
 BwdBuf carve_bwd(const leaf_text* h, Carver& c, int n_seq, size_t rows) {
     const size_t d = h->cfg.width;
-    const size_t rpad = align_up(rows, 64);
     BwdBuf b;
     b.dx = (float*)c.take(rows * d * 4);
     b.dx16 = (uint16_t*)c.take(rows * d * 2);
@@ -68,8 +65,6 @@ BwdBuf carve_bwd(const leaf_text* h, Carver& c, int n_seq, size_t rows) {
     b.big16 = (uint16_t*)c.take(rows * 4 * d * 2);
     b.dqkv = (uint16_t*)c.take(rows * 3 * d * 2);
     b.do16 = (uint16_t*)c.take(rows * d * 2);
-    b.tA = (uint16_t*)c.take(4 * d * rpad * 2);
-    b.tB = (uint16_t*)c.take(4 * d * rpad * 2);
     b.dout = (float*)c.take((size_t)n_seq * h->cfg.embed_dim * 4);
     b.gscale = (float*)c.take(256 + (size_t)n_seq * 8);   // {S, 1/S} + per-caption loss partials
     b.lnpart = (float*)c.take((size_t)2 * h->cfg.layers * leaf_ln_bwd_grid((int)rows, (int)d) * 2 * d * 4);
@@ -168,20 +163,11 @@ static int backward_impl(leaf_text_t h, const float* P, const void* w16_bwd, con
     if (!cw.ok()) { leaf_set_error("workspace too small: need %zu bytes, have %zu", cw.off, cw.cap); return 1; }
     const RowMap map{cu_rows, 0, 0, cf.context_length, nullptr, nullptr, 1};
     const int d = cf.width, L = cf.layers, D = cf.embed_dim;
-    const int rpad = (int)align_up((size_t)rows, 64);
     const size_t rd = (size_t)rows * d;
     const int fk = h->fwd_dtype == LEAF_DTYPE_FP16 ? 1 : 0;  // source kind of stashed activations
     const int gk = h->grad_dtype == LEAF_DTYPE_FP16 ? 1 : 0;  // 16-bit kind of the gradient path (kind == LEAF_* dtype id)
     const float* inv_s = b.gscale + 1;
     const uint16_t* WT = (const uint16_t*)w16_bwd;
-
-    // dW[Nw,Kw] += (dY^T X) / S  via  NT GEMM on transposed 16-bit copies; alpha = 1/S read on the device
-    auto wgrad = [&](const uint16_t* dY, int Nw, const void* X, int xkind, int Kw, float* dW) -> int {
-        LEAF_TRY(leaf_launch_transpose16(dY, gk, b.tA, gk, rows, Nw, Nw, rpad, s));
-        LEAF_TRY(leaf_launch_transpose16(X, xkind, b.tB, gk, rows, Kw, Kw, rpad, s));
-        return leaf_gemm(gk, EPI_STORE_F32, b.tA, rpad, b.tB, rpad, dW, Kw, nullptr, nullptr, Nw, Kw, rpad, 0, s, 1.0f, 0,
-                         inv_s);
-    };
 
     LEAF_TRY(leaf_launch_fare_loss(feat, anchor, n_seq, D, accum_scale, loss_out, b.dout, b.gscale, gk == 1, s,
                                    h->normalize_fare ? st.norms : nullptr, h->scaler));
@@ -193,10 +179,6 @@ static int backward_impl(leaf_text_t h, const float* P, const void* w16_bwd, con
                                           b.dxn /* free until the first dgrad */, s));
     LEAF_TRY(leaf_launch_cast16(b.dx, 2, b.dx16, gk, rd, s));
 
-    // LEAF_WGRAD=0: first implementation (two transposes + NT GEMM per weight, atomics column sums), kept for A/B
-    static int grouped = -1;
-    if (grouped < 0) { const char* e = getenv("LEAF_WGRAD"); grouped = (e && e[0] == '0') ? 0 : 1; }
-
     const int ln_grid = leaf_ln_bwd_grid(rows, d);
     const size_t ln_stride = (size_t)ln_grid * 2 * d;      // floats per LayerNorm in b.lnpart
     for (int l = L - 1; l >= 0; --l) {
@@ -205,33 +187,16 @@ static int backward_impl(leaf_text_t h, const float* P, const void* w16_bwd, con
         const uint16_t* xn1 = st.xn1 + l * rd; const uint16_t* qkv = st.qkv + 3 * l * rd; const uint16_t* ao = st.ao + l * rd;
         const uint16_t* xn2 = st.xn2 + l * rd; const uint16_t* pre = st.pre + 4 * l * rd; const uint16_t* hh = st.hh + 4 * l * rd;
         // ---- MLP
-        if (G && !grouped) {
-            if (wgrad(b.dx16, d, hh, fk, 4 * d, G + o.proj_w)) return 1;
-            LEAF_TRY(leaf_launch_colsum(b.dx16, gk, b.gscale, d, rows, d, G + o.proj_b, s));
-        }
         if (leaf_gemm(gk, EPI_ACTGRAD_T, b.dx16, d, WT + h->w16_proj(l), d, b.big16, 4 * d, nullptr, (void*)pre, rows,
                  4 * d, d, cf.activation, s, 0.f, fk)) return 1;
-        if (G && !grouped) {
-            if (wgrad(b.big16, 4 * d, xn2, fk, d, G + o.fc_w)) return 1;
-            LEAF_TRY(leaf_launch_colsum(b.big16, gk, b.gscale, 4 * d, rows, 4 * d, G + o.fc_b, s));
-        }
         if (leaf_gemm(gk, EPI_STORE_F32, b.big16, 4 * d, WT + h->w16_fc(l), 4 * d, b.dxn, d, nullptr, nullptr, rows, d,
                  4 * d, 0, s)) return 1;
         LEAF_TRY(leaf_launch_layernorm_bwd(b.dxn, x1, P + o.ln2_w, cf.ln_eps, b.dx, b.dx16b, gk,
                                            G ? b.lnpart + (size_t)(2 * l + 1) * ln_stride : nullptr, rows, d, s));
         // ---- attention
-        if (G && !grouped) {
-            if (wgrad(b.dx16b, d, ao, fk, d, G + o.out_w)) return 1;
-            LEAF_TRY(leaf_launch_colsum(b.dx16b, gk, b.gscale, d, rows, d, G + o.out_b, s));
-        }
         if (leaf_gemm(gk, EPI_STORE_T, b.dx16b, d, WT + h->w16_out(l), d, b.do16, d, nullptr, nullptr, rows, d, d, 0, s)) return 1;
         LEAF_TRY(leaf_launch_attention_bwd(qkv, h->fwd_dtype, b.do16, b.dqkv, gk, n_seq, map, cf.heads, d, s));
-        if (!G) {
-            // input-gradient-only: nothing to accumulate
-        } else if (!grouped) {
-            if (wgrad(b.dqkv, 3 * d, xn1, fk, d, G + o.qkv_w)) return 1;
-            LEAF_TRY(leaf_launch_colsum(b.dqkv, gk, b.gscale, 3 * d, rows, 3 * d, G + o.qkv_b, s));
-        } else {
+        if (G) {
             // all four weight + bias gradients of the block in one launch (wgrad.hip); must run before ln1's backward
             // overwrites dx16, the dY of c_proj
             WgradArgs wa{};

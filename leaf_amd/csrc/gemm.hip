@@ -324,9 +324,11 @@ static bool use_gemm64(const GemmArgs& p) {
 int leaf_gemm_family(const GemmArgs& p, int epi) {
     static int use256h = -1;   // LEAF_GEMM256H=0: A/B and test switch (the two-stage kernel then takes the big launches)
     if (use256h < 0) { const char* e = getenv("LEAF_GEMM256H"); use256h = (e && e[0] == '0') ? 0 : 1; }
-    static int use_pp = -1;    // LEAF_GEMM_PP=1: the two-workgroups-per-CU 128 x 256 kernel (gemm128pp.hip) takes the big launches
+#ifdef LEAF_VARIANTS         // diagnostic builds only (make variants): the round-3 two-workgroups-per-CU experiment, never in libleaf_hip.so
+    static int use_pp = -1;    // LEAF_GEMM_PP=1: the two-workgroups-per-CU 128 x 256 kernel (variants/gemm128pp.hip) takes the big launches
     if (use_pp < 0) { const char* e = getenv("LEAF_GEMM_PP"); use_pp = (e && e[0] == '1') ? 1 : 0; }
     if (use_pp && p.M > 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && leaf_gemm128pp_eligible(p, epi)) return 7;
+#endif
     if (use256h && p.M > 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && leaf_gemm256h_eligible(p, epi)) return 4;
     static int use256 = -1;
     if (use256 < 0) { const char* e = getenv("LEAF_GEMM256"); use256 = (e && e[0] == '0') ? 0 : 1; }
@@ -344,7 +346,9 @@ hipError_t leaf_launch_gemm(const GemmArgs& p_in, int dtype, int epi, hipStream_
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.N % BN || p.K % BK || p.lda % 8 || p.ldb % 8 || p.ldc % 4)
         return hipErrorInvalidValue;
     const int fam = leaf_gemm_family(p, epi);
+#ifdef LEAF_VARIANTS
     if (fam == 7) return leaf_launch_gemm128pp(p, dtype, epi, s);
+#endif
     if (fam == 4) return leaf_launch_gemm256h(p, dtype, epi, s);
     if (fam == 6) return leaf_launch_gemm64(p, dtype, epi, s);
     return dtype == LEAF_F16 ? launch_t<F16>(p, epi, s) : launch_t<BF16>(p, epi, s);

@@ -55,7 +55,7 @@ bool leaf_gemm256h_eligible(const GemmArgs& p, int epi);
 void leaf_gemm256h_set_min_tiles(int n);
 int leaf_gemm256h_pick_ngroup(const GemmArgs& p);   // N tiles per L2-sized group (0 = one group)
 hipError_t leaf_launch_gemm256h(const GemmArgs& p, int dtype, int epi, hipStream_t s);
-// 128 x 256 tiles, 4 waves, two workgroups per CU out of phase (gemm128pp.hip)
+// 128 x 256 tiles, 4 waves, two workgroups per CU out of phase (variants/gemm128pp.hip: diagnostic builds only, -DLEAF_VARIANTS)
 bool leaf_gemm128pp_eligible(const GemmArgs& p, int epi);
 void leaf_gemm128pp_set_min_tiles(int n);
 hipError_t leaf_launch_gemm128pp(const GemmArgs& p, int dtype, int epi, hipStream_t s);
@@ -75,12 +75,17 @@ struct QkvAttnArgs {
     void* out;                // attention output [M, d] 16-bit (eot_pos: [n_seq, d], one row per sequence)
     const void* kv_base;      // this layer's cached q|k|v rows of the clean captions (row stride kv_ld), or null
     const int32_t* eot_pos;   // last-layer mode: pooled position per sequence of the launch, or null
-    const int32_t* tile_seq;  // [n_tiles + 1] first sequence (launch-relative) of every M tile (leaf_qkv_attn_plan)
+    const int32_t* tile_seq;  // [n_tiles + 1][2] (first sequence, first row), launch-relative, of every M tile (leaf_qkv_attn_plan)
     RowMap map;
     int M, K, lda, ldb, heads, d, n_tiles, n_seq, kv_ld;
+    int ncap, caprows;        // caption images in LDS: how many, rows each (leaf_qkv_attn_lds_plan; the tile plan was cut for ncap)
     void* stamps;             // diagnostic builds only (-DLEAF_GEMM_STAMPS)
 };
-int leaf_qkv_attn_plan(const int32_t* lens, int ctx, int s0, int n, int prefixed, int group, int group_off, int32_t* out);
+int leaf_qkv_attn_tile_rows();                       // rows of an M tile of the kernel form in use
+int leaf_qkv_attn_ncap(int max_len);                 // captions per tile for sequences of <= max_len positions (0: not taken)
+void leaf_qkv_attn_lds_plan(int max_len, int* ncap, int* caprows);
+int leaf_qkv_attn_plan(const int32_t* lens, int ctx, int s0, int n, int prefixed, int group, int group_off, int tile_rows, int ncap,
+                       int32_t* out);
 bool leaf_qkv_attn_eligible(int d, int heads, int ctx, int K, int max_len);
 hipError_t leaf_launch_qkv_attn(const QkvAttnArgs& a, int dtype, hipStream_t s);
 
@@ -133,9 +138,6 @@ hipError_t leaf_launch_gather_rows(const float* x, const int32_t* eot_pos, float
                                    hipStream_t s);
 
 // ---- training-only kernels (train.hip)
-// dst[c, r] = (16-bit) src[r, c], zero padded to rpad columns.  kinds: 0 bf16, 1 fp16, 2 fp32 (source only)
-hipError_t leaf_launch_transpose16(const void* src, int src_kind, void* dst, int dst_kind, int rows, int cols, int ld_src,
-                                   int rpad, hipStream_t s);
 hipError_t leaf_launch_cast16(const void* src, int src_kind, void* dst, int dst_kind, size_t n, hipStream_t s);
 // loss = mean_b sum_j (anchor-feat)^2 ; dout = 2 (feat-anchor) / B * scale.  gscale[0] = S, gscale[1] = 1/S: the
 // power-of-two loss scale of the fp16 gradient path (S = 1 when use_scaling == 0), chosen so that max|dout| * S ~ 16.
@@ -168,9 +170,6 @@ struct LnReduceArgs {
     int n, grid, d;
 };
 hipError_t leaf_launch_ln_param_reduce(const LnReduceArgs& a, hipStream_t s);
-// dbias[n] += sum_r dy[r,n] / S   (dy 16-bit of kind gkind, row stride ld)
-hipError_t leaf_launch_colsum(const void* dy16, int gkind, const float* gscale, int ld, int rows, int n, float* dbias,
-                              hipStream_t s);
 // attention backward: q,k,v from qkv (fwd dtype), dO [rows,d] -> dqkv [rows,3d], both 16-bit of kind gkind
 // grouped TN weight/bias gradient launch (wgrad.hip): up to 4 problems dW[Nw,Kw] += alpha dY^T X, db[Nw] += alpha colsum(dY)
 struct WgradProb {

@@ -21,14 +21,13 @@
 
 namespace {
 
-constexpr int BM = 256, BNH = 192, BK = 64, NSLOT = 5, HD = 64;
+constexpr int BM = 256, BK = 64, NSLOT = 5, HD = 64;
 constexpr int HALF = BM * BK * 2;            // 32 KiB: one ring slot (an A panel; a B panel uses 24 KiB of it)
 constexpr int RING = NSLOT * HALF;           // 160 KiB
 constexpr int NCAP = LEAF_QKVATTN_NCAP, CAPROWS = LEAF_QKVATTN_CAPROWS;
 constexpr int MAXT = CAPROWS / 16;           // 16-row key / query tiles per sequence
 constexpr int CAP_OFF = 3 * HALF;
-constexpr int CAP_IMG = CAPROWS * 128;       // one K (or V) image of a caption
-constexpr int MISC_OFF = CAP_OFF + NCAP * 2 * CAP_IMG;
+constexpr int MISC_OFF = CAP_OFF + NCAP * 2 * CAPROWS * 128;   // images: p.ncap x (K rows, then V rows) of p.caprows rows each
 constexpr int STAT_OFF = MISC_OFF;           // float2[256]: (mean, rstd) of the tile's rows
 constexpr int SEQ_OFF = STAT_OFF + 2048;     // u32[256]: row | len << 9 | prefix << 16 | slot << 23 per sequence of the tile
 constexpr int EOT_OFF = SEQ_OFF + 1024;      // u8[256]: pooled position per sequence (last-layer mode)
@@ -55,6 +54,31 @@ typedef __attribute__((address_space(3))) char lds_char_t;
 __device__ __forceinline__ int lds_off_h(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 __device__ __forceinline__ int vswz(int row) { return 2 * ((row >> 1) & 3); }     // attention.hip's V image swizzle
 
+// x[l] (op) x[l ^ 16] (op) x[l ^ 32] (op) x[l ^ 48] for the four 16-lane rows of a wave on the gfx950 row / half swaps instead of
+// __shfl_xor's ds_bpermute (an LDS round trip each, four per query tile, on the critical path of a wave that has one partner to
+// hide behind).  v_permlane16_swap_b32 a, b: odd rows of a <-> even rows of b;  v_permlane32_swap_b32 a, b: lanes 32-63 of a <->
+// lanes 0-31 of b.  With a = b = x beforehand every lane then holds (its pair's low member, its pair's high member): the same
+// two operands as x and __shfl_xor(x, 16 | 32), in an order that max and the (commutative) IEEE add do not see -- same bits.
+// (Inline asm with the hazard pad inside: the builtin form folds max(r[0], r[1]) of a self-swap away.)
+__device__ __forceinline__ void swap_rows16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void swap_half32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ float rows4_max(float m) {
+    float a = m, b = m;
+    swap_rows16(a, b);
+    m = __builtin_fmaxf(a, b);
+    a = m; b = m;
+    swap_half32(a, b);
+    return __builtin_fmaxf(a, b);
+}
+__device__ __forceinline__ float rows4_sum(float x) {
+    float a = x, b = x;
+    swap_rows16(a, b);
+    x = a + b;
+    a = x; b = x;
+    swap_half32(a, b);
+    return a + b;
+}
+
 template <class TT>
 __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QkvAttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -65,24 +89,39 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QkvAttnArgs p) {
     // panel is fetched from beyond L2 once and shared by its 12-20 heads
     const int logical = xcd_remap(blockIdx.x, p.n_tiles * p.heads);
     const int tile = logical / p.heads, h = logical - tile * p.heads;
-    const int s_b = p.tile_seq[tile], s_e = p.tile_seq[tile + 1];      // sequences of this tile (indices inside the launch)
+    // the weight panel of K tile 0 needs nothing but the head: on its way before the first scalar load has come back
+    // (wave w moves pieces 3w..3w+2 of a B panel; B panel row r (0..191) = weight row (r / 64) * d + h * 64 + r % 64 of [q; k; v])
+    unsigned b0, b1, b2;
+    {
+        const int prow = lane >> 3;
+        const int schunk = (lane & 7) ^ prow;
+        auto brow = [&](int q) { const int pc = 3 * wid + q; return (pc >> 3) * p.d + h * HD + (pc & 7) * 8 + prow; };
+        b0 = (unsigned)brow(0) * (unsigned)p.ldb * 2u + schunk * 16;
+        b1 = (unsigned)brow(1) * (unsigned)p.ldb * 2u + schunk * 16;
+        b2 = (unsigned)brow(2) * (unsigned)p.ldb * 2u + schunk * 16;
+        const char* Bw = (const char*)p.B;
+        char* dst = smem + HALF + wid * 3072;
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(Bw + b0), (lds_void_t*)(dst), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(Bw + b1), (lds_void_t*)(dst + 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(Bw + b2), (lds_void_t*)(dst + 2048), 16, 0, 0);
+    }
+    // the tile's sequences (indices inside the launch) and its first row (launch-local), cut on the host: ONE round trip of scalar
+    // loads before the first operand DMA can go out (looking the row up in cu[] behind the sequence index was a second one)
+    const int2 tb = ((const int2*)p.tile_seq)[tile], te = ((const int2*)p.tile_seq)[tile + 1];
+    const int s_b = tb.x, s_e = te.x, r0 = tb.y;
     const int nseq = s_e - s_b;
-    const int r0 = seq_row(p.map, p.map.s0 + s_b);                      // first row of the tile (launch-local)
     const int d = p.d;
+    const int cap_img = p.caprows * 128;         // one K (or V) image of a caption
 
     // ---- per-sequence facts and row statistics: requested now, consumed in the epilogue (registers across the K loop)
-    unsigned my_seq = 0;
-    int my_eot = 0;
+    // (raw loaded values only: any arithmetic on them here would make the compiler wait for these loads -- and for the weight DMA
+    // above -- before the activation DMAs below can go out)
+    int my_c0 = 0, my_c1 = 0, my_pf = 0, my_eot = 0;
     if (tid < nseq) {
         const int sg = p.map.s0 + s_b + tid;
-        const int row = seq_row(p.map, sg) - r0, len = seq_len(p.map, sg), pfx = seq_prefix(p.map, sg);
-        int slot = 0;
-        if (pfx > 0) {
-            const int first = p.map.s0 + s_b > p.map.group_off ? p.map.s0 + s_b : p.map.group_off;
-            slot = (sg - p.map.group_off) / p.map.group - (first - p.map.group_off) / p.map.group;
-            slot = slot < 0 ? 0 : (slot > NCAP - 1 ? NCAP - 1 : slot);
-        }
-        my_seq = (unsigned)row | ((unsigned)len << 9) | ((unsigned)pfx << 16) | ((unsigned)slot << 23);
+        if (p.map.cu) { my_c0 = p.map.cu[sg]; my_c1 = p.map.cu[sg + 1]; }
+        else { my_c0 = sg * p.map.ctx; my_c1 = my_c0 + p.map.ctx; }
+        if (p.map.prefix) my_pf = p.map.prefix[sg];
         if (p.eot_pos) my_eot = p.eot_pos[s_b + tid];
     }
     float2 my_rowstat = float2{0.f, 0.f};
@@ -95,12 +134,11 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QkvAttnArgs p) {
 #pragma unroll
         for (int c = 0; c < NCAP; ++c) {
             cap_row0[c] = 0; cap_rows[c] = 0;
-            if (p.map.prefix && p.kv_base && last >= p.map.group_off) {
+            if (c < p.ncap && p.map.prefix && p.kv_base && last >= p.map.group_off) {
                 const int cap = (first - p.map.group_off) / p.map.group + c;
                 if (cap <= (last - p.map.group_off) / p.map.group) {
                     cap_row0[c] = p.map.base_cu[cap];
-                    const int n = p.map.base_cu[cap + 1] - cap_row0[c];
-                    cap_rows[c] = n < CAPROWS ? n : CAPROWS;
+                    cap_rows[c] = p.map.base_cu[cap + 1];      // (raw: the row count is formed in the epilogue)
                 }
             }
         }
@@ -109,7 +147,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QkvAttnArgs p) {
     // ---- DMA sources (gemm256h.hip): wave w moves pieces 4w..4w+3 of an A panel, 3w..3w+2 of a B panel (8 rows x 128 B each)
     const char* __restrict__ A = (const char*)p.A;
     const char* __restrict__ B = (const char*)p.B;
-    unsigned a0, a1, a2, a3, b0, b1, b2;
+    unsigned a0, a1, a2, a3;
     {
         const int prow = lane >> 3;
         const int schunk = (lane & 7) ^ prow;
@@ -118,11 +156,6 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QkvAttnArgs p) {
         a1 = (unsigned)arow(1) * (unsigned)p.lda * 2u + schunk * 16;
         a2 = (unsigned)arow(2) * (unsigned)p.lda * 2u + schunk * 16;
         a3 = (unsigned)arow(3) * (unsigned)p.lda * 2u + schunk * 16;
-        // B panel row r (0..191) = weight row (r / 64) * d + h * 64 + r % 64 of the standard [q; k; v] layout
-        auto brow = [&](int q) { const int pc = 3 * wid + q; return (pc >> 3) * d + h * HD + (pc & 7) * 8 + prow; };
-        b0 = (unsigned)brow(0) * (unsigned)p.ldb * 2u + schunk * 16;
-        b1 = (unsigned)brow(1) * (unsigned)p.ldb * 2u + schunk * 16;
-        b2 = (unsigned)brow(2) * (unsigned)p.ldb * 2u + schunk * 16;
     }
     const int apiece = wid * 4096, bpiece = wid * 3072;
 #define DMA16(src, dst) __builtin_amdgcn_global_load_lds((glb_void_t*)(src), (lds_void_t*)(dst), 16, 0, 0)
@@ -181,7 +214,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QkvAttnArgs p) {
     int sa = 0, sb = HALF;
     int i0 = 3 * HALF, i1 = 4 * HALF;
     STAMP(0)
-    ISSUE_HALF_A(0, 0) ISSUE_HALF_B(HALF, 0) ISSUE_HALF_A(2 * HALF, 1)
+    ISSUE_HALF_A(0, 0) ISSUE_HALF_A(2 * HALF, 1)      // (B of K tile 0: requested at the top of the kernel)
     SYNC_TILE(4)
     STAMP(1)
     READ_FRAGS(G, sa, sb, fo0)
@@ -198,6 +231,18 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QkvAttnArgs p) {
     }
     SYNC_TILE(4)
     KSTEP(F, G, sa, sb, fo0, ISSUE_B(i0, T + 1, 0);, ISSUE_B(i0, T + 1, 1);, ISSUE_B(i0, T + 1, 2);, NOP_)
+    // LN-fold operands of this lane's columns, requested behind the LAST operand DMA (from here on every wait is vmcnt(0), so
+    // these loads cannot shift a counted wait) with a K tile and a half of MFMAs to land under: tile column cb + 4 fq + e,
+    // cb = wn * 48 + 16 j, belongs to part cb / 64 (q, k, v)
+    const int fq = lane >> 4, efrow = lane & 15;
+    float4 bias4[3], s4[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int cb = wn * 48 + 16 * j;
+        const int gn = (cb >> 6) * d + h * HD + (cb & 63) + 4 * fq;
+        bias4[j] = *(const float4*)(p.bias + gn);
+        s4[j] = *(const float4*)(p.ln_s + gn);
+    }
     KSTEP(G, F, sa, sb, fo1, NOP_, NOP_, NOP_, NOP_)
     ADV(sa) ADV(sb)
     SYNC_TILE(0)
@@ -211,20 +256,19 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QkvAttnArgs p) {
     asm volatile("" ::: "memory");
     if (tid < BM) *(float2*)(smem + STAT_OFF + tid * 8) = my_rowstat;
     if (tid < nseq) {
+        const int sg = p.map.s0 + s_b + tid;
+        const int row = my_c0 - p.map.row0 - r0, len = my_c1 - my_c0, pfx = my_pf;
+        int slot = 0;
+        if (pfx > 0) {
+            const int first = p.map.s0 + s_b > p.map.group_off ? p.map.s0 + s_b : p.map.group_off;
+            slot = (sg - p.map.group_off) / p.map.group - (first - p.map.group_off) / p.map.group;
+            slot = slot < 0 ? 0 : (slot > p.ncap - 1 ? p.ncap - 1 : slot);
+        }
+        const unsigned my_seq = (unsigned)row | ((unsigned)len << 9) | ((unsigned)pfx << 16) | ((unsigned)slot << 23);
         *(unsigned*)(smem + SEQ_OFF + tid * 4) = my_seq;
         *(unsigned char*)(smem + EOT_OFF + tid) = (unsigned char)my_eot;
     }
     if (tid < 32) *(unsigned*)(smem + ZERO_OFF + tid * 4) = 0u;
-    // LN-fold operands of this lane's columns: tile column cb + 4 fq + e, cb = wn * 48 + 16 j, belongs to part cb / 64 (q, k, v)
-    const int fq = lane >> 4, efrow = lane & 15;
-    float4 bias4[3], s4[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int cb = wn * 48 + 16 * j;
-        const int gn = (cb >> 6) * d + h * HD + (cb & 63) + 4 * fq;
-        bias4[j] = *(const float4*)(p.bias + gn);
-        s4[j] = *(const float4*)(p.ln_s + gn);
-    }
     __syncthreads();
     float2 rs_all[8];
 #pragma unroll
@@ -233,14 +277,15 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QkvAttnArgs p) {
     // vmcnt(0) in front of the first use of any ordinary load, and in front of any LDS access it can see (the staging below is asm)
     __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0)
     // ---- cached prefix K / V of the tile's captions -> LDS images (waves 0..2 NCAP - 1: wave = 2 slot + (0: K, 1: V))
-    if (wid < 2 * NCAP) {
+    if (wid < 2 * p.ncap) {
         const int slot = wid >> 1, isv = wid & 1;
         int rows = 0, row0 = 0;
 #pragma unroll
-        for (int c = 0; c < NCAP; ++c) if (c == slot) { rows = cap_rows[c]; row0 = cap_row0[c]; }
+        for (int c = 0; c < NCAP; ++c) if (c == slot) { rows = cap_rows[c] - cap_row0[c]; row0 = cap_row0[c]; }
+        rows = rows < p.caprows ? rows : p.caprows;
         const int vr = lane >> 3, vc = lane & 7;
         const u16* src0 = (const u16*)p.kv_base + (size_t)row0 * p.kv_ld + (1 + isv) * d + h * HD;
-        char* img = smem + CAP_OFF + (2 * slot + isv) * CAP_IMG;
+        char* img = smem + CAP_OFF + (2 * slot + isv) * cap_img;
         for (int pc = 0; 8 * pc < rows; ++pc) {
             const int r = 8 * pc + vr;
             const int sw = isv ? vswz(r) : (r & 7);
@@ -279,8 +324,8 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QkvAttnArgs p) {
         const int row_s = sq & 511, len = (sq >> 9) & 127, pfx = (sq >> 16) & 127, slot = (sq >> 23) & 3;
         const int ctx = pfx + len;
         const int eot = p.eot_pos ? (int)*(const unsigned char*)(smem + EOT_OFF + si) : -1;
-        const char* capK = smem + CAP_OFF + 2 * slot * CAP_IMG;
-        const char* capV = capK + CAP_IMG;
+        const char* capK = smem + CAP_OFF + 2 * slot * cap_img;
+        const char* capV = capK + cap_img;
         const int ntl = (ctx + 15) >> 4;
         const int qt0 = eot >= 0 ? eot >> 4 : pfx >> 4;
         const int qt1 = eot >= 0 ? eot >> 4 : ntl - 1;
@@ -324,8 +369,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QkvAttnArgs p) {
                     }
                     sc[kt] = a;
                 }
-                m = __builtin_fmaxf(m, __shfl_xor(m, 16, 64));
-                m = __builtin_fmaxf(m, __shfl_xor(m, 32, 64));
+                m = rows4_max(m);
                 float sum = 0.f;
 #pragma unroll
                 for (int kt = 0; kt <= qt; ++kt)
@@ -335,8 +379,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QkvAttnArgs p) {
                         sc[kt][e] = pe;
                         sum += pe;
                     }
-                sum += __shfl_xor(sum, 16, 64);
-                sum += __shfl_xor(sum, 32, 64);
+                sum = rows4_sum(sum);
                 const float inv = 1.0f / sum;
                 f32x4 o[4];
 #pragma unroll
@@ -397,34 +440,54 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QkvAttnArgs p) {
 
 }  // namespace
 
-// Greedy cut of the launch's sequences into M tiles of whole sequences: <= 256 rows, and (prefix mode) the prefixed sequences of a
-// tile belong to <= NCAP consecutive captions (sequence s >= group_off belongs to caption (s - group_off) / group).
-// lens[i] = rows sequence s0 + i computes; out[0..n_tiles] = first sequence (launch-relative) of each tile, out[n_tiles] = n.
-int leaf_qkv_attn_plan(const int32_t* lens, int ctx, int s0, int n, int prefixed, int group, int group_off, int32_t* out) {
-    int nt = 0, rows = 0, first_cap = -1;
-    out[0] = 0;
+// Rows per caption image for sequences of <= max_len positions, and how many captions' images the LDS then holds
+static int caprows_for(int max_len) { const int m = max_len > 0 ? max_len : CAPROWS; return (m + 15) / 16 * 16; }
+int leaf_qkv_attn_tile_rows() { return BM; }
+int leaf_qkv_attn_ncap(int max_len) {
+    const int cr = caprows_for(max_len);
+    if (cr > CAPROWS) return 0;
+    const int n = (MISC_OFF - CAP_OFF) / (2 * cr * 128);
+    return n > NCAP ? NCAP : n;
+}
+void leaf_qkv_attn_lds_plan(int max_len, int* ncap, int* caprows) {
+    *ncap = leaf_qkv_attn_ncap(max_len);
+    *caprows = caprows_for(max_len);
+}
+
+// Greedy cut of the launch's sequences into M tiles of whole sequences: <= tile_rows rows, and (prefix mode) the prefixed sequences
+// of a tile belong to <= ncap consecutive captions (sequence s >= group_off belongs to caption (s - group_off) / group).
+// lens[i] = rows sequence s0 + i computes; out = (first sequence, first row) pairs, both launch-relative: out[2 t], out[2 t + 1] for
+// tile t and (n, total rows) behind the last tile (2 (n_tiles + 1) ints).
+int leaf_qkv_attn_plan(const int32_t* lens, int ctx, int s0, int n, int prefixed, int group, int group_off, int tile_rows, int ncap,
+                       int32_t* out) {
+    int nt = 0, rows = 0, first_cap = -1, total = 0;
+    out[0] = 0; out[1] = 0;
     for (int i = 0; i < n; ++i) {
         const int L = lens ? lens[i] : ctx;
         const int sg = s0 + i;
         const int cap = (prefixed && sg >= group_off && group > 0) ? (sg - group_off) / group : -1;
-        const bool cut = i > out[nt] && (rows + L > BM || (cap >= 0 && first_cap >= 0 && cap - first_cap >= NCAP));
-        if (cut) { out[++nt] = i; rows = 0; first_cap = -1; }
+        const bool cut = i > out[2 * nt] && (rows + L > tile_rows || (cap >= 0 && first_cap >= 0 && cap - first_cap >= ncap));
+        if (cut) { ++nt; out[2 * nt] = i; out[2 * nt + 1] = total; rows = 0; first_cap = -1; }
         rows += L;
+        total += L;
         if (cap >= 0 && first_cap < 0) first_cap = cap;
     }
-    out[++nt] = n;
+    ++nt;
+    out[2 * nt] = n; out[2 * nt + 1] = total;
     return nt;
 }
 
 bool leaf_qkv_attn_eligible(int d, int heads, int ctx, int K, int max_len) {
-    return d == heads * HD && d % 64 == 0 && K % BK == 0 && K >= 4 * BK && ctx <= CAPROWS && (max_len <= 0 || max_len <= CAPROWS) &&
+    return d == heads * HD && d % 64 == 0 && K % BK == 0 && K >= 4 * BK && ctx <= CAPROWS && leaf_qkv_attn_ncap(max_len > 0 ? max_len : ctx) >= 1 &&
            (unsigned long long)3 * d * K * 2ull < (1ull << 32);
 }
 
 hipError_t leaf_launch_qkv_attn(const QkvAttnArgs& a_in, int dtype, hipStream_t s) {
     QkvAttnArgs a = a_in;
     a.stamps = leaf_gemm_get_stamps();
-    if (a.n_tiles < 1 || a.heads < 1 || (unsigned long long)a.M * a.lda * 2ull >= (1ull << 32)) return hipErrorInvalidValue;
+    if (a.n_tiles < 1 || a.heads < 1 || a.ncap < 1 || a.ncap > NCAP || a.caprows < 16 || a.caprows % 16 || a.caprows > CAPROWS ||
+        2 * a.ncap * a.caprows * 128 > MISC_OFF - CAP_OFF || (unsigned long long)a.M * a.lda * 2ull >= (1ull << 32))
+        return hipErrorInvalidValue;
     const dim3 grid(a.n_tiles * a.heads), blk(512);
 #define LEAF_QA(TT)                                                                                                    \
     {                                                                                                                  \

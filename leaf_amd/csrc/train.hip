@@ -27,26 +27,6 @@ __device__ __forceinline__ void unpack4k(int kind, uint2 u, float (&o)[4]) {
     if (kind == 0) unpack4<BF16>(u, o); else unpack4<F16>(u, o);
 }
 
-// dst[c][r] = bf16(src[r][c]), r >= rows -> 0
-__global__ __launch_bounds__(256) void transpose16_kernel(const void* __restrict__ src, int kind,
-                                                          void* __restrict__ dst, int dkind, int rows, int cols, int ld_src,
-                                                          int rpad) {
-    __shared__ float tile[32][33];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int r = r0 + ty + 8 * i, c = c0 + tx;
-        tile[ty + 8 * i][tx] = (r < rows && c < cols) ? load_as_f32(src, kind, (size_t)r * ld_src + c) : 0.f;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int c = c0 + ty + 8 * i, r = r0 + tx;
-        if (c < cols && r < rpad) store16(dst, dkind, (size_t)c * rpad + r, tile[tx][ty + 8 * i]);
-    }
-}
-
 // All 4 GEMM weights of all layers in ONE launch: w16_bwd[l][m] = transpose(params[l][m]) in the gradient path's 16-bit
 // type.  The fp32 weights of a layer are contiguous in the order qkv [3d,d], out [d,d], fc [4d,d], proj [d,4d] (12 d^2
 // floats) and the 16-bit pack uses the same offsets; grid = (32 x 32 tiles of one layer = 12 d^2 / 1024, layers).
@@ -395,103 +375,6 @@ __global__ __launch_bounds__(256) void ln_param_reduce_kernel(LnReduceArgs a) {
     }
 }
 
-// dbias[n] += sum_r dy[r][n]; thread owns 4 columns, waves/blocks split rows
-__global__ __launch_bounds__(256) void colsum_kernel(const u16* __restrict__ dy, int gkind, const float* __restrict__ gscale,
-                                                     int ld, int rows, int n, float* __restrict__ dbias) {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int c = (blockIdx.x * 64 + lane) * 4;
-    if (c >= n) return;
-    float a[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int r = blockIdx.y * 4 + wid; r < rows; r += gridDim.y * 4) {
-        float v[4];
-        unpack4k(gkind, *(const uint2*)(dy + (size_t)r * ld + c), v);
-        a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) atomicAdd(dbias + c + e, a[e] * gscale[1]);
-}
-
-// ---------------------------------------------------------------- attention backward (one block per seq x head)
-constexpr int HD = 64, HP = 65;
-
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const u16* __restrict__ qkv, int qkv_f16,
-                                                       const u16* __restrict__ dO, u16* __restrict__ dqkv, int gkind,
-                                                       RowMap map, int heads, int d) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int n = blockIdx.x / heads, h = blockIdx.x % heads;
-    const int ctx = seq_len(map, map.s0 + n);
-    float* sq = (float*)smem;            // [ctx][HP]
-    float* sk = sq + ctx * HP;
-    float* sv = sk + ctx * HP;
-    float* sdo = sv + ctx * HP;
-    float* sp = sdo + ctx * HP;          // [ctx][ctx+1]  P
-    float* sds = sp + ctx * (ctx + 1);   // [ctx][ctx+1]  dS
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int ld = 3 * d, PS = ctx + 1;
-    const size_t row0 = (size_t)seq_row(map, map.s0 + n);
-    for (int idx = tid; idx < ctx * HD; idx += 256) {
-        const int r = idx >> 6, c = idx & 63;
-        const size_t o = (row0 + r) * ld + h * HD + c;
-        sq[r * HP + c] = load_as_f32(qkv, qkv_f16 ? 1 : 0, o);
-        sk[r * HP + c] = load_as_f32(qkv, qkv_f16 ? 1 : 0, o + d);
-        sv[r * HP + c] = load_as_f32(qkv, qkv_f16 ? 1 : 0, o + 2 * d);
-        sdo[r * HP + c] = load_as_f32(dO, gkind, (row0 + r) * d + h * HD + c);
-    }
-    __syncthreads();
-    // P rows (softmax of causal scores) and dS rows, one wave per query row
-    for (int i = wid; i < ctx; i += 4) {
-        float sc[2], dp[2];
-        float m = -INFINITY;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int j = lane + 64 * t;
-            float s = -INFINITY, dpv = 0.f;
-            if (j <= i && j < ctx) {
-                s = 0.f;
-                for (int c = 0; c < HD; ++c) {
-                    s = fmaf(sq[i * HP + c], sk[j * HP + c], s);
-                    dpv = fmaf(sdo[i * HP + c], sv[j * HP + c], dpv);
-                }
-                s *= 0.125f;
-            }
-            sc[t] = s; dp[t] = dpv;
-            m = fmaxf(m, s);
-        }
-        m = wave_max(m);
-        float sum = 0.f;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) { sc[t] = __expf(sc[t] - m); sum += sc[t]; }
-        sum = wave_sum(sum);
-        const float inv = 1.0f / sum;
-        float rd = 0.f;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) { sc[t] *= inv; rd = fmaf(sc[t], dp[t], rd); }
-        rd = wave_sum(rd);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int j = lane + 64 * t;
-            if (j < ctx) {
-                sp[i * PS + j] = sc[t];
-                sds[i * PS + j] = sc[t] * (dp[t] - rd) * 0.125f;
-            }
-        }
-    }
-    __syncthreads();
-    for (int idx = tid; idx < ctx * HD; idx += 256) {
-        const int r = idx >> 6, c = idx & 63;
-        float dq = 0.f, dk = 0.f, dv = 0.f;
-        for (int j = 0; j <= r; ++j) dq = fmaf(sds[r * PS + j], sk[j * HP + c], dq);
-        for (int i = r; i < ctx; ++i) {
-            dk = fmaf(sds[i * PS + r], sq[i * HP + c], dk);
-            dv = fmaf(sp[i * PS + r], sdo[i * HP + c], dv);
-        }
-        const size_t o = (row0 + r) * ld + h * HD + c;
-        store16(dqkv, gkind, o, dq);
-        store16(dqkv, gkind, o + d, dk);
-        store16(dqkv, gkind, o + 2 * d, dv);
-    }
-}
-
 // dpos[p][:] += sum_n dx[n*ctx+p][:]   (grid = ctx) ; dtok via atomics (grid-stride over rows)
 __global__ __launch_bounds__(256) void pos_bwd_kernel(const float* __restrict__ dx, const float* __restrict__ gscale,
                                                       float* __restrict__ dpos, int n_seq, RowMap map, int d) {
@@ -709,13 +592,6 @@ hipError_t leaf_launch_pgd_step(float* delta, const float* grad, int n_seq, RowM
     return hipGetLastError();
 }
 
-hipError_t leaf_launch_transpose16(const void* src, int src_kind, void* dst, int dst_kind, int rows, int cols, int ld_src,
-                                   int rpad, hipStream_t s) {
-    dim3 grid((cols + 31) / 32, (rpad + 31) / 32);
-    hipLaunchKernelGGL(transpose16_kernel, grid, dim3(256), 0, s, src, src_kind, dst, dst_kind, rows, cols, ld_src, rpad);
-    return hipGetLastError();
-}
-
 hipError_t leaf_launch_pack_transpose(const float* src, void* dst, int dst_kind, int d, int layers, hipStream_t s) {
     if (d % 32 || layers < 1) return hipErrorInvalidValue;
     hipLaunchKernelGGL(pack_transpose_kernel, dim3(12 * (d / 32) * (d / 32), layers), dim3(256), 0, s, src, dst, dst_kind, d);
@@ -804,39 +680,13 @@ hipError_t leaf_launch_ln_param_reduce(const LnReduceArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t leaf_launch_colsum(const void* dy16, int gkind, const float* gscale, int ld, int rows, int n, float* dbias,
-                              hipStream_t s) {
-    if (n % 4 || ld % 4) return hipErrorInvalidValue;
-    int ry = (rows + 63) / 64;
-    if (ry > 64) ry = 64;
-    if (ry < 1) ry = 1;
-    hipLaunchKernelGGL(colsum_kernel, dim3((n + 255) / 256, ry), dim3(256), 0, s, (const u16*)dy16, gkind, gscale, ld,
-                       rows, n, dbias);
-    return hipGetLastError();
-}
-
 hipError_t leaf_launch_attention_bwd(const void* qkv, int qkv_dtype, const void* dout16, void* dqkv16, int gkind,
                                      int n_seq, RowMap map, int heads, int d, hipStream_t s) {
-    const int ctx = map.ctx;
-    // LEAF_ATTN_BWD=0 selects the fp32 VALU kernel below (the first implementation, kept for A/B and ctx 97..128);
-    // default is the MFMA kernel of attention_bwd.hip
-    static int use_mfma = -1;
-    if (use_mfma < 0) { const char* e = getenv("LEAF_ATTN_BWD"); use_mfma = (e && e[0] == '0') ? 0 : 1; }
-    if (use_mfma && ctx <= 96 && !map.prefix)
-        return leaf_launch_attention_bwd_mfma(qkv, qkv_dtype, dout16, dqkv16, gkind, n_seq, map, heads, d, s);
-    if (d != heads * HD || ctx > 128) return hipErrorInvalidValue;
-    size_t lds = ((size_t)4 * ctx * HP + (size_t)2 * ctx * (ctx + 1)) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3(n_seq * heads), dim3(256), lds, s, (const u16*)qkv,
-                       qkv_dtype == LEAF_F16 ? 1 : 0, (const u16*)dout16, (u16*)dqkv16, gkind, map, heads, d);
-    return hipGetLastError();
+    // the MFMA kernel of attention_bwd.hip (ctx <= 96, no cached prefix: what the training pass runs).  The round-1 fp32 VALU
+    // kernel that used to stand behind LEAF_ATTN_BWD=0 is gone (round 4: nothing shipped ever dispatched it)
+    if (map.ctx > 96 || map.prefix) return hipErrorInvalidValue;
+    return leaf_launch_attention_bwd_mfma(qkv, qkv_dtype, dout16, dqkv16, gkind, n_seq, map, heads, d, s);
 }
-
 hipError_t leaf_launch_sat_check16(const void* const* bufs, const size_t* numel, int n, float* scaler, float* poison, hipStream_t s) {
     if (n < 1 || n > 5 || !scaler || !poison) return hipErrorInvalidValue;
     SatArgs a{};

@@ -25,9 +25,9 @@
 // test_lnfold_rows_do_not_depend_on_the_kernel).
 #include <type_traits>
 
-#include "common.h"
-#include "kernels.h"
-#include "lnfold.h"
+#include "../common.h"
+#include "../kernels.h"
+#include "../lnfold.h"
 
 namespace {
 

@@ -147,7 +147,9 @@ def test_train_cli_normalize_fare_and_grad_clip(tmp_path, monkeypatch):
 
 
 def test_train_cli_two_ranks_under_torch_distributed_run(tmp_path):
-    """The trainer itself at world size 2: `python -m torch.distributed.run --nproc-per-node 2 train_AT_text_only.py
+    """(The "--" in front of the script: torch.distributed.run's argparse rejects a script flag that is an ambiguous prefix of its
+    own options -- the reference's --logs is one of --logs-specs / --logs_specs -- unless everything behind it is positional.)
+    The trainer itself at world size 2: `python -m torch.distributed.run --nproc-per-node 2 train_AT_text_only.py
     --dist-backend gloo` with both ranks on this box's one GPU (RCCL needs a device per rank: the driver's scaling run), two epochs,
     --constrain and --accum-freq 2.  One checkpoint, the replicas' weights identical after every epoch (the CLI all-gathers a
     checksum), different captions and different search randomness per rank (seed + rank: train_AT_text_only.py:60-63,281), and a
@@ -171,7 +173,7 @@ def test_train_cli_two_ranks_under_torch_distributed_run(tmp_path):
         env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
         env["LEAF_DEBUG_DUMP_ADV"] = str(dump)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-               "--master-port", str(port), os.path.join(root, "train_AT_text_only.py"), "--dist-backend", "gloo",
+               "--master-port", str(port), "--", os.path.join(root, "train_AT_text_only.py"), "--dist-backend", "gloo",
                "--model", "tiny-test-quickgelu", "--dataset-type", "synthetic", "--train-num-samples", "64", "--batch-size", "8",
                "--accum-freq", "2", "--lr", "1e-4", "--wd", "1e-4", "--warmup", "2", "--rho", "6", "--k_adv", "1", "--seed", "5",
                "--epochs", "2", "--constrain", "--dictionary-file", str(words), "--dictionary-tokenizer", "treebank",

@@ -9,18 +9,20 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+VARIANTS_LIB = os.path.join(ROOT, "tools", "diag", "libleaf_hip_variants.so")   # make -C leaf_amd/csrc variants (__graft_entry__.build())
+
 VARIANTS = [
     {"LEAF_GEMM256H": "0"},                          # two-stage 256^2 + register-staged kernels instead of the half-stage ring
     {"LEAF_GEMM64_DEEP": "1", "LEAF_GEMM64_MI": "2"},  # 6-slot small-launch ring
     {"LEAF_GEMM64": "0", "LEAF_GEMM_BM64": "1"},     # register-staged 64-row tiles
-    {"LEAF_GEMM_PP": "1", "LEAF_GEMM_PP_MIN_TILES": "32"},   # 128 x 256 tiles, two workgroups per CU (gemm128pp.hip: kept, not dispatched)
+    {"LEAF_GEMM_PP": "1", "LEAF_GEMM_PP_MIN_TILES": "32"},   # 128 x 256 tiles, two workgroups per CU (variants/gemm128pp.hip: diagnostic build only)
 ]
 
 
 def test_pingpong_gemm_rows_have_the_same_bits_as_every_other_kernel():
-    """gemm128pp.hip (the round-3 two-workgroups-per-CU experiment, LEAF_GEMM_PP=1) through the bit-exactness tests of the GEMM
+    """variants/gemm128pp.hip (the round-3 two-workgroups-per-CU experiment, LEAF_GEMM_PP=1) through the bit-exactness tests of the GEMM
     family: big launch (ping-pong kernel) against chunked launches (small-launch kernels), all epilogues incl. the LN-folded ones."""
-    full = dict(os.environ, LEAF_GEMM_PP="1", LEAF_GEMM_PP_MIN_TILES="64")
+    full = dict(os.environ, LEAF_GEMM_PP="1", LEAF_GEMM_PP_MIN_TILES="64", LEAF_HIP_LIB=VARIANTS_LIB)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_kernels.py"), "-x", "-q", "-k",
                         "rows_do_not_depend or lnfold"], env=full, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
@@ -30,6 +32,8 @@ def test_pingpong_gemm_rows_have_the_same_bits_as_every_other_kernel():
 def test_gemm_variant(env):
     full = dict(os.environ)
     full.update(env)
+    if "LEAF_GEMM_PP" in env:
+        full["LEAF_HIP_LIB"] = VARIANTS_LIB      # the ping-pong kernel exists only in the diagnostic build
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_gemm_variant.py")], env=full, cwd=ROOT,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

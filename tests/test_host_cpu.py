@@ -63,6 +63,15 @@ def test_c_abi_exports_every_declared_symbol():
         assert hasattr(l, name), f"{name} declared in include/leaf_hip.h but not exported"
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     assert l.leaf_version() >= 1
+    # the product library carries no experiment and no diagnostic export: those live in the builds under
+    # tools/diag/ (include/leaf_hip_diag.h, leaf_amd/csrc/variants/)
+    import subprocess
+    syms = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (leaf_[A-Za-z0-9_]+)", syms))
+    assert exported == declared, exported ^ declared
+    assert "gemm128pp" not in syms and "leaf_debug" not in syms
+    diag = open(os.path.join(ROOT, "include", "leaf_hip_diag.h")).read()
+    assert set(re.findall(r"\b(leaf_debug_[a-z0-9_]+)\s*\(", diag)) == set(_lib.DIAG_SIGS)
 
 
 def test_handle_layout_and_errors_without_gpu():
@@ -255,20 +264,23 @@ def test_host_text_under_sanitizers(tmp_path):
 
 
 def test_fused_qkv_attention_tile_plan_properties():
-    """The host-side cut into M tiles (leaf_qkv_attn_plan, through its test hook): whole sequences, <= 256 rows, <= 3 captions."""
+    """The host-side cut into M tiles (leaf_qkv_attn_plan, through its test hook): whole sequences, <= tile_rows rows, <= ncap captions."""
     import ctypes as C
     from leaf_amd import _lib
-    lib = _lib.lib()
+    lib = _lib.diag_lib()           # a diagnostic export (include/leaf_hip_diag.h): tools/diag/libleaf_hip_variants.so
     rng = np.random.default_rng(0)
     for trial in range(20):
         B, rho = int(rng.integers(1, 40)), int(rng.integers(1, 60))
         goff = B if trial % 2 else 0
         lens = np.concatenate([rng.integers(2, 78, goff), rng.integers(1, 78 if trial % 3 else 3, B * rho)]).astype(np.int32)
-        out = np.zeros(lens.size + 2, dtype=np.int32)
-        nt = lib.leaf_debug_qkv_attn_plan(lens.ctypes.data_as(C.c_void_p), 77, 0, lens.size, 1, rho, goff, out.ctypes.data_as(C.c_void_p))
-        cut = out[: nt + 1]
+        out = np.zeros(2 * (lens.size + 2), dtype=np.int32)
+        tile_rows, ncap = (256, 3) if trial % 4 < 2 else (128, 1 + trial % 3)
+        nt = lib.leaf_debug_qkv_attn_plan(lens.ctypes.data_as(C.c_void_p), 77, 0, lens.size, 1, rho, goff, tile_rows, ncap,
+                                          out.ctypes.data_as(C.c_void_p))
+        cut, row0 = out[0:2 * (nt + 1):2], out[1:2 * (nt + 1):2]
+        assert (row0 == np.concatenate([[0], np.cumsum(lens)])[cut]).all()
         assert cut[0] == 0 and cut[-1] == lens.size and (np.diff(cut) > 0).all()
         for a, b in zip(cut[:-1], cut[1:]):
-            assert lens[a:b].sum() <= 256
+            assert lens[a:b].sum() <= tile_rows
             caps = [(s - goff) // rho for s in range(a, b) if s >= goff]
-            assert not caps or caps[-1] - caps[0] < 3
+            assert not caps or caps[-1] - caps[0] < ncap

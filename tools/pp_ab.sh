@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B of the ping-pong GEMM (gemm128pp.hip, LEAF_GEMM_PP=1) against the 256 x 256 half-stage kernel on one box:
 # the four GEMM shapes of a ViT-L block alone (tools/gemm_bench.py), then alternating bench.py runs.
+export LEAF_HIP_LIB=$PWD/tools/diag/libleaf_hip_variants.so   # the ping-pong kernel lives in the diagnostic build only (make -C leaf_amd/csrc variants)
 for pp in 0 1 0 1; do echo "== gemm_bench LEAF_GEMM_PP=$pp"; LEAF_GEMM_PP=$pp SEQS=${SEQS:-1200} timeout -k 10 120 python tools/gemm_bench.py || exit 1; done
 for pp in 0 1 0 1; do
   echo "== bench.py LEAF_GEMM_PP=$pp"

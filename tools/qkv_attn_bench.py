@@ -49,7 +49,7 @@ def main():
         rowstat = torch.stack([x16.float().mean(1), 1.0 / x16.float().std(1)], 1).contiguous()
         out = torch.zeros(rows, d, device=dev, dtype=torch.float16)
         cu_d, pfx_d, bcu_d = (torch.from_numpy(v).to(dev) for v in (cu, pfx, base_cu))
-        tile_seq = torch.zeros(n + 2, dtype=torch.int32, device=dev)
+        tile_seq = torch.zeros(2 * (n + 2), dtype=torch.int32, device=dev)
         P = lambda t: C.c_void_p(t.data_ptr())
         args = (1, P(x16), P(Wp), P(cvec), P(svec), P(rowstat), P(out), P(kv), C.c_void_p(lens.ctypes.data), P(cu_d), P(pfx_d), P(bcu_d),
                 None, P(tile_seq), n, rows, rho, 77, heads, d, st)
@@ -62,9 +62,9 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / a.iters
-        plan = np.zeros(n + 2, np.int32)
-        nt = lib.leaf_debug_qkv_attn_plan(C.c_void_p(lens.ctypes.data), 77, 0, n, 1, rho, 0, C.c_void_p(plan.ctypes.data))
-        per_tile = np.diff(plan[:nt + 1])
+        plan = np.zeros(2 * (n + 2), np.int32)
+        nt = _lib.diag_lib().leaf_debug_qkv_attn_plan(C.c_void_p(lens.ctypes.data), 77, 0, n, 1, rho, 0, 0, 0, C.c_void_p(plan.ctypes.data))
+        per_tile = np.diff(plan[0:2 * (nt + 1):2])
         fl = 2.0 * rows * 3 * d * d
         print(f"stage {stage}: {n} sequences, {rows} rows ({rows / n:.1f} per sequence), {nt} M tiles ({rows / nt:.0f} rows, {per_tile.mean():.1f} "
               f"sequences each, max {per_tile.max()}) x {heads} heads: {ms:.3f} ms, {fl / ms / 1e9:.0f} TFLOP/s of projection work", flush=True)
@@ -79,7 +79,7 @@ def main():
             seg = np.diff(s, axis=1)
             tot = s[:, 5] - s[:, 0]
             names = ["first DMA wait", "K loop", "tables + caption DMA issue + staging", "wait for DMA / barrier", "attention"]
-            print(f"   median workgroup {np.median(tot):.0f} ticks; kernel span {(s[:, 5].max() - s[:, 0].min()):.0f} ticks for {nblk / 256:.1f} rounds")
+            print(f"   median workgroup {np.median(tot):.0f} ticks ({nblk} workgroups)")
             for i, nm in enumerate(names):
                 print(f"   {nm:40s} median {np.median(seg[:, i]):8.0f}  mean {seg[:, i].mean():8.0f}  ({100 * seg[:, i].sum() / tot.sum():5.1f}%)")
 

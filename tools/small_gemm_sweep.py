@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Which GEMM kernel should take the B-caption launches (3-13k rows)?  Times the layer's GEMM shapes through the C-ABI hooks
-with the half-stage 256^2 ring kernel forced on (min tiles 1) and off (min tiles 10^9 -> 64 x 128 ring / two-stage kernels)."""
+with the half-stage 256^2 ring kernel forced on (min tiles 1) and off (min tiles 10^9 -> 64 x 128 ring / two-stage kernels).
+Needs the diagnostic build for leaf_debug_gemm_min_tiles: LEAF_HIP_LIB=tools/diag/libleaf_hip_variants.so (make -C leaf_amd/csrc variants)."""
 import ctypes as C
 import os
 import sys

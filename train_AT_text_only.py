@@ -6,7 +6,7 @@
     python3 train_AT_text_only.py --model hf-hub:chs20/fare2-clip --pretrained /path/to/open_clip_pytorch_model.bin \
         --train-data 'shards/{00000000..00001287}.tar' --dataset-type webdataset --train-num-samples 80000 \
         --batch-size 128 --lr 1e-5 --wd 1e-4 --warmup 1400 --epochs 30 --k_adv 1 --rho 50 --constrain --seed 1
-    python3 -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train_AT_text_only.py ...   # RCCL DP
+    python3 -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -- train_AT_text_only.py ...   # RCCL DP ("--": --logs is an ambiguous prefix of torchrun's own --logs-specs)
 
 Differences from the reference, all outside the hot path: downstream evaluation (ImageNet / AG-News zero-shot,
 utils_AT.py:428-556) is not run; ``hf-hub:`` ids select the architecture but weights come from ``--pretrained``
