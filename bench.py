@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS_16BIT = 2500.0  # MI355X dense bf16/fp16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_HBM_GBS = 8000.0       # HBM3E spec peak (same table; ~6.3 TB/s achievable)
-TRAFFIC_FILE = "r03_traffic.json"   # PMC summary of the dominant kernel (tools/pmc_passes.sh, tools/pmc_summary.py)
+TRAFFIC_FILE = "r04_traffic.json"   # PMC summary of the dominant kernel (tools/pmc_passes.sh, tools/pmc_summary.py)
 FAMILY = {0: "gemm_nt_kernel", 1: "gemm_nt256_kernel", 4: "gemm_nt256_half_kernel", 6: "gemm_nt64_ring_kernel", 7: "gemm_nt128pp_kernel",
           8: "qkv_attn_kernel"}
 EPI_NAMES = {0: "store16", 1: "act16", 2: "resid32", 3: "store32", 4: "actgrad16", 5: "lnfold16", 6: "lnfold_act16", 7: "resid32+x16+stats"}
@@ -47,7 +47,7 @@ def kernel_sources_hash():
     """sha256 over the GEMM kernel sources: a traffic summary under profiles/ is only attached to a line produced by the
     same kernels."""
     h = hashlib.sha256()
-    for f in ("gemm256h.hip", "gemm64.hip", "gemm.hip", "gemm_epilogue.h", "common.h"):
+    for f in ("gemm256h.hip", "gemm64.hip", "gemm.hip", "qkv_attn.hip", "gemm_epilogue.h", "common.h"):
         p = os.path.join(ROOT, "leaf_amd", "csrc", f)
         if os.path.exists(p):
             with open(p, "rb") as fh:
@@ -60,16 +60,30 @@ def fwd_flops_per_seq(cfg, L=77):
     return cfg.layers * (24 * cfg.width ** 2 * L + 4 * L * L * cfg.width)
 
 
-def cpu_baseline(model_name, rho, k, b_cpu, seed, budget_s):
-    """Plain PyTorch-CPU fp32 harness (own code, oracle/torch_cpu_harness.py) of the same step, dense, all usable cores."""
+def cpu_baseline(model_name, rho, k, b_cpu, seed, budget_s, gpu_encode=None):
+    """Plain PyTorch-CPU fp32 harness (own code, oracle/torch_cpu_harness.py) of the same step, dense, all usable cores.
+    ``gpu_encode`` (tokens -> features of the benchmark's start weights on the GPU): the same captions' embeddings are compared
+    with the harness's fp32 ones, so that every performance line carries its accuracy (``parity_rel_l2``; the oracle is the
+    checker here, outside the timed region)."""
+    import numpy as np
     from oracle import text_oracle as O
     from oracle import torch_cpu_harness as H
     cfg = O.CONFIGS[model_name]
     w = O.init_weights(cfg, seed=1)
     base = O.synthetic_tokens(b_cpu, seed=seed)
+    parity = None
+    if gpu_encode is not None:
+        import torch
+        with torch.no_grad():
+            ref = H.TorchTextTower(w, cfg).encode_text(torch.from_numpy(base.astype(np.int64))).numpy()
+        got = gpu_encode(base)
+        rows = np.linalg.norm(got - ref, axis=1) / np.linalg.norm(ref, axis=1)
+        parity = {"captions": int(b_cpu), "global": float(np.linalg.norm(got - ref) / np.linalg.norm(ref)), "row_max": float(rows.max()),
+                  "row_median": float(np.median(rows)), "tolerance": 1e-3,
+                  "against": "plain PyTorch CPU fp32 forward of the same start weights (oracle/torch_cpu_harness.py)"}
     r = H.time_step(w, cfg, base, lambda cur, rho_, s, pos: O.synthetic_candidates(cur, rho_, s, fixed_pos=pos), rho, k,
                     budget_s=budget_s)
-    return {"value": r["samples_per_s"], "unit": "samples/s", "cores": r["cores"], "kind": "port",
+    return {"value": r["samples_per_s"], "unit": "samples/s", "cores": r["cores"], "kind": "port", "parity_rel_l2": parity,
             "impl": "own harness: plain PyTorch CPU fp32 (torch.nn.functional ops), dense 77-row sequences",
             "sample": (f"BASELINE.json configs[0] shape: one step on B={b_cpu} captions, rho={rho}, k={k}: anchor + "
                        f"{r['total_candidate_forwards']} candidate forwards ({r['measured_candidate_forwards']} measured at "
@@ -317,6 +331,7 @@ def main():
         shapes, per_key = [], {}
         for i in range(n_out.value):
             key, N, K, cnt = info[4 * i], info[4 * i + 1], info[4 * i + 2], info[4 * i + 3]
+            big, key = key >= 256, key % 256          # launches of >= 16,384 rows (the scoring passes) are grouped apart
             if ms[i] <= 0:
                 continue
             kname = f"{FAMILY.get(key // 16, 'gemm?')}<{'F16' if (key // 8) % 2 == 1 else 'BF16'},{key % 8}>"
@@ -325,10 +340,10 @@ def main():
             # which roofline bounds this shape: algorithmic FLOP per algorithmic byte against the machine balance
             intensity = fl[i] / by[i]
             bound = "hbm" if intensity < PEAK_TFLOPS_16BIT * 1e12 / (PEAK_HBM_GBS * 1e9) * 0.5 else "mfma"
-            shapes.append({"kernel": kname, "epilogue": EPI_NAMES.get(key % 8), "N": N, "K": K, "launches": cnt,
+            shapes.append({"kernel": kname, "epilogue": EPI_NAMES.get(key % 8), "N": N, "K": K, "launches": cnt, "big_launches": big,
                            "rows_per_launch": rows[i] / cnt, "ms_per_step": ms[i] / args.steps, "tflops": tf,
                            "mfma_frac": tf / PEAK_TFLOPS_16BIT, "algorithmic_gbs": gbs, "hbm_frac": gbs / PEAK_HBM_GBS,
-                           "flop_per_byte": intensity, "bound": bound})
+                           "flop_per_byte": intensity, "bound": bound, "algorithmic_bytes_per_launch": by[i] / cnt})
             a = per_key.setdefault(key, [0.0, 0.0, 0.0, 0])
             a[0] += ms[i]; a[1] += fl[i]; a[2] += by[i]; a[3] += cnt
         shapes.sort(key=lambda s: -s["ms_per_step"])
@@ -343,12 +358,14 @@ def main():
         # optional embedding-space PGD mode k x (fwd + input-gradient bwd ~ 1 + 1) on top of anchor + start fwd + train bwd
         flops_per_sample = (2 * args.rho * args.k_adv + 4) * F if args.attack == "leaf" else (2 * args.k_adv + 4) * F
         value = B * world * args.steps / dt
-        traffic, traffic_note = None, "no PMC summary under profiles/ for this kernel build"
+        traffic, traffic_note, traffic_kernels = None, "no PMC summary under profiles/ for this kernel build", None
         try:    # HBM bytes per launch of the dominant kernel from the committed PMC passes; only for the build they were taken on
             with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)) as f:
                 tj = json.load(f)
             default_cfg = not args.dense and not args.no_prefix_reuse and args.model == "ViT-L-14-quickgelu" and B == 128 \
                 and args.k_adv == 1 and args.attack == "leaf"
+            if tj.get("kernel_sources_sha16") == kernel_sources_hash() and default_cfg:
+                traffic_kernels = tj.get("kernels")        # every big kernel: measured bytes / algorithmic bytes of the PMC run itself
             if tj.get("kernel") == dom_name and tj.get("kernel_sources_sha16") == kernel_sources_hash() and default_cfg:
                 traffic = tj["traffic_bytes_per_launch"]
                 traffic_note = ("HBM bytes per launch, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) * 1024, separate passes, "
@@ -382,14 +399,14 @@ def main():
                        "parallelism": f"dp{world}", "candidate_forwards_per_step_per_gpu": 2 * args.rho * args.k_adv * B},
             "roofline": {
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS_16BIT, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_TFLOPS_16BIT, "traffic": traffic, "traffic_note": traffic_note,
+                "frac": achieved / PEAK_TFLOPS_16BIT, "traffic": traffic, "traffic_note": traffic_note, "traffic_kernels": traffic_kernels,
                 "kernel": f"{dom_name} {EPI_NAMES.get(dom_key % 8)}",
                 "algorithmic_bytes_per_launch": dom_bytes / dom_cnt if dom_bytes else None,
                 "launches": int(dom_cnt), "avg_launch_ms": dom_ms / dom_cnt,
                 "algorithmic_gflop_per_launch": dom_fl / dom_cnt / 1e9,
                 "all_gemm_tflops": gemm_total_fl / (gemm_total_ms * 1e-3) / 1e12,
                 "gemm_share_of_step": gemm_total_ms * 1e-3 / dt,
-                "shapes": shapes[:12],
+                "shapes": shapes[:16],
             },
             "step_exec_frac": gemm_total_fl / dt / (PEAK_TFLOPS_16BIT * 1e12),
             **step_trend(step_marks),
@@ -419,7 +436,10 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and args.attack == "leaf":
             oracle_name = args.model if args.model in ("ViT-L-14", "ViT-L-14-quickgelu", "ViT-H-14", "ViT-g-14", "ViT-bigG-14") else "ViT-L-14"
-            out["cpu_baseline"] = cpu_baseline(oracle_name, args.rho, args.k_adv, args.cpu_batch, seed=1234, budget_s=args.cpu_budget_s)
+            same_weights = oracle_name == args.model          # the frozen model still holds the seed-1 start weights
+            out["cpu_baseline"] = cpu_baseline(oracle_name, args.rho, args.k_adv, args.cpu_batch, seed=1234, budget_s=args.cpu_budget_s,
+                                               gpu_encode=(lambda t: frozen.encode_text(t).cpu().numpy()) if same_weights else None)
+            out["parity_rel_l2"] = out["cpu_baseline"].pop("parity_rel_l2")
         print(json.dumps(out), flush=True)
         if os.environ.get("LEAF_BENCH_JSON_OUT"):     # the PMC passes keep the line of THEIR run (tools/pmc_passes.sh): own algorithmic bytes
             with open(os.environ["LEAF_BENCH_JSON_OUT"], "w") as f:

@@ -253,7 +253,7 @@ extern "C" int leaf_prof_end(double* ms, double* flops, double* bytes, int64_t* 
 
 // Same as leaf_prof_end but grouped by (key, N, K) -- one line per GEMM SHAPE of each kernel, so that e.g. the two
 // residual GEMMs (out_proj: N = K = d, HBM-bound; c_proj: K = 4d, MFMA-bound) are reported separately.  info[i] =
-// {key, N, K, launches}; rows[i] = sum of M over the launches.  Returns the number of groups in *n_out (<= max_groups).
+// {key (+ 256 for launches of >= 16,384 rows), N, K, launches}; rows[i] = sum of M over the launches.  Returns the number of groups in *n_out (<= max_groups).
 extern "C" int leaf_prof_end_shapes(double* ms, double* flops, double* bytes, int64_t* rows, int32_t* info, int max_groups,
                                     int* n_out) {
     g_prof_on = false;
@@ -262,12 +262,15 @@ extern "C" int leaf_prof_end_shapes(double* ms, double* flops, double* bytes, in
         LEAF_TRY(hipEventSynchronize(r.b));
         float t = 0.f;
         LEAF_TRY(hipEventElapsedTime(&t, r.a, r.b));
+        // launches of >= 16,384 rows (the scoring passes) and the small B-caption launches of the same kernel and shape are
+        // reported apart: group key = key + 256 for the big ones
+        const int gkey = r.key + (r.M >= 16384 ? 256 : 0);
         int i = 0;
         for (; i < n; ++i)
-            if (info[4 * i] == r.key && info[4 * i + 1] == r.N && info[4 * i + 2] == r.K) break;
+            if (info[4 * i] == gkey && info[4 * i + 1] == r.N && info[4 * i + 2] == r.K) break;
         if (i == n) {
             if (n == max_groups) continue;
-            info[4 * n] = r.key; info[4 * n + 1] = r.N; info[4 * n + 2] = r.K; info[4 * n + 3] = 0;
+            info[4 * n] = gkey; info[4 * n + 1] = r.N; info[4 * n + 2] = r.K; info[4 * n + 3] = 0;
             ms[n] = 0; flops[n] = 0; bytes[n] = 0; rows[n] = 0;
             ++n;
         }

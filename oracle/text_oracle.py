@@ -167,20 +167,44 @@ def _act_grad(cfg, x):
 Round = Optional[Callable[[np.ndarray], np.ndarray]]
 
 
-def _mm(a, b_t, rnd: Round):
+class RoundPolicy:
+    """Operand rounding that depends on WHERE a value is used: ``default`` everywhere except the (layer, site, what) triples
+    ``exact`` answers True for -- site in {"qkv", "attn", "out", "fc", "proj", "final"}, what in {"a" (activation operand),
+    "w" (weight operand), "out" (a stored 16-bit result: q|k|v, probabilities, attention output, hidden activations)}.
+    Used by tests/test_precision_budget.py to attribute the 16-bit forward's error to layers and sites and to price targeted
+    spends (a site kept in fp32 / split into hi + lo halves behaves as exact here)."""
+
+    def __init__(self, default, exact=lambda layer, site, what: False):
+        self.default, self.exact = default, exact
+
+    def pick(self, layer, site, what):
+        return None if self.exact(layer, site, what) else self.default
+
+
+def _r(rnd, layer, site, what):
+    """the rounding function in force at (layer, site, what): a plain callable applies everywhere"""
+    if rnd is None:
+        return None
+    return rnd.pick(layer, site, what) if isinstance(rnd, RoundPolicy) else rnd
+
+
+def _mm(a, b_t, rnd: Round, layer=-1, site=""):
     """a[M,K] @ b_t[N,K]^T with optional operand rounding (emulates 16-bit MFMA inputs,
     fp32 accumulate).  rnd=None is the fp32 oracle."""
-    if rnd is not None:
-        a, b_t = rnd(a), rnd(b_t)
+    ra, rw = _r(rnd, layer, site, "a"), _r(rnd, layer, site, "w")
+    if ra is not None:
+        a = ra(a)
+    if rw is not None:
+        b_t = rw(b_t)
     return (a @ b_t.T).astype(F32)
 
 
-def _mha(cfg, xn, wqkv, bqkv, wo, bo, rnd: Round, stash=None):
+def _mha(cfg, xn, wqkv, bqkv, wo, bo, rnd: Round, stash=None, layer=-1):
     N, L, d = xn.shape
     H, hd = cfg.heads, cfg.head_dim
-    qkv = _mm(xn.reshape(N * L, d), wqkv, rnd) + bqkv
-    if rnd is not None:
-        qkv = rnd(qkv)
+    qkv = _mm(xn.reshape(N * L, d), wqkv, rnd, layer, "qkv") + bqkv
+    if _r(rnd, layer, "qkv", "out") is not None:
+        qkv = _r(rnd, layer, "qkv", "out")(qkv)
     qkv = qkv.reshape(N, L, 3, H, hd)
     q = qkv[:, :, 0].transpose(0, 2, 1, 3)  # [N,H,L,hd]
     k = qkv[:, :, 1].transpose(0, 2, 1, 3)
@@ -191,13 +215,14 @@ def _mha(cfg, xn, wqkv, bqkv, wo, bo, rnd: Round, stash=None):
     s = s - s.max(-1, keepdims=True)
     p = np.exp(s)
     p = (p / p.sum(-1, keepdims=True)).astype(F32)
-    pv = rnd(p) if rnd is not None else p
+    rp = _r(rnd, layer, "attn", "out")
+    pv = rp(p) if rp is not None else p
     o = np.matmul(pv, v).transpose(0, 2, 1, 3).reshape(N * L, d).astype(F32)
-    if rnd is not None:
-        o = rnd(o)
+    if rp is not None:
+        o = rp(o)
     if stash is not None:
         stash["q"], stash["k"], stash["v"], stash["p"], stash["o"] = q, k, v, p, o
-    return (_mm(o, wo, rnd) + bo).reshape(N, L, d)
+    return (_mm(o, wo, rnd, layer, "out") + bo).reshape(N, L, d)
 
 
 def encode_text(w: Dict[str, np.ndarray], cfg: TextCfg, tokens: np.ndarray, normalize: bool = False,
@@ -218,14 +243,14 @@ def encode_text(w: Dict[str, np.ndarray], cfg: TextCfg, tokens: np.ndarray, norm
         st = {} if stash is not None else None
         xn, mu1, rs1 = layer_norm(x, w[p + "ln_1.weight"], w[p + "ln_1.bias"], cfg.eps)
         a = _mha(cfg, xn, w[p + "attn.in_proj_weight"], w[p + "attn.in_proj_bias"],
-                 w[p + "attn.out_proj.weight"], w[p + "attn.out_proj.bias"], rnd, st)
+                 w[p + "attn.out_proj.weight"], w[p + "attn.out_proj.bias"], rnd, st, layer=i)
         x1 = (x + a).astype(F32)
         xn2, mu2, rs2 = layer_norm(x1, w[p + "ln_2.weight"], w[p + "ln_2.bias"], cfg.eps)
-        pre = _mm(xn2.reshape(N * L, d), w[p + "mlp.c_fc.weight"], rnd) + w[p + "mlp.c_fc.bias"]
+        pre = _mm(xn2.reshape(N * L, d), w[p + "mlp.c_fc.weight"], rnd, i, "fc") + w[p + "mlp.c_fc.bias"]
         h = act(pre)
-        if rnd is not None:
-            h = rnd(h)
-        m = _mm(h, w[p + "mlp.c_proj.weight"], rnd) + w[p + "mlp.c_proj.bias"]
+        if _r(rnd, i, "fc", "out") is not None:
+            h = _r(rnd, i, "fc", "out")(h)
+        m = _mm(h, w[p + "mlp.c_proj.weight"], rnd, i, "proj") + w[p + "mlp.c_proj.bias"]
         x2 = (x1 + m.reshape(N, L, d)).astype(F32)
         if stash is not None:
             st.update(x0=x, xn1=xn, mu1=mu1, rs1=rs1, x1=x1, xn2=xn2, mu2=mu2, rs2=rs2, pre=pre, h=h)
@@ -234,7 +259,7 @@ def encode_text(w: Dict[str, np.ndarray], cfg: TextCfg, tokens: np.ndarray, norm
     xf, muf, rsf = layer_norm(x, w["ln_final.weight"], w["ln_final.bias"], cfg.eps)
     eot = tokens.argmax(-1)
     pooled = xf[np.arange(N), eot]
-    out = _mm(pooled, np.ascontiguousarray(w["text_projection"].T), rnd)
+    out = _mm(pooled, np.ascontiguousarray(w["text_projection"].T), rnd, cfg.layers, "final")
     if stash is not None:
         stash.append(dict(x=x, muf=muf, rsf=rsf, eot=eot, pooled=pooled, out=out))
     if normalize:

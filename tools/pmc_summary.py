@@ -56,16 +56,37 @@ def main():
     fe, wr = per_kernel(fd, "FETCH_SIZE"), per_kernel(wd, "WRITE_SIZE")
     write_csv(out + "_pmc_fetch.csv", fe, "FETCH_SIZE")
     write_csv(out + "_pmc_write.csv", wr, "WRITE_SIZE")
-    gemms = {k: v for k, v in fe.items() if "gemm_nt" in k and (want is None or want in k)}
-    k = max(gemms, key=lambda x: gemms[x][0])
-    fkb, wkb = fe[k][0] / fe[k][1], wr[k][0] / wr[k][1]
+    gemms = {k: v for k, v in fe.items() if ("gemm_nt" in k or "qkv_attn" in k) and (want is None or want in k)}
     from bench import kernel_sources_hash
-    algo = None
+    algo, bj = None, None
     if bench_json and os.path.exists(bench_json):
         bj = json.load(open(bench_json))
-        if bj["roofline"]["kernel"].split(" ")[0] == short(k):
-            algo = bj["roofline"]["algorithmic_bytes_per_launch"]
+    # the kernel the bench line names as dominant (largest summed time), else the one with the largest summed fetch
+    dom = bj["roofline"]["kernel"].split(" ")[0] if bj else None
+    named = [k for k in gemms if short(k) == dom]
+    k = named[0] if named else max(gemms, key=lambda x: gemms[x][0])
+    fkb, wkb = fe[k][0] / fe[k][1], wr[k][0] / wr[k][1]
+    if bj and dom == short(k):
+        algo = bj["roofline"]["algorithmic_bytes_per_launch"]
     traffic = (2 * fkb + wkb) * 1024
+    # every big kernel of the step beside it: measured bytes per launch against the algorithmic bytes of the SAME run (mean over
+    # the kernel's shapes, weighted by launches), and what of it was fetched from beyond L2
+    kernels = []
+    if bj:
+        per = defaultdict(lambda: [0.0, 0])
+        for sh in bj["roofline"]["shapes"]:
+            if sh.get("algorithmic_bytes_per_launch") and sh.get("big_launches"):
+                per[sh["kernel"]][0] += sh["algorithmic_bytes_per_launch"] * sh["launches"]
+                per[sh["kernel"]][1] += sh["launches"]
+        for kk in gemms:
+            nm = short(kk) if "qkv_attn" not in kk else "qkv_attn_kernel<%s,5>" % ("F16" if "F16" in kk else "BF16")
+            big_disp = fe[kk][0] / fe[kk][1] > 100 * 1024            # > 100 MB fetched per dispatch: the scoring passes' launches
+            if nm in per and per[nm][1] and big_disp:
+                f_, w_ = fe[kk][0] / fe[kk][1] * 1024, wr[kk][0] / wr[kk][1] * 1024
+                a_ = per[nm][0] / per[nm][1]
+                kernels.append({"kernel": nm, "dispatches": fe[kk][1], "fetch_bytes_per_launch": 2 * f_, "write_bytes_per_launch": w_,
+                                "algorithmic_bytes_per_launch": a_, "traffic_over_algorithmic": (2 * f_ + w_) / a_})
+        kernels.sort(key=lambda r: -r["fetch_bytes_per_launch"] * r["dispatches"])
     json.dump({
         "kernel": short(k),
         "kernel_sources_sha16": kernel_sources_hash(),   # bench.py attaches this summary only to lines from the same kernel sources
@@ -76,6 +97,7 @@ def main():
         "traffic_bytes_per_launch": traffic,
         "algorithmic_bytes_per_launch": algo,      # of the SAME run (bench.py's line of the FETCH pass), or null
         "traffic_over_algorithmic": traffic / algo if algo else None,
+        "kernels": kernels,
     }, open(out + "_traffic.json", "w"), indent=1)
     print(short(k), "fetch KB", fkb, "write KB", wkb, "traffic B/launch", (2 * fkb + wkb) * 1024)
 

@@ -35,12 +35,29 @@ json.dump({"abbrev_types": ["dr", "mr", "mrs", "st", "e.g", "i.e", "vs", "inc", 
            "sent_starters": ["the", "a"], "ortho_context": {"the": 34, "a": 50}}, open("/tmp/leaf_trainer_bench/punkt.json", "w"))
 PY
 ROOT=$PWD
+# fourth run: the same captions as DataComp-style webdataset shards (per sample a ~60-KB dummy .jpg, the .txt, a .json), read by the
+# header-scanning tar reader on the loader's background thread: "Load (t)" in the log line is what the step waited for a batch
+python - <<'PY'
+import sys
+sys.path.insert(0, "tools")
+import io, os, random, tarfile
+caps = open("/tmp/leaf_trainer_bench/captions.txt").read().split("\n")
+os.makedirs("/tmp/leaf_trainer_bench/shards", exist_ok=True)
+blob = os.urandom(60 * 1024)
+per = 1920
+for s in range(len(caps) // per):
+    with tarfile.open(f"/tmp/leaf_trainer_bench/shards/{s:08d}.tar", "w", format=tarfile.USTAR_FORMAT) as tf:
+        for i, c in enumerate(caps[s * per:(s + 1) * per]):
+            for ext, data in ((".jpg", blob), (".txt", c.encode()), (".json", b'{"width": 512}')):
+                ti = tarfile.TarInfo(f"{s:05d}{i:05d}{ext}"); ti.size = len(data); tf.addfile(ti, io.BytesIO(data))
+PY
 i=0
 for c in "" "--constrain --dictionary-file $W/words.txt" \
-         "--constrain --dictionary-file $W/words.txt --dictionary-tokenizer treebank --punkt-params $W/punkt.json --dataset-type text --train-data $W/captions.txt"; do
+         "--constrain --dictionary-file $W/words.txt --dictionary-tokenizer treebank --punkt-params $W/punkt.json --dataset-type text --train-data $W/captions.txt" \
+         "--constrain --dictionary-file $W/words.txt --dictionary-tokenizer treebank --punkt-params $W/punkt.json --dataset-type webdataset --train-data $W/shards/{00000000..00000003}.tar --workers 8"; do
   i=$((i + 1)); name=run$i
   (cd $W && timeout -k 10 400 python $ROOT/train_AT_text_only.py --model ViT-L-14-quickgelu --random-init --dataset-type synthetic \
      --train-num-samples 7680 --batch-size 128 --epochs 1 --rho 50 --k_adv 1 --lr 1e-5 --wd 1e-4 --warmup 10 --log-every-n-steps 10 \
      --save-frequency 0 --seed 1 --custom_out_folder b_ --logs $W/logs --name $name $c > $OUT/$name.log 2>&1)
-  echo "== ${c:-unconstrained}"; grep -o "Batch (t): [0-9.]*, [0-9.]*/s" $OUT/$name.log | tail -4
+  echo "== ${c:-unconstrained}"; grep -o "Data (t): [0-9.]* Batch (t): [0-9.]*, [0-9.]*/s\|Load (t): [0-9.]*" $OUT/$name.log | paste - - | tail -4
 done
