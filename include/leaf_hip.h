@@ -5,7 +5,8 @@
  *   - plain C symbols, `int` status (0 = ok), message via leaf_last_error(); no exceptions cross the ABI;
  *   - the library allocates NO caller-visible device memory: the caller (PyTorch) owns parameters,
  *     gradients, optimizer state, activations and workspace and passes raw device pointers + a hipStream_t;
- *   - every call is asynchronous on the given stream; a handle is host-only state, not thread-safe;
+ *   - every call is asynchronous on the given stream; a handle is host-only state, not thread-safe (it owns one small ring of
+ *     PINNED HOST buffers for the tile plans of the fused QKV + attention launches, freed by leaf_text_destroy);
  *   - tokens are int32 [n_seq, ctx] row-major, pad id 0, EOT = row maximum (open_clip tokenizer.py:256-263).
  *
  * Parameter buffer: ONE flat fp32 array (leaf_text_param_count floats).  Tensors that receive weight
