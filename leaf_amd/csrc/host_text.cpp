@@ -14,6 +14,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <pthread.h>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -245,9 +246,31 @@ private:
     bool stop_ = false;
 };
 
+// One pool per PROCESS, created on first use and never destroyed.  Never destroyed: a joining destructor at exit / dlclose can hang
+// when the interpreter tears the process down while a worker is inside a job, and idle workers own nothing that needs cleaning up.
+// Per process: after fork() the child inherits the pool OBJECT but none of its threads (and its locks in whatever state another
+// thread of the parent left them), so run() would wait for workers that do not exist; the atfork child handler abandons the
+// inherited object -- it is not destroyed: std::thread's destructor would terminate on the phantom joinable threads -- and the
+// child's first parallel call builds a pool of its own.
+std::atomic<WorkerPool*> g_pool{nullptr};
+std::atomic_flag g_pool_lock = ATOMIC_FLAG_INIT;
+void pool_after_fork_in_child() {
+    g_pool.store(nullptr, std::memory_order_relaxed);
+    g_pool_lock.clear();
+}
 WorkerPool& pool() {
-    static WorkerPool p;
-    return p;
+    WorkerPool* p = g_pool.load(std::memory_order_acquire);
+    if (p) return *p;
+    while (g_pool_lock.test_and_set(std::memory_order_acquire)) std::this_thread::yield();
+    p = g_pool.load(std::memory_order_relaxed);
+    if (!p) {
+        static bool registered = false;
+        if (!registered) { pthread_atfork(nullptr, nullptr, pool_after_fork_in_child); registered = true; }
+        p = new WorkerPool();
+        g_pool.store(p, std::memory_order_release);
+    }
+    g_pool_lock.clear(std::memory_order_release);
+    return *p;
 }
 
 template <class F>

@@ -324,16 +324,16 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QkvAttnArgs p) {
         const int row_s = sq & 511, len = (sq >> 9) & 127, pfx = (sq >> 16) & 127, slot = (sq >> 23) & 3;
         const int ctx = pfx + len;
         const int eot = p.eot_pos ? (int)*(const unsigned char*)(smem + EOT_OFF + si) : -1;
-        const char* capK = smem + CAP_OFF + 2 * slot * cap_img;
-        const char* capV = capK + cap_img;
         const int ntl = (ctx + 15) >> 4;
         const int qt0 = eot >= 0 ? eot >> 4 : pfx >> 4;
         const int qt1 = eot >= 0 ? eot >> 4 : ntl - 1;
         // position pos of this sequence -> its K (or Q) row image, chunk-swizzled by the row's index inside that image
+        // (byte offsets and selects, no pointers from two bases: the compiler turned those into exec-masked branches)
+        const int capK_off = CAP_OFF + 2 * slot * cap_img, capV_off = capK_off + cap_img;
         auto krow = [&](int pos, int chunk) -> const char* {
-            if (pos < pfx) return capK + pos * 128 + ((chunk ^ (pos & 7)) << 4);
-            const int r = row_s + pos - pfx;
-            return smem + HALF + r * 128 + ((chunk ^ (r & 7)) << 4);
+            const bool inp = pos < pfx;
+            const int r = inp ? pos : row_s + pos - pfx;
+            return smem + (inp ? capK_off : HALF) + r * 128 + ((chunk ^ (r & 7)) << 4);
         };
         typename TT::vec8 kf[MAXT][2];
 #pragma unroll
@@ -393,22 +393,22 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QkvAttnArgs p) {
                         // dims dim0 + 4 pp .. + 3; keys beyond the sequence read the zero line (P is zero there; 0 x anything must stay +0)
                         const int q4 = r16 >> 2, pp = r16 & 3;
                         const int pos = kt * 16 + 4 * g + q4;
-                        const char* vrow;
-                        int vr;
-                        if (pos >= ctx) { vrow = smem + ZERO_OFF; vr = 0; }
-                        else if (pos < pfx) { vrow = capV + pos * 128; vr = pos; }
-                        else { vr = row_s + pos - pfx; vrow = smem + 2 * HALF + vr * 128; }
+                        const bool past = pos >= ctx, inp = pos < pfx;
+                        const int vr = past ? 0 : (inp ? pos : row_s + pos - pfx);                  // row inside its image (0: the zero line)
+                        const int vbase = (past ? ZERO_OFF : (inp ? capV_off : 2 * HALF) + vr * 128) + (pp & 1) * 8;
+                        const int vsw = past ? 0 : vswz(vr);                                         // (any chunk of the zero line is zero)
 #pragma unroll
                         for (int dt = 0; dt < 4; ++dt) {
                             typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-                            const int chunk = (pos >= ctx) ? (2 * dt + (pp >> 1)) & 7 : ((2 * dt + (pp >> 1)) ^ vswz(vr));
-                            const s16x4 vf = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vrow + (chunk << 4) + (pp & 1) * 8));
+                            const int chunk = (2 * dt + (pp >> 1)) ^ vsw;
+                            const s16x4 vf = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(smem + vbase + (chunk << 4)));
                             o[dt] = TT::mfma16(vf, pf, o[dt]);
                         }
                     }
                 }
                 if (eot >= 0 ? qidx == eot : (qidx < ctx && qidx >= pfx)) {
-                    u16* op = (u16*)p.out + (eot >= 0 ? (size_t)(s_b + si) : (size_t)r0 + row_s + qidx - pfx) * d + h * HD + 4 * g;
+                    // (32-bit element offset: rows * d * 2 B < 4 GiB is checked by the launcher)
+                    u16* op = (u16*)p.out + (unsigned)((eot >= 0 ? s_b + si : r0 + row_s + qidx - pfx) * d + h * HD + 4 * g);
 #pragma unroll
                     for (int dt = 0; dt < 4; ++dt)
                         *(uint2*)(op + dt * 16) = pack4_bounded<TT>(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);

@@ -284,3 +284,26 @@ def test_fused_qkv_attention_tile_plan_properties():
             assert lens[a:b].sum() <= tile_rows
             caps = [(s - goff) // rho for s in range(a, b) if s >= goff]
             assert not caps or caps[-1] - caps[0] < ncap
+
+
+def test_native_tokenizer_survives_fork():
+    """the persistent worker pool of host_text.cpp is per process -- a forked child (a DataLoader worker, multiprocessing)
+    inherits the pool object but none of its threads and used to wait for them for ever; now its first parallel call builds a
+    pool of its own, and the parent's keeps working."""
+    import multiprocessing as mp
+    from leaf_amd.native_text import NativeTokenizer
+    texts = [f"a photo of cat number {i} on the wet street" for i in range(400)]
+    tok = NativeTokenizer(n_threads=4)
+    want = tok.encode_batch(texts)                 # starts the parent's workers
+
+    def child(q):
+        q.put(NativeTokenizer(n_threads=4).encode_batch(texts).tobytes() == want.tobytes() and tok.encode_batch(texts).tobytes() == want.tobytes())
+
+    ctx = mp.get_context("fork")
+    q = ctx.Queue()
+    p = ctx.Process(target=child, args=(q,))
+    p.start()
+    ok = q.get(timeout=60)
+    p.join(timeout=30)
+    assert ok and p.exitcode == 0
+    assert tok.encode_batch(texts).tobytes() == want.tobytes()
