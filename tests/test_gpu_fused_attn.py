@@ -117,3 +117,47 @@ def test_fused_qkv_attention_dense_rows_trim_off_and_one_row_sequences(torch_mod
     pl = _prefix_lens(cand, base)
     g, h = _both(m, lambda: m.score_candidates(flat, anchor, rho, "l2", want_loss=True, seq_lens=clens, prefix_lens=pl, kv=kv))
     _eq(torch_mod, g, h, "one-row sequences")
+
+
+@pytest.mark.parametrize("model,B", [("ViT-H-14", 10), ("ViT-bigG-14", 8)])
+def test_fused_qkv_attention_other_towers(torch_mod, model, B):
+    """d = 1024 / 1280 (16 / 20 heads, K loops of 16 / 20 tiles, erf-GELU towers): packed rows and prefix reuse, fused against the two
+    kernels, bit for bit."""
+    m = _model(model, 2)
+    rho = 50
+    base = O.synthetic_tokens(B, seed=91, min_len=10, max_len=50)
+    cand = O.synthetic_candidates(base, rho, seed=92)
+    flat = cand.reshape(-1, 77)
+    lens = np.repeat(base.argmax(-1) + 1, rho)
+    assert lens.sum() // 256 * m.cfg.heads >= 256        # the fused launch engages
+    anchor = m.encode_text(base) + 0.2
+    a, b = _both(m, lambda: m.score_candidates(flat, anchor, rho, "l2", want_loss=True, seq_lens=lens))
+    _eq(torch_mod, a, b, "packed rows")
+    kv = m.encode_text_kv(base)
+    pl = _prefix_lens(cand, base)
+    c, d = _both(m, lambda: m.score_candidates(flat, anchor, rho, "l2", want_loss=True, seq_lens=lens, prefix_lens=pl, kv=kv))
+    _eq(torch_mod, c, d, "prefix reuse")
+    _eq(torch_mod, a, c, "prefix reuse against full recomputation")
+
+
+def test_fused_qkv_attention_long_captions_one_caption_per_tile(torch_mod):
+    """Captions of up to 77 tokens: the caption images take 80 rows each (three per tile still fit), prefixes of up to 75 positions,
+    and with short suffixes many sequences per tile."""
+    m = _model("ViT-L-14-quickgelu", 4)
+    B, rho = 24, 50
+    base = O.synthetic_tokens(B, seed=93, min_len=60, max_len=75)
+    bl = base.argmax(-1) + 1
+    cand = np.repeat(base[:, None, :], rho, axis=1)
+    rng = np.random.default_rng(7)
+    for bi in range(B):
+        for r in range(rho):
+            cand[bi, r, int(rng.integers(max(1, bl[bi] - 12), bl[bi] - 1))] = int(rng.integers(1, 49405))    # late edits: long prefixes
+    flat = cand.reshape(-1, 77)
+    lens = np.repeat(bl, rho)
+    anchor = m.encode_text(base) + 0.1
+    kv = m.encode_text_kv(base)
+    pl = _prefix_lens(cand, base)
+    a, b = _both(m, lambda: m.score_candidates(flat, anchor, rho, "l2", want_loss=True, seq_lens=lens, prefix_lens=pl, kv=kv))
+    _eq(torch_mod, a, b, "long prefixes")
+    full = m.score_candidates(flat, anchor, rho, "l2", want_loss=True, seq_lens=lens)
+    _eq(torch_mod, a, full, "long prefixes against full recomputation")
