@@ -326,8 +326,12 @@ int leaf_gemm_family(const GemmArgs& p, int epi) {
     if (use256h < 0) { const char* e = getenv("LEAF_GEMM256H"); use256h = (e && e[0] == '0') ? 0 : 1; }
 #ifdef LEAF_VARIANTS         // diagnostic builds only (make variants): the round-3 two-workgroups-per-CU experiment, never in libleaf_hip.so
     static int use_pp = -1;    // LEAF_GEMM_PP=1: the two-workgroups-per-CU 128 x 256 kernel (variants/gemm128pp.hip) takes the big launches
-    if (use_pp < 0) { const char* e = getenv("LEAF_GEMM_PP"); use_pp = (e && e[0] == '1') ? 1 : 0; }
-    if (use_pp && p.M > 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && leaf_gemm128pp_eligible(p, epi)) return 7;
+    if (use_pp < 0) { const char* e = getenv("LEAF_GEMM_PP"); use_pp = (e && (e[0] == '1' || e[0] == '2')) ? 1 : 0; }
+    // LEAF_GEMM_PP=2: only the HBM-bound residual shape (out_proj: N = K = d), where the ping-pong kernel measured 5-9 % faster alone
+    static int pp_mode = -1;
+    if (pp_mode < 0) { const char* e = getenv("LEAF_GEMM_PP"); pp_mode = e ? atoi(e) : 0; }
+    const bool pp_shape = pp_mode != 2 || (p.N == p.K && (epi == EPI_RESID_LN || epi == EPI_RESID_F32));
+    if (use_pp && pp_shape && p.M > 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && leaf_gemm128pp_eligible(p, epi)) return 7;
 #endif
     if (use256h && p.M > 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && leaf_gemm256h_eligible(p, epi)) return 4;
     static int use256 = -1;
