@@ -13,8 +13,14 @@
 // LDS by LDS-DMA (once per tile instead of once per candidate), and then its eight waves run attn_fwd_kernel's MFMA body per
 // sequence with every operand out of LDS.  Only the attention output (2d bytes per row) is written.
 //
-// LDS map (160 KiB): [0, 96 K) ring slots 0-2 = Q | K | V staging, 256 rows x 128 B each (after the K loop); [96 K, 156 K) three
-// caption images (K rows then V rows, 80 x 128 B each); [156 K, 160 K) row statistics, sequence table, a zero line.
+// LDS map (160 KiB): [0, 96 K) ring slots 0-2 = Q | K | V staging, 256 rows x 128 B each (after the K loop); [96 K, 156 K) up to
+// three caption images (K rows then V rows, caprows x 128 B each; caprows = the launch's longest sequence rounded up to 16, <= 80);
+// [156 K, 160 K) row statistics, sequence table, a zero line.
+//
+// What was tried and not kept: 128-row tiles with two 4-wave workgroups per CU (operand traffic of a
+// 128 x 192 tile exceeds what a CU takes in from L2; slower), attention work dealt per (sequence, query tile) through an LDS-atomic
+// list (the stage is instruction bound, not idle; slower), a persistent form (no LDS left to prefetch the next tile into while the
+// attention stage holds Q | K | V and the caption images).
 #include "common.h"
 #include "kernels.h"
 #include "lnfold.h"

@@ -161,3 +161,35 @@ def test_fused_qkv_attention_long_captions_one_caption_per_tile(torch_mod):
     _eq(torch_mod, a, b, "long prefixes")
     full = m.score_candidates(flat, anchor, rho, "l2", want_loss=True, seq_lens=lens)
     _eq(torch_mod, a, full, "long prefixes against full recomputation")
+
+
+def test_scoring_passes_take_the_fused_launch(torch_mod):
+    """No silent fall-back: in the benchmark's shape every transformer block of a scoring stage is ONE qkv_attn launch (profiler
+    family 8) and neither a stand-alone LN-folded QKV GEMM nor an attention launch of its own; with the option off the GEMM is back."""
+    import ctypes as C
+    from leaf_amd import _lib
+    lib = _lib.lib()
+    m = _model("ViT-L-14-quickgelu", 1)
+    B, rho = 32, 50
+    base = O.synthetic_tokens(B, seed=95, min_len=8, max_len=40)
+    cand = O.synthetic_candidates(base, rho, seed=96)
+    flat = cand.reshape(-1, 77)
+    lens = np.repeat(base.argmax(-1) + 1, rho)
+    anchor = m.encode_text(base)
+    kv = m.encode_text_kv(base)
+    pl = _prefix_lens(cand, base)
+
+    def families():
+        lib.leaf_prof_begin()
+        m.score_candidates(flat, anchor, rho, "l2", seq_lens=lens, prefix_lens=pl, kv=kv)
+        ng = 64
+        ms, fl, by = (C.c_double * ng)(), (C.c_double * ng)(), (C.c_double * ng)()
+        rows, info, n = (C.c_int64 * ng)(), (C.c_int32 * (4 * ng))(), C.c_int(0)
+        _lib.check(lib.leaf_prof_end_shapes(ms, fl, by, rows, info, ng, C.byref(n)), "prof")
+        return {((info[4 * i] % 256) // 16, info[4 * i] % 8, info[4 * i + 1]): info[4 * i + 3] for i in range(n.value)}
+    on = families()
+    assert on.get((8, 5, 3 * 768)) == m.cfg.layers and not any(f != 8 and e == 5 and N == 3 * 768 for (f, e, N) in on), on
+    m.set_option("fuse_attn", 0)
+    off = families()
+    m.set_option("fuse_attn", 1)
+    assert (8, 5, 3 * 768) not in off and off.get((4, 5, 3 * 768)) == m.cfg.layers, off

@@ -169,3 +169,15 @@ def test_vitl_grad_fixture(golden_dir):
             assert rel_l2(flat[_sample_index(flat.size)], z["s:" + k]) < 2e-4, k
     rows = z["tok_rows"].astype(np.int64)
     assert rel_l2(g["token_embedding.weight"][rows], z["g_tok_rows"].astype(np.float32)) < 1e-3   # fixture rows stored in fp16
+
+
+def test_round_policy_default_equals_a_plain_rounding_callable():
+    """oracle.RoundPolicy with nothing exempted is the plain operand-rounding emulation (the site plumbing changed no arithmetic), and
+    exempting every site is the fp32 oracle."""
+    cfg = O.TextCfg(128, 2, 2, 64, quick_gelu=True)
+    w = O.init_weights(cfg, seed=12)
+    toks = O.synthetic_tokens(5, seed=3)
+    plain = O.encode_text(w, cfg, toks, rnd=O.round_fp16)
+    assert np.array_equal(plain, O.encode_text(w, cfg, toks, rnd=O.RoundPolicy(O.round_fp16)))
+    assert np.array_equal(O.encode_text(w, cfg, toks), O.encode_text(w, cfg, toks, rnd=O.RoundPolicy(O.round_fp16, lambda l, s, wh: True)))
+    assert not np.array_equal(plain, O.encode_text(w, cfg, toks))
