@@ -290,15 +290,22 @@ def train_step_tokens(model, frozen, base: torch.Tensor, cfg: StepConfig, seed: 
     still queued on the current stream and the anchor of step i+1 overlaps the tail of step i; without it the side
     stream waits for everything queued so far (always safe)."""
     model.eval()
-    # The frozen model's anchor forward and the trained model's clean-caption K/V pass are independent B-sequence passes
-    # (grids that fill about half the chip each): the anchor runs on a side stream and the search waits for it right
-    # before its first scoring call.
+    # The frozen model's anchor forward depends on nothing but the captions and the FROZEN weights: it runs on a side stream and the
+    # search waits for it right before its first scoring call.  The side stream also waits for the PREVIOUS step's search
+    # (LEAF_ANCHOR_AT=tail, the default): the host runs a stage ahead of the device, and without that ordering the anchor's ~85 small
+    # launches land in the middle of the previous step's second stage, beside its big persistent GEMMs, instead of beside that
+    # step's training pass (small launches, AdamW).  Round 4, same-box A/B (profiles/r04_anchor_ab.txt): 50.41 against 50.54 ms per
+    # step; queueing the NEXT step's anchor into the hole at the stage boundary, where the device waits for the host to read the
+    # winners, was tried too and is slower (50.9: it then runs beside the start of stage 2).  LEAF_ANCHOR_AT=free: no ordering.
     cur = torch.cuda.current_stream()
     side = _side_stream(base.device)
     if base_ready is not None:
         side.wait_event(base_ready)
     else:
         side.wait_stream(cur)
+    prev = getattr(model, "_search_done", None)
+    if prev is not None and os.environ.get("LEAF_ANCHOR_AT", "tail") == "tail":
+        side.wait_event(prev)
     with torch.cuda.stream(side):
         anchor = frozen.encode_text(base, seq_lens=base_lens)
         ready = torch.cuda.Event()
@@ -315,6 +322,9 @@ def train_step_tokens(model, frozen, base: torch.Tensor, cfg: StepConfig, seed: 
     else:
         adv = search_synthetic(model, anchor, base, cfg, seed, base_lens=base_lens, prefix_reuse=prefix_reuse,
                                anchor_ready=ready)
+        done = torch.cuda.Event()
+        done.record(cur)
+        model._search_done = done
         model.train()
         feat = model.forward_train(adv, seq_lens=base_lens)
     if micro_index % cfg.accum_freq == 0:
