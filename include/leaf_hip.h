@@ -199,6 +199,14 @@ int leaf_adamw_step_clip(float* params, const float* grads, float* exp_avg, floa
                          float lr, float beta1, float beta2, float eps, float wd, int step, float grad_scale,
                          float max_norm, float* clip_ws, leaf_stream_t s);
 
+/* torch.nn.utils.clip_grad_norm_ IN PLACE, for --grad-clip-norm together with --accum-freq > 1 (utils_AT.py:348-357 clips the
+ * running gradient sum after every micro-batch's backward, not only before the step): grads <- grads * pre_scale *
+ * min(1, max_norm / (pre_scale * ||grads||_2 + 1e-6)).  pre_scale folds a pending factor into the same pass (data parallel: the
+ * replicated running sum is divided by the world size before the next micro-batch's local gradients are added and summed over
+ * ranks); max_norm = +inf only applies pre_scale.  A non-finite norm leaves the gradients untouched (the step's guard skips).
+ * ws: fp32 device scratch [2 + 2048]; ws[0] = the factor applied, ws[1] = the norm. */
+int leaf_clip_grads_inplace(float* grads, size_t n, float pre_scale, float max_norm, float* ws, leaf_stream_t s);
+
 /* ---- native host side of the search: CLIP BPE + single-edit mutation, multithreaded ----
  * leaf_tok_create takes the DECOMPRESSED text of bpe_simple_vocab_16e6.txt (src/open_clip/tokenizer.py:139-150).
  * Fast path = printable ASCII without '&'; other inputs are flagged in `fallback` (1 byte per text / per candidate)

@@ -65,6 +65,7 @@ _SIGS = {
     "leaf_textfare_backward_events": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
                                                 C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "leaf_clip_grads_inplace": (C.c_int, [C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "leaf_adamw_step_clip": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_float,
                                       C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float,
                                       C.c_void_p, C.c_void_p]),

@@ -302,6 +302,11 @@ extern "C" int leaf_adamw_step(float* params, const float* grads, float* exp_avg
                                         grad_scale, (hipStream_t)s), "adamw");
 }
 
+extern "C" int leaf_clip_grads_inplace(float* grads, size_t n, float pre_scale, float max_norm, float* ws, leaf_stream_t s) {
+    if (!grads || !ws || !(max_norm > 0.f) || !(pre_scale > 0.f)) { leaf_set_error("null/invalid argument"); return 1; }
+    return leaf_check(leaf_launch_clip_inplace(grads, n, pre_scale, max_norm, ws, (hipStream_t)s), "clip_grads_inplace");
+}
+
 extern "C" int leaf_adamw_step_clip(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n,
                                     size_t n_decay, float lr, float beta1, float beta2, float eps, float wd, int step,
                                     float grad_scale, float max_norm, float* clip_ws, leaf_stream_t s) {

@@ -78,6 +78,7 @@ struct QkvAttnArgs {
     const int32_t* tile_seq;  // [n_tiles + 1][2] (first sequence, first row), launch-relative, of every M tile (leaf_qkv_attn_plan)
     RowMap map;
     int M, K, lda, ldb, heads, d, n_tiles, n_seq, kv_ld;
+    int hsplit;               // head groups an M range is split into across XCDs (1 = an XCD runs all heads of its tiles)
     int ncap, caprows;        // caption images in LDS: how many, rows each (leaf_qkv_attn_lds_plan; the tile plan was cut for ncap)
     void* stamps;             // diagnostic builds only (-DLEAF_GEMM_STAMPS)
 };
@@ -202,6 +203,7 @@ hipError_t leaf_launch_attention_bwd(const void* qkv, int qkv_dtype, const void*
 // dtok[tokens[r],:] += dx[r,:] ; dpos[r % ctx,:] += dx[r,:]
 hipError_t leaf_launch_embed_bwd(const float* dx, const float* gscale, const int32_t* tokens, float* dtok, float* dpos,
                                  int rows, int n_seq, RowMap map, int d, int vocab, hipStream_t s);
+hipError_t leaf_launch_clip_inplace(float* g, size_t n, float pre_scale, float max_norm, float* ws, hipStream_t s);
 hipError_t leaf_launch_adamw(float* p, const float* g, float* m, float* v, size_t n, size_t n_decay, float lr,
                              float beta1, float beta2, float eps, float wd, int step, float grad_scale, hipStream_t s,
                              float max_norm = 0.f /* > 0: clip_grad_norm_ first */, float* clip_ws = nullptr /* [LEAF_SC_WORDS + 2048] fp32 */);

@@ -93,8 +93,24 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QkvAttnArgs p) {
     const int wm = wid >> 2, wn = wid & 3;
     // work item = (M tile, head); the heads of a tile are consecutive logical ids, an XCD owns a contiguous range: the tile's A
     // panel is fetched from beyond L2 once and shared by its 12-20 heads
-    const int logical = xcd_remap(blockIdx.x, p.n_tiles * p.heads);
-    const int tile = logical / p.heads, h = logical - tile * p.heads;
+    int tile, h;
+    if (p.hsplit <= 1) {
+        const int logical = xcd_remap(blockIdx.x, p.n_tiles * p.heads);
+        tile = logical / p.heads;
+        h = logical - tile * p.heads;
+    } else {
+        // head-split order: 8 / hsplit contiguous M ranges, each owned by hsplit XCDs that run heads / hsplit heads of every tile
+        // of the range -- an XCD's live weight panels shrink to heads / hsplit (ViT-L, 2: 1.8 MB of its 4-MiB L2) at the price
+        // of the A panel being fetched by hsplit XCDs
+        const int x = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int R = 8 / p.hsplit, r = x / p.hsplit, hg = x - r * p.hsplit, HG = p.heads / p.hsplit;
+        const int q = p.n_tiles / R, rem = p.n_tiles - q * R;
+        const int base = r * q + (r < rem ? r : rem), cnt = q + (r < rem ? 1 : 0);
+        const int t = slot / HG;
+        if (t >= cnt) return;
+        tile = base + t;
+        h = hg * HG + (slot - t * HG);
+    }
     // the weight panel of K tile 0 needs nothing but the head: on its way before the first scalar load has come back
     // (wave w moves pieces 3w..3w+2 of a B panel; B panel row r (0..191) = weight row (r / 64) * d + h * 64 + r % 64 of [q; k; v])
     unsigned b0, b1, b2;
@@ -494,7 +510,22 @@ hipError_t leaf_launch_qkv_attn(const QkvAttnArgs& a_in, int dtype, hipStream_t 
     if (a.n_tiles < 1 || a.heads < 1 || a.ncap < 1 || a.ncap > NCAP || a.caprows < 16 || a.caprows % 16 || a.caprows > CAPROWS ||
         2 * a.ncap * a.caprows * 128 > MISC_OFF - CAP_OFF || (unsigned long long)a.M * a.lda * 2ull >= (1ull << 32))
         return hipErrorInvalidValue;
-    const dim3 grid(a.n_tiles * a.heads), blk(512);
+    // head groups per M range: the fewest (1, 2, 4) that bring an XCD's live weight panels (heads / hsplit x 192 rows x K) under half
+    // of its 4-MiB L2 -- ViT-L 2 (1.8 MB; beyond-L2 fetches 911 -> 503 MB per launch, L2 hit rate 77 -> 86 %, launch -1.5 %:
+    // profiles/r04_fused_attn_hsplit.txt), ViT-H 4 (1.6 MB), bigG 4 (2.5 MB).  LEAF_QKVATTN_HSPLIT=1|2|4 overrides.
+    static const int hsplit_env = [] { const char* e = getenv("LEAF_QKVATTN_HSPLIT"); return e ? atoi(e) : 0; }();
+    a.hsplit = 1;
+    if (hsplit_env == 1 || ((hsplit_env == 2 || hsplit_env == 4) && a.heads % hsplit_env == 0)) {
+        a.hsplit = hsplit_env;
+    } else {
+        for (int hs = 1; hs <= 4; hs *= 2) {
+            if (a.heads % hs) break;
+            a.hsplit = hs;
+            if ((size_t)(a.heads / hs) * 192 * a.K * 2 <= (2u << 20)) break;
+        }
+    }
+    const int R = 8 / a.hsplit;
+    const dim3 grid(a.hsplit > 1 ? 8 * ((a.n_tiles + R - 1) / R) * (a.heads / a.hsplit) : a.n_tiles * a.heads), blk(512);
 #define LEAF_QA(TT)                                                                                                    \
     {                                                                                                                  \
         static bool attr = false;                                                                                      \

@@ -482,6 +482,35 @@ __global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict_
     }
 }
 
+// In-place form for gradient accumulation (utils_AT.py:348-357 with --accum-freq > 1: clip_grad_norm_ runs after EVERY micro-batch's
+// backward, on the running sum): coef[0] = pre * min(1, c / (pre * ||g|| + 1e-6)), 1 (gradients untouched) when the norm is not
+// finite -- the optimizer step's guard then skips the step as it would have without this call.
+__global__ __launch_bounds__(256) void clip_inplace_coef_kernel(const float* __restrict__ partial, int nb, float pre, float max_norm,
+                                                                float* __restrict__ coef) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nb; b += 256) s += (double)partial[b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float norm = pre * (float)sqrt((red[0] + red[1]) + (red[2] + red[3]));
+        const float c = max_norm / (norm + 1e-6f);
+        const bool finite = norm == norm && norm < 3.0e38f;
+        coef[0] = finite ? pre * (c < 1.f ? c : 1.f) : 1.f;
+        coef[1] = norm;
+    }
+}
+__global__ __launch_bounds__(256) void scale_inplace_kernel(float* __restrict__ g, size_t n4, const float* __restrict__ coef) {
+    const float c = coef[0];
+    if (c == 1.f) return;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 v = ((float4*)g)[i];
+        ((float4*)g)[i] = float4{v.x * c, v.y * c, v.z * c, v.w * c};
+    }
+}
+
 // Saturation check of the 16-bit gradient tensors of one transformer block (fp16 gradient path): a stored value of magnitude
 // >= 65504 (0x7BFF: the conversions saturate there; 0x7C00.. = inf / NaN) means the loss scale was too large for this step.
 // The reference's GradScaler finds that as an inf in the unscaled gradients; here the kernel raises scaler[LEAF_SC_SAT_FLAG] and
@@ -706,6 +735,16 @@ hipError_t leaf_launch_embed_bwd(const float* dx, const float* gscale, const int
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(tok_bwd_kernel, dim3(rows), dim3(256), 0, s, dx, gscale, tokens, dtok, rows, n_seq, map, d, vocab);
+    return hipGetLastError();
+}
+
+hipError_t leaf_launch_clip_inplace(float* g, size_t n, float pre_scale, float max_norm, float* ws, hipStream_t s) {
+    if (n % 4 || !ws) return hipErrorInvalidValue;
+    const size_t n4 = n / 4, nb = (n4 + 255) / 256;
+    const int pb = (int)(nb < 2048 ? nb : 2048);
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(pb), dim3(256), 0, s, g, n4, ws + 2);
+    hipLaunchKernelGGL(clip_inplace_coef_kernel, dim3(1), dim3(256), 0, s, ws + 2, pb, pre_scale, max_norm, ws);
+    hipLaunchKernelGGL(scale_inplace_kernel, dim3((unsigned)(nb < 16384 ? nb : 16384)), dim3(256), 0, s, g, n4, ws);
     return hipGetLastError();
 }
 

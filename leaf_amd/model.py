@@ -531,6 +531,17 @@ class LeafCLIPText:
                                                     ws.numel(), self._stream()), "leaf_textfare_backward")
         return loss
 
+    def clip_grads_(self, max_norm: Optional[float], pre_scale: float = 1.0) -> torch.Tensor:
+        """``torch.nn.utils.clip_grad_norm_`` on the accumulated gradient buffer, in place (utils_AT.py:348-357 with
+        --accum-freq > 1: the running sum is clipped after every micro-batch's backward).  ``pre_scale`` is applied in the same
+        pass; ``max_norm=None`` only applies it.  Returns the 0-d norm tensor (of pre_scale * grads, before clipping)."""
+        if getattr(self, "_clipi_ws", None) is None:
+            self._clipi_ws = torch.zeros(2 + 2048, dtype=torch.float32, device=self.device)
+        _lib.check(self._lib.leaf_clip_grads_inplace(_ptr(self.grads), self.n_params, float(pre_scale),
+                                                     float(max_norm) if max_norm is not None else float("inf"),
+                                                     _ptr(self._clipi_ws), self._stream()), "leaf_clip_grads_inplace")
+        return self._clipi_ws[1]
+
     def adamw_step(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
                    grad_scale: float = 1.0, max_norm: Optional[float] = None, guard: bool = True):
         """Fused AdamW over the flat buffers.  ``max_norm`` (--grad-clip-norm, utils_AT.py:348-357): clip the global L2

@@ -130,11 +130,13 @@ class LeafAdamW:
             {"params": excl, "weight_decay": 0.0, "lr": lr, "betas": tuple(betas), "eps": eps},
             {"params": rest, "weight_decay": weight_decay, "lr": lr, "betas": tuple(betas), "eps": eps}]
 
-    def step(self, max_norm=None):
+    def step(self, max_norm=None, reduced=False):
         """``max_norm``: --grad-clip-norm (utils_AT.py:348-357), applied to the all-reduced, averaged gradients like
-        clip_grad_norm_ on DDP-averaged .grad; returns the total norm (0-d tensor) when clipping."""
+        clip_grad_norm_ on DDP-averaged .grad; returns the total norm (0-d tensor) when clipping.  ``reduced``: the gradient
+        buffer already holds the clipped mean over ranks (micro-batch clipping, ``MicroClip`` below)."""
         g = self.param_groups[1]
-        scale = get_reducer(self.model).finish()   # waits for the bucketed reduction queued behind the backward (or runs the flat one)
+        # waits for the bucketed reduction queued behind the backward (or runs the flat one)
+        scale = 1.0 if reduced else get_reducer(self.model).finish()
         total = self.model.adamw_step(g["lr"], g["betas"], g["eps"], g["weight_decay"], grad_scale=scale, max_norm=max_norm)
         self.model.pack()
         return total
@@ -392,6 +394,43 @@ def get_text_data(args, epoch=0):
     return {"train": DataInfo(loader)}
 
 
+class MicroClip:
+    """--grad-clip-norm together with --accum-freq > 1 (utils_AT.py:348-357): the reference calls clip_grad_norm_ after EVERY
+    micro-batch's backward, i.e. on the running sum of the micro-batch gradients (under DDP: of their means over ranks, every
+    backward all-reduces).  With a GradScaler (--precision amp, train_AT_text_only.py:347) the second ``scaler.unscale_`` of an
+    optimizer step raises in torch -- that combination never trains in the reference, and ``check`` raises the same error.
+    Otherwise, per micro-batch j of an optimizer step, with G the replicated running sum (mean units):
+        G <- G / world (j > 0, data parallel only);  G += g_local / (accum * world);  all-reduce(sum);  G <- clip(G)
+    so that the optimizer step finds the gradient the reference's AdamW finds; one gradient reduction per MICRO-batch is what
+    these semantics cost (the default path reduces once per optimizer step)."""
+
+    def __init__(self, model, args):
+        self.model = unwrap_model(model)
+        self.max_norm = args.grad_clip_norm
+        self.accum = args.accum_freq
+        self.active = self.max_norm is not None and self.accum > 1
+
+    @staticmethod
+    def check(args, scaler=None):
+        if args.grad_clip_norm is not None and args.accum_freq > 1 and (scaler is not None or getattr(args, "precision", "amp") == "amp"):
+            raise RuntimeError("unscale_() has already been called on this optimizer since the last update().  (--grad-clip-norm "
+                               "with --accum-freq > 1 under --precision amp: the reference un-scales the gradients once per "
+                               "micro-batch, utils_AT.py:348-351, which torch.cuda.amp.GradScaler refuses; use amp_bf16)")
+
+    def backward(self, feat, anchor, micro: int):
+        from .step import _dp_active
+        import torch.distributed as dist
+        red = get_reducer(self.model)
+        world = dist.get_world_size() if _dp_active() else 1
+        if world > 1 and micro > 0:
+            self.model.clip_grads_(None, pre_scale=1.0 / world)
+        loss = red.backward(feat, anchor, accum_scale=1.0 / (self.accum * world), last_micro=True)
+        if world > 1:
+            red.finish()
+        self.model.clip_grads_(self.max_norm)
+        return loss
+
+
 # ----------------------------------------------------------------------------- the epoch loop
 def train_one_epoch_text_only(model, model_frozen, tokenizer, V, data, loss, epoch, optimizer, scaler, scheduler, args,
                               tb_writer=None):
@@ -400,6 +439,8 @@ def train_one_epoch_text_only(model, model_frozen, tokenizer, V, data, loss, epo
     if getattr(args, "horovod", False):
         raise NotImplementedError("horovod is not supported; launch with torch.distributed.run (RCCL)")
     normalize_fare = bool(getattr(args, "normalize_fare", False))   # utils_AT.py:296,319
+    MicroClip.check(args, scaler)
+    micro_clip = MicroClip(model, args)
     device = torch.device(args.device)
     model.train()
     data['train'].set_epoch(epoch)
@@ -453,15 +494,20 @@ def train_one_epoch_text_only(model, model_frozen, tokenizer, V, data, loss, epo
         model.train()
         feat = model.forward_train(adv_tokens, normalize=normalize_fare)
         data_time_m.update(time.time() - end)
-        loss_fare = get_reducer(model).backward(feat, anchor, accum_scale=1.0 / args.accum_freq,
-                                                last_micro=(i + 1) % args.accum_freq == 0)   # device scalar, no sync
+        if micro_clip.active:
+            loss_fare = micro_clip.backward(feat, anchor, i % args.accum_freq)                # device scalar, no sync
+        else:
+            loss_fare = get_reducer(model).backward(feat, anchor, accum_scale=1.0 / args.accum_freq,
+                                                    last_micro=(i + 1) % args.accum_freq == 0)
         for key in ("loss", "loss_FARE_text"):
             losses_accum[key] = losses_accum.get(key, 0) + loss_fare / args.accum_freq
         if (i + 1) % args.accum_freq == 0:
-            # --grad-clip-norm (utils_AT.py:348-357) is fused into the step.  The reference clips after EVERY micro-batch's
-            # backward (also when accum_freq > 1, i.e. the partial sums get clipped repeatedly); here the accumulated
-            # gradient is clipped once, right before the step.
-            optimizer.step(max_norm=args.grad_clip_norm)
+            # --grad-clip-norm (utils_AT.py:348-357): with one micro-batch per step the clip is fused into the AdamW kernel; with
+            # --accum-freq > 1 the running sum was clipped after every micro-batch's backward (MicroClip), the last one included
+            if micro_clip.active:
+                optimizer.step(max_norm=None, reduced=True)
+            else:
+                optimizer.step(max_norm=args.grad_clip_norm)
             optimizer.zero_grad()
         with torch.no_grad():
             unwrap_model(model).logit_scale.clamp_(0, math.log(100))

@@ -442,6 +442,21 @@ def clip_grad_norm(g: Dict[str, np.ndarray], max_norm: float) -> float:
     return total
 
 
+def accumulate_micro_clipped(w, cfg: TextCfg, micro_batches, max_norm: float, world_batches=None):
+    """--grad-clip-norm with --accum-freq > 1, no GradScaler (utils_AT.py:327-362): per micro-batch ``backward(loss / accum)``
+    into the running sum, then clip_grad_norm_ ON that sum.  ``micro_batches``: list of (tokens, anchor).  Returns (grads the
+    optimizer step sees, [total norm found at each micro-batch])."""
+    accum = len(micro_batches)
+    run: Dict[str, np.ndarray] = {}
+    norms = []
+    for toks, anchor in micro_batches:
+        _, _, g = encode_text_backward(w, cfg, toks, anchor, accum_scale=1.0 / accum)
+        for k, v in g.items():
+            run[k] = (run[k] + v).astype(F32) if k in run else v.astype(F32)
+        norms.append(clip_grad_norm(run, max_norm))
+    return run, norms
+
+
 def cosine_lr(base_lr: float, warmup: int, total_steps: int, step: int) -> float:
     """src/open_clip_train/scheduler.py:4-10,43-53."""
     if step < warmup:

@@ -144,6 +144,16 @@ def test_train_cli_normalize_fare_and_grad_clip(tmp_path, monkeypatch):
     hdr, vals = rows[0].split(","), rows[1].split(",")
     loss = float(vals[hdr.index("loss")])
     assert np.isfinite(loss) and 0.0 <= loss <= 4.0        # squared distance of two unit vectors
+    # together with --accum-freq 2 the reference clips the running sum after EVERY micro-batch (utils_AT.py:348-362): under its
+    # default --precision amp torch's GradScaler refuses the second unscale_ of a step -- same error here; without a scaler it runs
+    acc = [a if a != "runn" else "runa" for a in args] + ["--accum-freq", "2"]
+    acc[acc.index("--custom_out_folder") + 1] = "a_"
+    with pytest.raises(RuntimeError, match="unscale_"):
+        cli.main(acc)
+    acc[acc.index("--custom_out_folder") + 1], acc[acc.index("--name") + 1] = "b_", "runb"
+    assert cli.main(acc + ["--precision", "amp_bf16"]) == 0
+    rows = open(tmp_path / "results" / "b_text_only_k1_rho6_seed2" / "results.csv").read().strip().splitlines()
+    assert np.isfinite(float(rows[1].split(",")[rows[0].split(",").index("loss")]))
 
 
 def test_train_cli_two_ranks_under_torch_distributed_run(tmp_path):

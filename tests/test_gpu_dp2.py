@@ -116,6 +116,67 @@ def test_two_ranks_overlapped_equals_flat_and_the_concatenated_batch(tmp_path, n
     assert worst < 1e-5
 
 
+def _micro_clip_run(m, toks, lens, anchor, rows_of_micro, max_norm):
+    """two micro-batches through the trainer's MicroClip; returns (norm found at each micro-batch, gradient the step sees)"""
+    import types
+    import torch
+    from leaf_amd.train import MicroClip
+    mc = MicroClip(m, types.SimpleNamespace(grad_clip_norm=max_norm, accum_freq=len(rows_of_micro), precision="amp_bf16"))
+    m.train()
+    m.zero_grad()
+    norms = []
+    for j, sl in enumerate(rows_of_micro):
+        feat = m.forward_train(toks[sl], seq_lens=lens[sl])
+        mc.backward(feat, anchor[sl].contiguous(), j)
+        norms.append(float(m._clipi_ws[1]))
+    torch.cuda.synchronize()
+    return norms, m.grads.cpu()
+
+
+def _micro_clip_worker(rank, world, port, name, n, max_norm, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from leaf_amd.model import create_model
+    m = create_model(name, seed=1, trainable=True)
+    toks, lens = _inputs(name, n)
+    anchor = m.encode_text(toks, seq_lens=lens)
+    g = torch.Generator(device="cpu").manual_seed(7)
+    anchor = anchor + (anchor.norm(dim=-1, keepdim=True) / anchor.shape[-1] ** 0.5) * torch.randn(anchor.shape, generator=g).to(anchor.device)
+    q = n // 4                                   # micro-batch j of rank r = rows [(2 j + r) q, (2 j + r + 1) q)
+    norms, grads = _micro_clip_run(m, toks, lens, anchor, [slice((2 * j + rank) * q, (2 * j + rank + 1) * q) for j in (0, 1)], max_norm)
+    torch.save({"norms": norms, "grads": grads}, f"{out}.{rank}")
+    dist.destroy_process_group()
+
+
+def test_micro_batch_clipping_two_ranks_equals_the_concatenated_micro_batches(tmp_path):
+    """--grad-clip-norm with --accum-freq 2 under data parallelism (utils_AT.py:348-362 inside DDP: every micro-batch's backward
+    all-reduces, the clip sees the mean over ranks of the running sum): two ranks with half of each micro-batch == one process
+    on the whole micro-batches -- the norms found at each clip and the gradient handed to the optimizer step."""
+    import torch
+    import torch.multiprocessing as mp
+    name, n = "tiny-test-quickgelu", 16
+    sys.path.insert(0, ROOT)
+    from leaf_amd.model import create_model
+    m = create_model(name, seed=1, trainable=True)
+    toks, lens = _inputs(name, n)
+    anchor = m.encode_text(toks, seq_lens=lens)
+    g = torch.Generator(device="cpu").manual_seed(7)
+    anchor = anchor + (anchor.norm(dim=-1, keepdim=True) / anchor.shape[-1] ** 0.5) * torch.randn(anchor.shape, generator=g).to(anchor.device)
+    free_norms, _ = _micro_clip_run(m, toks, lens, anchor, [slice(0, 8), slice(8, 16)], 1e30)
+    max_norm = 0.4 * min(free_norms)             # both clips active
+    ref_norms, ref = _micro_clip_run(m, toks, lens, anchor, [slice(0, 8), slice(8, 16)], max_norm)
+    assert all(x > max_norm for x in ref_norms) and float(ref.norm()) <= max_norm * (1 + 1e-5)
+    out = str(tmp_path / "mc")
+    mp.spawn(_micro_clip_worker, args=(2, _free_port(), name, n, max_norm, out), nprocs=2, join=True)
+    a0, a1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert torch.equal(a0["grads"], a1["grads"]) and a0["norms"] == a1["norms"]           # replicas stay replicas
+    assert np.allclose(a0["norms"], ref_norms, rtol=1e-5), (a0["norms"], ref_norms)
+    assert float((a0["grads"] - ref).norm() / ref.norm()) < 1e-5
+
+
 def test_bench_two_ranks_rehearsal_on_one_gpu():
     """`bench.py --gpus 2 --backend gloo`: the launcher, the barrier-bracketed timing with the max over ranks, n_ranks_seen and
     the full step (search with per-rank seeds, bucketed reduction beside the backward, AdamW) with two ranks sharing this box's

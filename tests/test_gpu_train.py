@@ -189,6 +189,46 @@ def test_grad_clip_norm_vs_reference_fixture(torch_mod, golden_dir):
         assert d.max() < 2.5 * lr and d.mean() < 5e-2 * lr, (k, d.max(), d.mean())
 
 
+def test_micro_batch_clipping_vs_reference_fixture(torch_mod, golden_dir):
+    """--grad-clip-norm with --accum-freq 2 (utils_AT.py:348-362): the trainer's MicroClip clips the running sum after each
+    micro-batch's backward (leaf_clip_grads_inplace); norms and the gradient the step sees against the reference fixture
+    (tests/golden/make_golden_microclip.py).  Under --precision amp the reference's GradScaler refuses the second unscale_."""
+    import types
+    from leaf_amd.model import create_model
+    from leaf_amd.train import MicroClip
+    z = np.load(os.path.join(golden_dir, "tiny_microclip.npz"))
+    zq = np.load(os.path.join(golden_dir, "tiny_quickgelu.npz"))
+    args = types.SimpleNamespace(grad_clip_norm=float(z["max_norm"]), accum_freq=2, precision="amp_bf16")
+    with pytest.raises(RuntimeError, match="unscale_"):
+        MicroClip.check(types.SimpleNamespace(grad_clip_norm=1.0, accum_freq=2, precision="amp"))
+    MicroClip.check(args)
+    MicroClip.check(types.SimpleNamespace(grad_clip_norm=1.0, accum_freq=1, precision="amp"))
+    m = create_model("tiny-test-quickgelu", seed=12, trainable=True)
+    mc = MicroClip(m, args)
+    assert mc.active
+    toks, anchor = zq["tokens"][:8], torch_mod.from_numpy(zq["anchor"]).cuda()
+    m.zero_grad()
+    norms = []
+    for j in range(2):
+        feat = m.forward_train(toks[4 * j: 4 * j + 4])
+        mc.backward(feat, anchor[4 * j: 4 * j + 4], j)
+        norms.append(float(m._clipi_ws[1]))
+        assert abs(float(m._clipi_ws[0]) - float(z["max_norm"]) / (norms[-1] + 1e-6)) < 1e-6
+    assert np.allclose(norms, z["norms"], rtol=6e-3), (norms, z["norms"])           # fp16 gradient path
+    tot = float(torch_mod.linalg.vector_norm(m.grads))
+    assert abs(tot - float(z["final_grad_norm"])) < 6e-3 * float(z["final_grad_norm"]) and tot <= float(z["max_norm"]) * (1 + 1e-5)
+    for k, (off, shape) in m.layout.items():
+        g = m.grads[off: off + int(np.prod(shape))].view(shape).cpu().numpy()
+        if k == "token_embedding.weight":
+            assert rel_l2(g[z["tok_rows"]], z["grad_tok_rows"]) < 1e-2, k
+        elif "grad:" + k in z.files and np.linalg.norm(z["grad:" + k]) > 1e-3 * float(z["final_grad_norm"]):
+            assert rel_l2(g, z["grad:" + k]) < 1e-2, k
+    # pre_scale alone (the data-parallel hand-over between micro-batches): an exact power-of-two scaling, no clip
+    before = m.grads.clone()
+    m.clip_grads_(None, pre_scale=0.5)
+    assert torch_mod.equal(m.grads, before * 0.5)
+
+
 def test_non_finite_gradients_skip_the_step(torch_mod):
     """a NaN / inf anywhere in the gradient buffer must not reach the weights or the AdamW moments (and, through
     the flat all-reduce, the other ranks): the fused step is skipped as a whole, as GradScaler.step does in the reference's

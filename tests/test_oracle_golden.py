@@ -141,6 +141,28 @@ def test_normalize_fare_matches_reference(golden_dir):
     assert rel_l2(g["token_embedding.weight"][z["tok_rows"]], z["g_tok_rows"]) < 2e-4
 
 
+def test_micro_batch_clipping_matches_reference(golden_dir):
+    """--grad-clip-norm with --accum-freq 2 (utils_AT.py:348-362, no GradScaler): the running gradient sum is clipped after each
+    micro-batch's backward; norms found and the gradient the step sees against tests/golden/make_golden_microclip.py's fixture."""
+    z = np.load(os.path.join(golden_dir, "tiny_microclip.npz"))
+    zq = np.load(os.path.join(golden_dir, "tiny_quickgelu.npz"))
+    cfg = O.TextCfg(128, 2, 2, 64, quick_gelu=True)
+    w = O.init_weights(cfg, seed=12)
+    toks, anchor = zq["tokens"][:8], zq["anchor"]
+    g, norms = O.accumulate_micro_clipped(w, cfg, [(toks[:4], anchor[:4]), (toks[4:8], anchor[4:8])], float(z["max_norm"]))
+    assert np.allclose(norms, z["norms"], rtol=1e-4), (norms, z["norms"])
+    assert all(n > float(z["max_norm"]) for n in norms)                       # both clips are active in this fixture
+    for k in z.files:
+        if k.startswith("grad:"):
+            assert rel_l2(g[k[5:]], z[k]) < 2e-4, k
+    assert rel_l2(g["token_embedding.weight"][z["tok_rows"]], z["grad_tok_rows"]) < 2e-4
+    # ... and it is NOT what clipping once before the step gives (the quantity round 3 computed)
+    once, _ = O.accumulate_micro_clipped(w, cfg, [(toks[:4], anchor[:4]), (toks[4:8], anchor[4:8])], 1e30)
+    O.clip_grad_norm(once, float(z["max_norm"]))
+    k = "transformer.resblocks.0.mlp.c_fc.weight"
+    assert rel_l2(once[k], z["grad:" + k]) > 5e-2
+
+
 def _sample_index(numel, n_sample=257):
     """Same walk as tests/golden/make_golden_vitl_grads.py:sample_index."""
     n = min(n_sample, numel)
