@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS_16BIT = 2500.0  # MI355X dense bf16/fp16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_HBM_GBS = 8000.0       # HBM3E spec peak (same table; ~6.3 TB/s achievable)
-TRAFFIC_FILE = "r04_traffic.json"   # PMC summary of the dominant kernel (tools/pmc_passes.sh, tools/pmc_summary.py)
+TRAFFIC_GLOB = "r04_traffic*.json"   # PMC summaries, one per workload (tools/pmc_passes.sh, tools/pmc_summary.py)
 FAMILY = {0: "gemm_nt_kernel", 1: "gemm_nt256_kernel", 4: "gemm_nt256_half_kernel", 6: "gemm_nt64_ring_kernel", 7: "gemm_nt128pp_kernel",
           8: "qkv_attn_kernel"}
 EPI_NAMES = {0: "store16", 1: "act16", 2: "resid32", 3: "store32", 4: "actgrad16", 5: "lnfold16", 6: "lnfold_act16", 7: "resid32+x16+stats"}
@@ -358,24 +358,37 @@ def main():
         # optional embedding-space PGD mode k x (fwd + input-gradient bwd ~ 1 + 1) on top of anchor + start fwd + train bwd
         flops_per_sample = (2 * args.rho * args.k_adv + 4) * F if args.attack == "leaf" else (2 * args.k_adv + 4) * F
         value = B * world * args.steps / dt
-        traffic, traffic_note, traffic_kernels = None, "no PMC summary under profiles/ for this kernel build", None
-        try:    # HBM bytes per launch of the dominant kernel from the committed PMC passes; only for the build they were taken on
-            with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)) as f:
-                tj = json.load(f)
-            default_cfg = not args.dense and not args.no_prefix_reuse and args.model == "ViT-L-14-quickgelu" and B == 128 \
-                and args.k_adv == 1 and args.attack == "leaf"
-            if tj.get("kernel_sources_sha16") == kernel_sources_hash() and default_cfg:
+        traffic, traffic_note, traffic_kernels = None, "no PMC summary under profiles/ for this kernel build and workload", None
+        # workload a PMC summary belongs to: tools/pmc_summary.py copies this key from the line of its own FETCH pass
+        wkey = (f"{args.model}|B{B}|accum{args.accum_freq}|k{args.k_adv}|rho{args.rho}|{args.attack}|"
+                f"{'dense' if args.dense else 'trimmed'}|{'noprefix' if args.no_prefix_reuse else 'prefix'}")
+        default_key = "ViT-L-14-quickgelu|B128|accum1|k1|rho50|leaf|trimmed|prefix"
+        try:    # HBM bytes per launch of the dominant kernel from the committed PMC passes; only for the build AND workload they were taken on
+            import glob
+            stale = False
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", TRAFFIC_GLOB))):
+                with open(path) as f:
+                    tj = json.load(f)
+                if tj.get("workload_key", default_key) != wkey:
+                    continue
+                name = "profiles/" + os.path.basename(path)
+                if tj.get("kernel_sources_sha16") != kernel_sources_hash():
+                    stale = True
+                    traffic_note = name + " was taken on different kernel sources: not attached"
+                    continue
                 traffic_kernels = tj.get("kernels")        # every big kernel: measured bytes / algorithmic bytes of the PMC run itself
-            if tj.get("kernel") == dom_name and tj.get("kernel_sources_sha16") == kernel_sources_hash() and default_cfg:
-                traffic = tj["traffic_bytes_per_launch"]
-                traffic_note = ("HBM bytes per launch, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) * 1024, separate passes, "
-                                "profiles/" + TRAFFIC_FILE + " (same kernel sources, sha16 " + tj["kernel_sources_sha16"] + "; that run's own "
-                                f"algorithmic bytes per launch: {tj.get('algorithmic_bytes_per_launch')})")
-            elif tj.get("kernel_sources_sha16") != kernel_sources_hash():
-                traffic_note = "profiles/" + TRAFFIC_FILE + " was taken on different kernel sources: not attached"
-            elif not default_cfg:
-                traffic_note = ("profiles/" + TRAFFIC_FILE + " holds the default configuration (configs[1]); no PMC pass exists for this one: "
-                                "tools/pmc_passes.sh + tools/pmc_summary.py produce it")
+                if tj.get("kernel") == dom_name:
+                    traffic = tj["traffic_bytes_per_launch"]
+                    traffic_note = ("HBM bytes per launch, rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) * 1024, separate passes, "
+                                    + name + " (same kernel sources, sha16 " + tj["kernel_sources_sha16"] + ", same workload; that run's own "
+                                    f"algorithmic bytes per launch: {tj.get('algorithmic_bytes_per_launch')})")
+                else:
+                    traffic_note = name + " names " + str(tj.get("kernel")) + " as dominant, this line " + dom_name + ": per-kernel list attached only"
+                break
+            else:
+                if not stale:
+                    traffic_note = ("no PMC summary under profiles/ for this workload (" + wkey + "): tools/pmc_passes.sh + "
+                                    "tools/pmc_summary.py produce it")
         except (OSError, ValueError, KeyError):
             pass
         out = {
@@ -394,7 +407,7 @@ def main():
                                    (f"CLIP {args.model} text encoder, OPTIONAL embedding-space PGD mode (SURVEY 8a row a12, NOT "
                                     f"the reference's text attack): k={args.k_adv} steps, {args.pgd_norm} eps={args.pgd_eps} "
                                     f"alpha={args.pgd_alpha}, B={B} per GPU, seq=77"),
-                       "attack": args.attack, "accum_freq": args.accum_freq, "baseline_config_index": args.config or None,
+                       "attack": args.attack, "accum_freq": args.accum_freq, "baseline_config_index": args.config or None, "workload_key": wkey,
                        "global_batch": B * world, "seq_len": cfg.context_length, "rho": args.rho, "k": args.k_adv,
                        "parallelism": f"dp{world}", "candidate_forwards_per_step_per_gpu": 2 * args.rho * args.k_adv * B},
             "roofline": {

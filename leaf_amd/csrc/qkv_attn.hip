@@ -34,7 +34,7 @@ constexpr int NCAP = LEAF_QKVATTN_NCAP, CAPROWS = LEAF_QKVATTN_CAPROWS;
 constexpr int MAXT = CAPROWS / 16;           // 16-row key / query tiles per sequence
 constexpr int CAP_OFF = 3 * HALF;
 constexpr int MISC_OFF = CAP_OFF + NCAP * 2 * CAPROWS * 128;   // images: p.ncap x (K rows, then V rows) of p.caprows rows each
-constexpr int STAT_OFF = MISC_OFF;           // float2[256]: (mean, rstd) of the tile's rows
+constexpr int STAT_OFF = MISC_OFF;           // (2 KiB unused: the row statistics go straight from global memory to registers)
 constexpr int SEQ_OFF = STAT_OFF + 2048;     // u32[256]: row | len << 9 | prefix << 16 | slot << 23 per sequence of the tile
 constexpr int EOT_OFF = SEQ_OFF + 1024;      // u8[256]: pooled position per sequence (last-layer mode)
 constexpr int ZERO_OFF = EOT_OFF + 256;      // 128 zero bytes: V rows beyond a sequence's end
@@ -146,8 +146,6 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QkvAttnArgs p) {
         if (p.map.prefix) my_pf = p.map.prefix[sg];
         if (p.eot_pos) my_eot = p.eot_pos[s_b + tid];
     }
-    float2 my_rowstat = float2{0.f, 0.f};
-    if (tid < BM && r0 + tid < p.M) my_rowstat = p.rowstat[r0 + tid];
     // caption images: rows of the tile's captions inside the cache (uniform: scalar loads)
     int cap_row0[NCAP], cap_rows[NCAP];
     {
@@ -265,6 +263,13 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QkvAttnArgs p) {
         bias4[j] = *(const float4*)(p.bias + gn);
         s4[j] = *(const float4*)(p.ln_s + gn);
     }
+    // ... and the (mean, rstd) of this lane's eight rows (fragment row 16 i + lane % 16 of the wave's 128)
+    float2 rs_all[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = r0 + wm * 128 + 16 * i + efrow;
+        rs_all[i] = p.rowstat[r < p.M ? r : p.M - 1];
+    }
     KSTEP(G, F, sa, sb, fo1, NOP_, NOP_, NOP_, NOP_)
     ADV(sa) ADV(sb)
     SYNC_TILE(0)
@@ -276,7 +281,6 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QkvAttnArgs p) {
     // ================================================================ epilogue: the ring is idle after this barrier
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (tid < BM) *(float2*)(smem + STAT_OFF + tid * 8) = my_rowstat;
     if (tid < nseq) {
         const int sg = p.map.s0 + s_b + tid;
         const int row = my_c0 - p.map.row0 - r0, len = my_c1 - my_c0, pfx = my_pf;
@@ -291,10 +295,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QkvAttnArgs p) {
         *(unsigned char*)(smem + EOT_OFF + tid) = (unsigned char)my_eot;
     }
     if (tid < 32) *(unsigned*)(smem + ZERO_OFF + tid * 4) = 0u;
-    __syncthreads();
-    float2 rs_all[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) rs_all[i] = *(const float2*)(smem + STAT_OFF + (wm * 128 + 16 * i + efrow) * 8);
+    // (the tables and the zero line are read in the attention stage only, behind the barrier that ends the staging)
     // everything loaded so far is retired before the caption DMAs go out: with LDS-DMAs in flight the compiler would drain
     // vmcnt(0) in front of the first use of any ordinary load, and in front of any LDS access it can see (the staging below is asm)
     __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0)

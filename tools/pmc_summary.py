@@ -80,7 +80,7 @@ def main():
                 per[sh["kernel"]][1] += sh["launches"]
         for kk in gemms:
             nm = short(kk) if "qkv_attn" not in kk else "qkv_attn_kernel<%s,5>" % ("F16" if "F16" in kk else "BF16")
-            big_disp = fe[kk][0] / fe[kk][1] > 100 * 1024            # > 100 MB fetched per dispatch: the scoring passes' launches
+            big_disp = fe[kk][0] / fe[kk][1] > 20 * 1024             # > 20 MB fetched per dispatch: the scoring passes' launches
             if nm in per and per[nm][1] and big_disp:
                 f_, w_ = fe[kk][0] / fe[kk][1] * 1024, wr[kk][0] / wr[kk][1] * 1024
                 a_ = per[nm][0] / per[nm][1]
@@ -90,6 +90,7 @@ def main():
     json.dump({
         "kernel": short(k),
         "kernel_sources_sha16": kernel_sources_hash(),   # bench.py attaches this summary only to lines from the same kernel sources
+        "workload_key": bj["config"].get("workload_key") if bj else None,   # ... and the same workload
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --steps 2 --warmup 1 "
                   "--no-cpu-baseline --no-dense-leg`, mean over that kernel's dispatches (tools/pmc_summary.py)",
         "fetch_kb_mean": fkb, "write_kb_mean": wkb,
