@@ -87,6 +87,8 @@ def main():
                 kernels.append({"kernel": nm, "dispatches": fe[kk][1], "fetch_bytes_per_launch": 2 * f_, "write_bytes_per_launch": w_,
                                 "algorithmic_bytes_per_launch": a_, "traffic_over_algorithmic": (2 * f_ + w_) / a_})
         kernels.sort(key=lambda r: -r["fetch_bytes_per_launch"] * r["dispatches"])
+        seen = set()          # persistent and plain instantiations share a short name: keep the one that moved the most bytes
+        kernels = [r for r in kernels if not (r["kernel"] in seen or seen.add(r["kernel"]))]
     json.dump({
         "kernel": short(k),
         "kernel_sources_sha16": kernel_sources_hash(),   # bench.py attaches this summary only to lines from the same kernel sources
