@@ -1,6 +1,6 @@
 """Parity of the HIP text path (through the C ABI) against the golden fixtures produced by the reference and
 against the CPU oracle.  Tolerance (north_star): embeddings within 1e-3 rel-L2 of the fp32 reference, fp16 MFMA
-operands with fp32 accumulation; the per-row bound is 1.25e-3 (measured max 1.0e-3 with the oracle's fp16 emulation)."""
+operands with fp32 accumulation; the per-row bound is north_star's 1e-3 too (tests/util.py:TOL_ROW; measured maxima 9.2e-4 ... 9.9e-4)."""
 import json
 import os
 
@@ -8,10 +8,10 @@ import numpy as np
 import pytest
 
 from oracle import text_oracle as O
-from tests.util import rel_l2, row_rel_l2
+from tests.util import TOL_ROW, rel_l2, row_rel_l2
 
 pytestmark = pytest.mark.gpu
-TOL_GLOBAL, TOL_ROW = 1.0e-3, 1.25e-3
+TOL_GLOBAL = 1.0e-3
 
 
 @pytest.fixture(scope="module")
