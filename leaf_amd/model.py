@@ -263,6 +263,8 @@ class LeafCLIPText:
         return C.c_void_p(lens.ctypes.data), torch.from_numpy(cu).pin_memory().to(self.device, non_blocking=True), lens
 
     def encode_text(self, text, normalize: bool = False, seq_lens=None) -> torch.Tensor:
+        if len(text) == 0:      # an empty batch encodes to an empty [0, embed_dim] tensor, as the torch module's (model.py:269-284)
+            return torch.empty(0, self.cfg.embed_dim, dtype=torch.float32, device=self.device)
         if not self._packed:
             self.pack()
         lens_p, cu, keep = self._row_plan(text, seq_lens)

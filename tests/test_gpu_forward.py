@@ -47,6 +47,25 @@ def test_encode_text_tiny_golden(torch_mod, golden_dir, name, seed, model):
     assert rel_l2(outn, z["out_norm"]) < TOL_GLOBAL
 
 
+def test_encode_text_degenerate_batches(torch_mod):
+    """empty batch -> empty [0, D] (what the torch module returns); the shortest caption there is (SOT, EOT) and one that fills all
+    77 positions, alone and mixed in one ragged batch, against the oracle"""
+    m = _model("tiny-test-quickgelu", 12)
+    cfg = O.TextCfg(128, 2, 2, 64, quick_gelu=True)
+    w = O.init_weights(cfg, seed=12)
+    assert tuple(m.encode_text(np.zeros((0, 77), np.int32)).shape) == (0, cfg.embed_dim)
+    assert tuple(m.encode_text(torch_mod.zeros(0, 77, dtype=torch_mod.int64)).shape) == (0, cfg.embed_dim)
+    t = np.zeros((3, 77), np.int32)
+    t[0, 0], t[0, 1] = 49406, 49407                                 # SOT EOT
+    t[1, :76], t[1, 76] = 5, 49407                                  # EOT at the last position
+    t[2, 0], t[2, 1:9], t[2, 9] = 49406, np.arange(1, 9), 49407
+    want = O.encode_text(w, cfg, t)
+    got = m.encode_text(t).cpu().numpy()
+    assert np.isfinite(got).all() and row_rel_l2(got, want).max() < 1.5e-3
+    for i in range(3):                                              # each alone gives the same bits as in the ragged batch
+        assert np.array_equal(m.encode_text(t[i:i + 1]).cpu().numpy()[0], got[i])
+
+
 @pytest.mark.parametrize("fname,model", [("vitl_gelu", "ViT-L-14"), ("vitl_quickgelu", "ViT-L-14-quickgelu")])
 def test_encode_text_vitl_golden(torch_mod, golden_dir, fname, model):
     z = np.load(os.path.join(golden_dir, fname + ".npz"))
