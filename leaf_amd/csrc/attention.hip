@@ -171,7 +171,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const u16* __restrict__ q
                 }
             sum += __shfl_xor(sum, 16, 64);
             sum += __shfl_xor(sum, 32, 64);
-            const float inv = 1.0f / sum;
+            // v_rcp_f32 (1 ulp) instead of the 11-instruction IEEE division: P is rounded to 16 bits right below; qkv_attn.hip's
+            // attention stage must use the same instruction (its outputs are bit-identical to this kernel's: tests/test_gpu_fused_attn.py)
+            const float inv = __builtin_amdgcn_rcpf(sum);
             // O^T[dim][q] = sum_key V^T[dim][key] P^T[key][q], 16 keys per MFMA, P from the S^T accumulators
             f32x4 o[4];
 #pragma unroll

@@ -71,10 +71,13 @@ __device__ __forceinline__ void swap_half32(float& a, float& b) { asm volatile("
 __device__ __forceinline__ float rows4_max(float m) {
     float a = m, b = m;
     swap_rows16(a, b);
-    m = __builtin_fmaxf(a, b);
+    // (v_max_f32 in asm: behind the asm swaps the compiler would canonicalise both inputs of an fmaxf first, two more instructions
+    // per step; the scores are never NaN)
+    asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(a), "v"(b));
     a = m; b = m;
     swap_half32(a, b);
-    return __builtin_fmaxf(a, b);
+    asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(a), "v"(b));
+    return m;
 }
 __device__ __forceinline__ float rows4_sum(float x) {
     float a = x, b = x;
@@ -403,7 +406,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QkvAttnArgs p) {
                         sum += pe;
                     }
                 sum = rows4_sum(sum);
-                const float inv = 1.0f / sum;
+                const float inv = __builtin_amdgcn_rcpf(sum);   // (attention.hip: the same v_rcp_f32, not the IEEE division sequence)
                 f32x4 o[4];
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
