@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Per-row embedding error of the 16-bit forward on the BASELINE.json towers (north_star: rel-L2 <= 1e-3 per row): the two reference-generated
 ViT-L fixtures, and N synthetic captions per tower against the fp32 oracle (test infrastructure: oracle/ is only the checker here).
-  python tools/row_error_survey.py [N]"""
+  python tests/row_error_survey.py [N]"""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # (lives under tests/: only tests may import oracle/)
 sys.path.insert(0, ROOT)
 from oracle import text_oracle as O  # noqa: E402
 from leaf_amd.model import create_model  # noqa: E402

@@ -32,6 +32,6 @@ def stream():
 
 
 # north_star's embedding gate: rel-L2 <= 1e-3 PER ROW against the fp32 reference / oracle on the BASELINE.json towers (ViT-L, ViT-H, bigG).
-# Round 4: tightened from 1.25e-3 after measuring every row these tests look at (tools/row_error_survey.py,
+# Round 4: tightened from 1.25e-3 after measuring every row these tests look at (tests/row_error_survey.py,
 # profiles/r04_row_error_survey.txt: maxima 9.3e-4 ... 9.9e-4); the forward is deterministic, so a test that passes, passes again.
 TOL_ROW = 1.0e-3
