@@ -187,6 +187,9 @@ def main():
     ap.add_argument("--host-threads", type=int, default=0,
                     help="host threads per rank (torch CPU ops, the native tokenizer: LEAF_HOST_THREADS); default = usable cores // ranks on this node")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--prof-every", type=int, default=4,
+                    help="take the per-launch HIP events of the live roofline on every N-th timed step (an event pair makes the queue wait for the "
+                         "launch before it: 1.2 ms per 50-ms step when taken on all of them)")
     ap.add_argument("--dry", action="store_true", help="rendezvous rehearsal only (no GPU work); with --backend gloo runs on CPU")
     ap.add_argument("--attack", default="leaf", choices=["leaf", "pgd"],
                     help="leaf = the reference's character search (the BASELINE.json metric); pgd = the OPTIONAL embedding-space "
@@ -285,9 +288,15 @@ def main():
 
     step_marks = []     # one event per timed step (current stream, no synchronisation): the step time is DATA dependent
 
+    prof = {"on": False, "steps": 0}
+
     def run_steps(n, lens_arg, prefix, mark=False):
         loss = None
-        for _ in range(n):
+        for j in range(n):
+            if prof["on"]:                      # the live roofline samples every --prof-every-th timed step
+                take = j % max(args.prof_every, 1) == 0
+                lib.leaf_prof_pause(0 if take else 1)
+                prof["steps"] += int(take)
             loss = train_step_tokens(model, frozen, base, sc, seed=step_id[0], base_lens=lens_arg, prefix_reuse=prefix,
                                      base_ready=base_ready, micro_index=step_id[0] % args.accum_freq)
             step_id[0] += 1
@@ -305,10 +314,12 @@ def main():
     reducer.exposed_ms()          # drop the warm-up's pairs
     rows0 = model.rows_scored
     barrier()
-    if rank == 0:
+    if rank == 0 and os.environ.get("LEAF_BENCH_NO_PROF") != "1":     # (=1: overhead probe of the live per-launch events; the line then has no roofline)
         lib.leaf_prof_begin()
+        prof["on"] = True
     t0 = time.perf_counter()
     loss = run_steps(args.steps, base_lens, not args.no_prefix_reuse, mark=True)
+    prof["on"] = False
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -322,6 +333,13 @@ def main():
         gathered = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
         dist.all_gather(gathered, mine)
     dt = float(tmax.item())
+    if os.environ.get("LEAF_BENCH_NO_PROF") == "1":      # overhead probe only: no per-launch events were taken, so no roofline
+        if rank == 0:
+            print(json.dumps({"probe": "no per-launch events", "ms_per_step": dt / args.steps * 1e3, "steps": args.steps}), flush=True)
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     if rank == 0:
         ng = 256
@@ -329,6 +347,7 @@ def main():
         rows, info, n_out = (C.c_int64 * ng)(), (C.c_int32 * (4 * ng))(), C.c_int(0)
         _lib.check(lib.leaf_prof_end_shapes(ms, fl, by, rows, info, ng, C.byref(n_out)), "leaf_prof_end_shapes")
         shapes, per_key = [], {}
+        psteps = max(prof["steps"], 1)          # timed steps whose launches carry events
         for i in range(n_out.value):
             key, N, K, cnt = info[4 * i], info[4 * i + 1], info[4 * i + 2], info[4 * i + 3]
             big, key = key >= 256, key % 256          # launches of >= 16,384 rows (the scoring passes) are grouped apart
@@ -341,7 +360,7 @@ def main():
             intensity = fl[i] / by[i]
             bound = "hbm" if intensity < PEAK_TFLOPS_16BIT * 1e12 / (PEAK_HBM_GBS * 1e9) * 0.5 else "mfma"
             shapes.append({"kernel": kname, "epilogue": EPI_NAMES.get(key % 8), "N": N, "K": K, "launches": cnt, "big_launches": big,
-                           "rows_per_launch": rows[i] / cnt, "ms_per_step": ms[i] / args.steps, "tflops": tf,
+                           "rows_per_launch": rows[i] / cnt, "ms_per_step": ms[i] / psteps, "tflops": tf,
                            "mfma_frac": tf / PEAK_TFLOPS_16BIT, "algorithmic_gbs": gbs, "hbm_frac": gbs / PEAK_HBM_GBS,
                            "flop_per_byte": intensity, "bound": bound, "algorithmic_bytes_per_launch": by[i] / cnt})
             a = per_key.setdefault(key, [0.0, 0.0, 0.0, 0])
@@ -418,10 +437,11 @@ def main():
                 "launches": int(dom_cnt), "avg_launch_ms": dom_ms / dom_cnt,
                 "algorithmic_gflop_per_launch": dom_fl / dom_cnt / 1e9,
                 "all_gemm_tflops": gemm_total_fl / (gemm_total_ms * 1e-3) / 1e12,
-                "gemm_share_of_step": gemm_total_ms * 1e-3 / dt,
+                "gemm_share_of_step": gemm_total_ms * 1e-3 / (dt * psteps / args.steps),
+                "sampled_steps": psteps,
                 "shapes": shapes[:16],
             },
-            "step_exec_frac": gemm_total_fl / dt / (PEAK_TFLOPS_16BIT * 1e12),
+            "step_exec_frac": gemm_total_fl / (dt * psteps / args.steps) / (PEAK_TFLOPS_16BIT * 1e12),
             **step_trend(step_marks),
             "dense_equiv_frac": value * flops_per_sample / (world * PEAK_TFLOPS_16BIT * 1e12),
             "algorithmic_tflop_per_sample": flops_per_sample / 1e12,
@@ -430,7 +450,7 @@ def main():
                                    f"mean kept rows {float(lens_np.mean()):.1f} of 77" +
                                    ("" if args.no_prefix_reuse else "; prefix reuse: rows before the edited token come "
                                     "from the clean caption's per-layer K/V cache (bit-identical outputs)"),
-            "executed_gemm_tflop_per_step": gemm_total_fl / args.steps / 1e12,
+            "executed_gemm_tflop_per_step": gemm_total_fl / psteps / 1e12,
             "kernel_sources_sha16": kernel_sources_hash(),
             "loss": float(loss),
         }

@@ -283,6 +283,7 @@ int leaf_tok_duplicate_map(const int32_t* tokens, int B, int rho, int ctx, int32
  * its stream; end() sums duration / algorithmic FLOPs / algorithmic bytes / launches per key = kernel_family*16 + operand_dtype*8 + epilogue id
  * (family 0 = gemm_nt_kernel, 1 = gemm_nt256_kernel, 4 = gemm_nt256_half_kernel, 6 = gemm_nt64_ring_kernel; keys < 128). */
 int leaf_prof_begin(void);
+int leaf_prof_pause(int paused);   /* suspend / resume the recording (per-launch events on a sample of the timed steps only) */
 int leaf_prof_end(double* ms, double* flops, double* bytes /* algorithmic, may be NULL */, int64_t* count, int n_keys);
 /* same records grouped by (key, N, K): info[4 i] = {key, N, K, launches}, rows[i] = sum of M; *n_out groups written */
 int leaf_prof_end_shapes(double* ms, double* flops, double* bytes, int64_t* rows, int32_t* info, int max_groups, int* n_out);

@@ -95,6 +95,7 @@ _SIGS = {
     "leaf_tok_constrain": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                      C.c_void_p, C.c_void_p, C.c_int]),
     "leaf_prof_begin": (C.c_int, []),
+    "leaf_prof_pause": (C.c_int, [C.c_int]),
     "leaf_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                C.c_int]),
     "leaf_prof_end_shapes": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64),
