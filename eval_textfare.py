@@ -14,6 +14,8 @@ batches (the LEAF search is per-sentence independent, so results do not change),
 import argparse
 import csv
 import os
+
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # before torch loads the HIP runtime (leaf_amd/__init__.py says why)
 import string
 import sys
 
