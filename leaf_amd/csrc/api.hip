@@ -397,12 +397,12 @@ int forward_chunk(const leaf_text* h, const float* P, const uint16_t* W, const i
         const bool fused_attn = kv.attn_tiles > 0;
         if (fused_attn) {
             if (kv.kv_self_rows) {
+                // only the K and V thirds: nothing ever reads a caption's q rows from the cache (its own attention runs inside the
+                // fused launch below, from LDS) -- weight rows [d, 3d) into cache columns [d, 3d) of the [rows, 3d] layout
                 uint16_t* dst = kv.kv_copy + (size_t)l * kv.kv_stride;
-                uint16_t* keep = b.qkv;
-                b.qkv = dst;
-                const int rc = qkv_gemm(l, (int)kv.kv_self_rows, ln, b.a);
-                b.qkv = keep;
-                if (rc) return 1;
+                GemmLn q = ln; q.ln_s = h->fold_s_qkv(W, l) + d;
+                if (leaf_gemm(dt, EPI_LNFOLD_T, ln.x16, d, W + h->w16_fold_qkv(l) + (size_t)d * d, d, dst + d, 3 * d, h->fold_c_qkv(W, l) + d,
+                              nullptr, (int)kv.kv_self_rows, 2 * d, d, 0, s, 0.f, 0, nullptr, &q)) return 1;
                 kvl = dst;
             }
             const bool trim = last && h->last_trim && out;
