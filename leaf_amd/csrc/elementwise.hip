@@ -315,17 +315,37 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ fe
     __shared__ int s_best;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const float* a = anchor + (size_t)b * D;
-    for (int r = wid; r < rho; r += 4) {
-        const float* f = feat + ((size_t)b * rho + r) * D;
+    // one wave per candidate, four candidates per wave in flight (their loads are independent: one memory round trip per group instead of
+    // one per candidate and per 64 columns -- the launch sits between a stage's last GEMM and the host's read of the winners)
+    auto partial = [&](const float* f) {
         float s = 0.f;
-        if (objective <= 1) {
+        if ((D & 3) == 0) {
+            for (int j = 4 * lane; j < D; j += 256) {
+                const float4 fv = *(const float4*)(f + j), av = *(const float4*)(a + j);
+                if (objective <= 1) {
+                    const float t0 = fv.x - av.x, t1 = fv.y - av.y, t2 = fv.z - av.z, t3 = fv.w - av.w;
+                    s = fmaf(t0, t0, s); s = fmaf(t1, t1, s); s = fmaf(t2, t2, s); s = fmaf(t3, t3, s);
+                } else {
+                    s = fmaf(fv.x, av.x, s); s = fmaf(fv.y, av.y, s); s = fmaf(fv.z, av.z, s); s = fmaf(fv.w, av.w, s);
+                }
+            }
+        } else if (objective <= 1) {
             for (int j = lane; j < D; j += 64) { float t = f[j] - a[j]; s = fmaf(t, t, s); }
         } else {
             for (int j = lane; j < D; j += 64) s = fmaf(f[j], a[j], s);
         }
-        s = wave_sum(s);
-        if (objective == 1 || objective == 2) s = -s;  // 0 l2, 1 negl2, 2 dissim, 3 sim
-        if (lane == 0) { ls[r] = s; if (loss_out) loss_out[(size_t)b * rho + r] = s; }
+        return s;
+    };
+    for (int r0 = 4 * wid; r0 < rho; r0 += 16) {
+        float s[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s[q] = r0 + q < rho ? partial(feat + ((size_t)b * rho + r0 + q) * D) : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v = wave_sum(s[q]);
+            if (objective == 1 || objective == 2) v = -v;  // 0 l2, 1 negl2, 2 dissim, 3 sim
+            if (lane == 0 && r0 + q < rho) { ls[r0 + q] = v; if (loss_out) loss_out[(size_t)b * rho + r0 + q] = v; }
+        }
     }
     __syncthreads();
     if (wid == 0) {
