@@ -347,37 +347,58 @@ class LeafCLIPText:
         return (idx, feat, loss) if want_loss else (idx, feat)
 
     def _score_prefix(self, tokens, anchor, rho, objective, want_features, want_loss, seq_lens, prefix_lens, kv):
+        return self.score_candidates_run(
+            self.score_candidates_prepare(tokens, anchor, rho, objective, want_features, want_loss, seq_lens, kv), prefix_lens)
+
+    def score_candidates_prepare(self, tokens, anchor, rho, objective="l2", want_features=True, want_loss=False, seq_lens=None, kv=None):
+        """Everything of a prefix-reuse ``score_candidates`` call that does NOT depend on the prefix lengths: token / anchor placement,
+        output buffers, the length limits and a pinned staging buffer for the row plan.  The search calls this BEFORE it waits for the
+        previous stage's winners and ``score_candidates_run(plan, prefix_lens)`` right after them: the device idles at that boundary
+        for as long as the host needs between the two (round 4, tools/stage_hole_probe.py: 270 -> 94 us at ViT-L B = 128, 181 -> 123 us at ViT-H
+        B = 32)."""
         if not self._packed:
             self.pack()
         if seq_lens is None:
             arr = tokens if isinstance(tokens, np.ndarray) else tokens.cpu().numpy()
             seq_lens = arr.reshape(-1, arr.shape[-1]).argmax(-1) + 1
-        full = np.asarray(seq_lens, dtype=np.int64).reshape(-1)
-        pfx = np.minimum(np.asarray(prefix_lens, dtype=np.int64).reshape(-1), full - 1)      # keep at least the EOT row
-        pfx = np.minimum(pfx, np.repeat(kv["lens"].astype(np.int64), rho))                   # rows the cache really holds
-        suf = np.ascontiguousarray(full - pfx, dtype=np.int32)
-        cu = np.zeros(suf.size + 1, dtype=np.int32)
-        np.cumsum(suf, out=cu[1:])
-        host = np.concatenate([cu, pfx.astype(np.int32)])
-        dev = torch.from_numpy(host).pin_memory().to(self.device, non_blocking=True)
-        cu_dev, pfx_dev = dev[:suf.size + 1], dev[suf.size + 1:]
+        full = np.ascontiguousarray(np.asarray(seq_lens).reshape(-1), dtype=np.int32)
+        n = full.size
+        # prefix <= full - 1 (keep at least the EOT row) and <= the rows the cache really holds
+        limit = np.minimum(full - 1, np.repeat(kv["lens"].astype(np.int32), rho))
+        host = torch.empty(2 * n + 1, dtype=torch.int32, pin_memory=True)      # [cu (n + 1) | prefix (n)]
         if isinstance(tokens, np.ndarray):
             tokens = torch.from_numpy(tokens)
         t = self._tokens(tokens.reshape(-1, tokens.shape[-1]))
         B = anchor.shape[0]
-        if t.shape[0] != B * rho or kv["n"] != B:
+        if t.shape[0] != B * rho or kv["n"] != B or n != B * rho:
             raise ValueError("candidate rows / kv cache do not match B*rho")
         anchor = anchor.to(device=self.device, dtype=torch.float32).contiguous()
         idx = torch.empty(B, dtype=torch.int32, device=self.device)
         feat = torch.empty(B, self.cfg.embed_dim, dtype=torch.float32, device=self.device) if want_features else None
         loss = torch.empty(B, rho, dtype=torch.float32, device=self.device) if want_loss else None
-        ws = self._workspace(1, B * rho)
-        self.rows_scored += int(cu[-1])
+        return {"full": full, "limit": limit, "host": host, "t": t, "anchor": anchor, "idx": idx, "feat": feat, "loss": loss, "B": B,
+                "rho": rho, "obj": _OBJ[objective], "kv": kv, "ws": self._workspace(1, B * rho), "max_len": int(full.max()),
+                "want_loss": want_loss}
+
+    def score_candidates_run(self, plan, prefix_lens):
+        """The prefix-dependent rest of ``score_candidates_prepare``: row plan (suffix rows per candidate, their running sum), one
+        host-to-device copy, the launches.  Returns what ``score_candidates`` returns."""
+        full, n, kv = plan["full"], plan["full"].size, plan["kv"]
+        hv = plan["host"].numpy()
+        pfx = hv[n + 1:]
+        np.minimum(np.asarray(prefix_lens).reshape(-1), plan["limit"], out=pfx, casting="unsafe")
+        suf = full - pfx                                                       # rows to compute per candidate (int32, contiguous)
+        hv[0] = 0
+        np.cumsum(suf, out=hv[1:n + 1])
+        dev = plan["host"].to(self.device, non_blocking=True)
+        cu_dev, pfx_dev = dev[:n + 1], dev[n + 1:]
+        self.rows_scored += int(hv[n])
         _lib.check(self._lib.leaf_score_candidates_prefix(
-            self._h, _ptr(self.flat), _ptr(self.w16), _ptr(t), C.c_void_p(suf.ctypes.data), _ptr(cu_dev), _ptr(pfx_dev),
-            _ptr(kv["base_cu"]), _ptr(kv["kv"]), kv["base_rows"], int(full.max()), _ptr(anchor), B, rho, _OBJ[objective], _ptr(idx),
-            _ptr(feat), _ptr(loss), _ptr(ws), ws.numel(), self._stream()), "leaf_score_candidates_prefix")
-        return (idx, feat, loss) if want_loss else (idx, feat)
+            self._h, _ptr(self.flat), _ptr(self.w16), _ptr(plan["t"]), C.c_void_p(suf.ctypes.data), _ptr(cu_dev), _ptr(pfx_dev),
+            _ptr(kv["base_cu"]), _ptr(kv["kv"]), kv["base_rows"], plan["max_len"], _ptr(plan["anchor"]), plan["B"], plan["rho"], plan["obj"],
+            _ptr(plan["idx"]), _ptr(plan["feat"]), _ptr(plan["loss"]), _ptr(plan["ws"]), plan["ws"].numel(), self._stream()),
+            "leaf_score_candidates_prefix")
+        return (plan["idx"], plan["feat"], plan["loss"]) if plan["want_loss"] else (plan["idx"], plan["feat"])
 
     def score_candidates_fused(self, base_tokens, base_lens, tokens, anchor: torch.Tensor, rho: int, seq_lens, prefix_lens,
                                objective: str = "l2", want_features: bool = False, want_loss: bool = False):

@@ -126,9 +126,16 @@ def search_synthetic(model, anchor: torch.Tensor, base: torch.Tensor, cfg: StepC
         if os.environ.get("LEAF_DIAG_FIXED_WINNER") == "1":
             best1 = torch.zeros_like(best1)      # diagnostic A/B runs only: the same row plan whatever the (garbage) scores say
         cand = gen.stage2_device(cur, best1)                             # queued behind stage 1, before the host waits
+        # ... and everything of the second stage's call that does not need the winners (the device has nothing to run between their
+        # arrival on the host and that call's first launch)
+        plan2 = model.score_candidates_prepare(cand.view(B * cfg.rho, -1), anchor, cfg.rho, "l2", want_features=False,
+                                               seq_lens=cand_lens, kv=kv) if reuse and kv is not None else None
         pos2 = gen.stage2_positions(pos, best1.cpu().numpy())           # the search's device->host sync (B indices)
-        best2, _ = model.score_candidates(cand.view(B * cfg.rho, -1), anchor, cfg.rho, "l2", want_features=False,
-                                          seq_lens=cand_lens, prefix_lens=pos2.reshape(-1) if reuse else None, kv=kv)
+        if plan2 is not None:
+            best2, _ = model.score_candidates_run(plan2, pos2)
+        else:
+            best2, _ = model.score_candidates(cand.view(B * cfg.rho, -1), anchor, cfg.rho, "l2", want_features=False,
+                                              seq_lens=cand_lens, prefix_lens=pos2.reshape(-1) if reuse else None, kv=kv)
         cur = cand[ar, best2.to(torch.int64)]
     return cur
 
