@@ -163,11 +163,26 @@ def test_vitl_k5_search_every_stage_rescored_by_oracle(torch_mod):
         calls.append((tokens.detach().cpu().numpy().copy(), idx.cpu().numpy().copy(), loss.cpu().numpy().copy(),
                       feat.cpu().numpy().copy()))
         return idx, feat, kv
+    # the second stage of every edit goes through the prepare / run pair (prepared before the host waits for the first stage's winners)
+    real_prep, real_run = m.score_candidates_prepare, m.score_candidates_run
+
+    def spy_prep(tokens, anchor_, rho_, objective="l2", want_features=True, want_loss=False, **kw):
+        plan = real_prep(tokens, anchor_, rho_, objective, want_features=True, want_loss=True, **kw)
+        plan["_tokens"] = tokens
+        return plan
+
+    def spy_run(plan, prefix_lens):
+        idx, feat, loss = real_run(plan, prefix_lens)
+        calls.append((plan["_tokens"].detach().cpu().numpy().copy(), idx.cpu().numpy().copy(), loss.cpu().numpy().copy(),
+                      feat.cpu().numpy().copy()))
+        return idx, feat
     m.score_candidates = spy
     m.score_candidates_fused = spy_fused
+    m.score_candidates_prepare, m.score_candidates_run = spy_prep, spy_run
     adv = search_synthetic(m, anchor, base, StepConfig(rho=rho, k_adv=k), seed=3, base_lens=lens, prefix_reuse=True)
     m.score_candidates = real
     m.score_candidates_fused = real_fused
+    m.score_candidates_prepare, m.score_candidates_run = real_prep, real_run
     assert len(calls) == 2 * k
     L = int(lens.max())
     cur = base_np.copy()
