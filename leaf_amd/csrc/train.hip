@@ -155,11 +155,42 @@ __global__ __launch_bounds__(256) void fare_reduce_kernel(const float* __restric
 // dproj[k][j] += sum_b pooled[b][k] * dout[b][j]      grid = d blocks
 __global__ __launch_bounds__(256) void proj_wgrad_kernel(const float* __restrict__ pooled, const float* __restrict__ dout,
                                                          float* __restrict__ dproj, int B, int d, int D) {
+    // column k of `pooled` goes through LDS once, the dout loads of eight captions are in flight together (the first form issued one
+    // dependent pair of loads per caption: 107 us for 0.15 GFLOP); same single accumulator per (k, j), captions in ascending order
+    __shared__ float pk[256];
     const int k = blockIdx.x;
-    for (int j = threadIdx.x; j < D; j += 256) {
-        float acc = 0.f;
-        for (int b = 0; b < B; ++b) acc = fmaf(pooled[(size_t)b * d + k], dout[(size_t)b * D + j], acc);
-        dproj[(size_t)k * D + j] += acc;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};                 // j = threadIdx.x + 256 u  (D <= 1024 per pass of the outer loop)
+    for (int j0 = 0; j0 < D; j0 += 1024) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = 0.f;
+        for (int b0 = 0; b0 < B; b0 += 256) {
+            __syncthreads();
+            if (b0 + (int)threadIdx.x < B) pk[threadIdx.x] = pooled[(size_t)(b0 + threadIdx.x) * d + k];
+            __syncthreads();
+            const int nb = B - b0 < 256 ? B - b0 : 256;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + threadIdx.x + 256 * u;
+                if (j >= D) continue;
+                const float* dj = dout + (size_t)b0 * D + j;
+                float a = acc[u];
+                int bb = 0;
+                for (; bb + 8 <= nb; bb += 8) {
+                    float v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = dj[(size_t)(bb + q) * D];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) a = fmaf(pk[bb + q], v[q], a);
+                }
+                for (; bb < nb; ++bb) a = fmaf(pk[bb], dj[(size_t)bb * D], a);
+                acc[u] = a;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + threadIdx.x + 256 * u;
+            if (j < D) dproj[(size_t)k * D + j] += acc[u];
+        }
     }
 }
 
@@ -248,7 +279,23 @@ __global__ __launch_bounds__(256) void pool_ln_wgrad_kernel(const float* __restr
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= d) return;
     float sg = 0.f, sb = 0.f;
-    for (int b = 0; b < n_seq; ++b) {
+    // the loads of eight captions are issued together (their addresses hang on per-caption table look-ups: one caption at a time was a
+    // chain of dependent round trips, 42 us for 128 captions); the sums still run over the captions in ascending order
+    int b = 0;
+    for (; b + 8 <= n_seq; b += 8) {
+        float dy[8], xv[8], mu[8], rs[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const size_t row = (size_t)seq_row(map, map.s0 + b + q) + eot_idx[b + q];
+            dy[q] = dpooled[(size_t)(b + q) * d + c];
+            xv[q] = x[row * d + c];
+            mu[q] = stats[2 * (b + q)];
+            rs[q] = stats[2 * (b + q) + 1];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { sg = fmaf(dy[q], (xv[q] - mu[q]) * rs[q], sg); sb += dy[q]; }
+    }
+    for (; b < n_seq; ++b) {
         const size_t row = (size_t)seq_row(map, map.s0 + b) + eot_idx[b];
         const float dy = dpooled[(size_t)b * d + c];
         sg = fmaf(dy, (x[row * d + c] - stats[2 * b]) * stats[2 * b + 1], sg);
@@ -382,7 +429,17 @@ __global__ __launch_bounds__(256) void pos_bwd_kernel(const float* __restrict__ 
     const int c = blockIdx.y * 256 + threadIdx.x;     // grid (ctx, ceil(d / 256)): one column per thread
     if (c < d) {
         float s = 0.f;
-        for (int n = 0; n < n_seq; ++n)
+        // eight sequences' loads in flight (each address hangs on two table look-ups); summed in ascending order as before
+        int n = 0;
+        for (; n + 8 <= n_seq; n += 8) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                v[q] = p < seq_len(map, map.s0 + n + q) ? dx[((size_t)seq_row(map, map.s0 + n + q) + p) * d + c] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += v[q];
+        }
+        for (; n < n_seq; ++n)
             if (p < seq_len(map, map.s0 + n)) s += dx[((size_t)seq_row(map, map.s0 + n) + p) * d + c];
         dpos[(size_t)p * d + c] += s * gscale[1];
     }
