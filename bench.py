@@ -32,10 +32,11 @@ import subprocess
 import sys
 import time
 
-os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # before the HIP runtime initialises (leaf_amd/__init__.py says why)
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+from leaf_amd import configure_runtime  # noqa: E402
+
+configure_runtime()   # HIP_FORCE_DEV_KERNARG=1, before the HIP runtime initialises (leaf_amd/__init__.py says why)
 
 PEAK_TFLOPS_16BIT = 2500.0  # MI355X dense bf16/fp16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_HBM_GBS = 8000.0       # HBM3E spec peak (same table; ~6.3 TB/s achievable)
@@ -169,6 +170,71 @@ def dry_run(args):
         dist.destroy_process_group()
 
 
+def rank_sim(args, model, frozen, sc, batch_for, dev, B):
+    """the R-GPU step predicted from one GPU.  Data parallelism here = every rank searches and back-propagates its
+    own B captions on the SAME weights, the gradients are summed, one AdamW.  That is what this loop executes, one rank after the
+    other (micro-batches with accum_scale 1/R = the mean over ranks), with an event behind every rank's backward: t_r.  On R GPUs
+    the ranks meet at the gradient reduction, so a step costs max_r t_r (+ the optimizer, + what of the all-reduce stays exposed);
+    on one GPU per rank it costs t_r.  pred_eff = E_step[mean_r t_r + t_opt] / E_step[max_r t_r + t_opt + exposed]."""
+    import statistics
+    import torch
+    from leaf_amd.step import StepConfig, get_reducer, train_step_tokens
+    R = args.rank_sim
+    sc = StepConfig(**{**sc.__dict__, "accum_freq": R})
+    cur = torch.cuda.current_stream(dev)
+    per_step = []
+
+    def one_step(step, timed):
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(R + 2)]
+        rows = []
+        evs[0].record(cur)
+        for r in range(R):
+            base, lens_np, ready = batch_for(step, r)
+            rows0 = model.rows_scored
+            train_step_tokens(model, frozen, base, sc, seed=step * R + r, base_lens=None if args.dense else lens_np,
+                              prefix_reuse=not args.no_prefix_reuse, base_ready=ready, micro_index=r, optimizer_step=False)
+            evs[r + 1].record(cur)
+            rows.append(model.rows_scored - rows0)
+        get_reducer(model).finish()
+        model.adamw_step(sc.lr, (sc.beta1, sc.beta2), sc.eps, sc.wd, grad_scale=1.0)
+        model.pack()
+        evs[R + 1].record(cur)
+        if timed:
+            per_step.append((evs, rows))
+
+    for i in range(args.warmup):
+        one_step(i, False)
+    torch.cuda.synchronize()
+    for i in range(args.steps):
+        one_step(args.warmup + i, True)
+    torch.cuda.synchronize()
+    t = [[e[r].elapsed_time(e[r + 1]) for r in range(R)] for e, _ in per_step]
+    t_opt = [e[R].elapsed_time(e[R + 1]) for e, _ in per_step]
+    mean_r = [statistics.mean(x) for x in t]
+    max_r = [max(x) for x in t]
+    opt = statistics.mean(t_opt)
+    exposed = float(os.environ.get("LEAF_RANKSIM_EXPOSED_MS", "0.9"))     # DESIGN.md section 6: last bucket of the overlapped all-reduce
+    one_gpu = statistics.mean(mean_r) + opt
+    n_gpu = statistics.mean(max_r) + opt
+    out = {"rank_sim": R, "steps": args.steps, "warmup": args.warmup, "B_per_rank": B, "model": args.model, "k": args.k_adv, "rho": args.rho,
+           "batches": "fixed per rank" if args.fixed_batch else "new per (rank, step)",
+           "ms_per_rank_step_mean": statistics.mean(mean_r), "ms_per_rank_step_by_rank": [statistics.mean(x[r] for x in t) for r in range(R)],
+           "ms_max_over_ranks_mean": statistics.mean(max_r), "ms_optimizer": opt,
+           "skew_ratio_max_over_mean": statistics.mean(max_r) / statistics.mean(mean_r),
+           "rank_time_cv": statistics.mean(statistics.pstdev(x) / statistics.mean(x) for x in t),
+           "scored_rows_per_rank_step_min_mean_max": [min(min(r_) for _, r_ in per_step), statistics.mean(statistics.mean(r_) for _, r_ in per_step),
+                                                      max(max(r_) for _, r_ in per_step)],
+           "pred_eff_skew_only": one_gpu / n_gpu,
+           "exposed_collective_ms_assumed": exposed,
+           "pred_eff": one_gpu / (n_gpu + exposed),
+           "pred_samples_per_s_R_gpus": R * B / ((n_gpu + exposed) * 1e-3),
+           "samples_per_s_one_gpu_same_loop": B / (one_gpu * 1e-3),
+           "note": "one GPU, ranks run one after another on the same weights (gradient sum, one AdamW = the R-rank step's arithmetic); "
+                   "t_r = events around rank r's anchor + search + forward + backward; the anchor of rank r + 1 overlaps the tail of rank r "
+                   "as in the real step; exposed collective = an ESTIMATE (no multi-GPU box), override with LEAF_RANKSIM_EXPOSED_MS"}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -193,6 +259,14 @@ def main():
                     help="take the per-launch HIP events of the live roofline on every N-th timed step (an event pair makes the queue wait for the "
                          "launch before it: 1.2 ms per 50-ms step when taken on all of them)")
     ap.add_argument("--dry", action="store_true", help="rendezvous rehearsal only (no GPU work); with --backend gloo runs on CPU")
+    ap.add_argument("--fixed-batch", action="store_true",
+                    help="train on ONE synthetic batch for all steps (the rounds 1-4 form; A/B work).  Default: a NEW batch per step, seeded "
+                         "by (rank, step), built on a side stream one step ahead -- the step is data dependent and must not depend on how far "
+                         "the model has over-fitted one batch")
+    ap.add_argument("--rank-sim", type=int, default=0, metavar="R",
+                    help="predict the R-GPU data-parallel step from ONE GPU: per step the R ranks' batches run one after another on the same "
+                         "weights (gradients summed, ONE AdamW: exactly the R-rank step's arithmetic), each rank's time is taken with events; "
+                         "prints pred_eff = (mean_r t_r + t_opt) / (max_r t_r + t_opt + exposed collective) instead of the metric line")
     ap.add_argument("--attack", default="leaf", choices=["leaf", "pgd"],
                     help="leaf = the reference's character search (the BASELINE.json metric); pgd = the OPTIONAL embedding-space "
                          "PGD mode of SURVEY.md 8a row a12 (k-adv inner steps), which the reference's text trainer does not run")
@@ -265,21 +339,50 @@ def main():
     model.pack()
     sc = StepConfig(rho=args.rho, k_adv=args.k_adv, lr=1e-5, wd=1e-4, attack=args.attack, pgd_eps=args.pgd_eps,
                     pgd_alpha=args.pgd_alpha, pgd_norm=args.pgd_norm, accum_freq=args.accum_freq)
-    # synthetic captions: SOT, U{8..40} ids, EOT, zero pad; a different shard per rank (seed + rank)
-    g = torch.Generator().manual_seed(1234 + rank)
+    # synthetic captions: SOT, U{8..40} ids, EOT, zero pad; a different shard per rank (seed + rank) and -- unless
+    # --fixed-batch -- a different batch per step: the lengths are drawn on the host (the row plan needs them), the ids on the device
+    # on a stream of their own, one step ahead of the step that consumes them
     B = args.batch
-    base = torch.zeros(B, cfg.context_length, dtype=torch.int32)
-    lens = torch.randint(8, 41, (B,), generator=g)
-    for i in range(B):
-        n = int(lens[i])
-        base[i, 0] = cfg.vocab_size - 2
-        base[i, 1:1 + n] = torch.randint(1, cfg.vocab_size - 2, (n,), generator=g, dtype=torch.int32)
-        base[i, 1 + n] = cfg.vocab_size - 1
-    lens_np = lens.numpy().astype(np.int32) + 2                       # SOT + n ids + EOT rows are kept
-    base_lens = None if args.dense else lens_np
-    base = base.to(dev)
-    base_ready = torch.cuda.Event()
-    base_ready.record()
+    ctx, V = cfg.context_length, cfg.vocab_size
+    data_stream = torch.cuda.Stream(device=dev)
+    dgen = torch.Generator(device=dev)
+    col = torch.arange(ctx, device=dev, dtype=torch.int64)[None, :]
+    data_stream.wait_stream(torch.cuda.current_stream(dev))       # ``col`` was made on the current stream
+    keep_alive = []
+    lens_seen = []
+
+    def make_batch(step, rank_=None):
+        r_ = rank if rank_ is None else rank_
+        seed_ = 1234 + r_ if args.fixed_batch else 1234 + r_ + 1000003 * (step + 1)
+        n = torch.randint(8, 41, (B,), generator=torch.Generator().manual_seed(seed_))
+        n_pin = n.pin_memory()
+        with torch.cuda.stream(data_stream):
+            dgen.manual_seed(seed_)
+            ids = torch.randint(1, V - 2, (B, ctx), device=dev, generator=dgen, dtype=torch.int32)
+            nd = n_pin.to(dev, non_blocking=True)[:, None]
+            b = torch.where((col >= 1) & (col <= nd), ids, torch.zeros_like(ids))
+            b[:, 0] = V - 2
+            b.scatter_(1, nd + 1, torch.full((B, 1), V - 1, device=dev, dtype=torch.int32))
+            ev = torch.cuda.Event()
+            ev.record(data_stream)
+        keep_alive.append((b, n_pin))                  # allocated on data_stream, read on two other streams: keep a few alive
+        del keep_alive[:-6]
+        ln = n.numpy().astype(np.int32) + 2             # SOT + n ids + EOT rows are kept
+        lens_seen.append(float(ln.mean()))
+        return b, ln, ev
+
+    fixed = make_batch(0) if args.fixed_batch else None
+    pending = {}
+
+    def batch_for(step, rank_=None):
+        """(ids, kept rows per caption, ready event) of a step; the NEXT step's batch is requested right away"""
+        if fixed is not None and rank_ is None:
+            return fixed
+        key = (step, rank_)
+        cur_ = pending.pop(key, None) or make_batch(step, rank_)
+        if rank_ is None:
+            pending[(step + 1, None)] = make_batch(step + 1)
+        return cur_
 
     def barrier():
         if use_dist:
@@ -299,8 +402,9 @@ def main():
                 take = j % max(args.prof_every, 1) == 0
                 lib.leaf_prof_pause(0 if take else 1)
                 prof["steps"] += int(take)
-            loss = train_step_tokens(model, frozen, base, sc, seed=step_id[0], base_lens=lens_arg, prefix_reuse=prefix,
-                                     base_ready=base_ready, micro_index=step_id[0] % args.accum_freq)
+            base, lens_np, base_ready = batch_for(step_id[0])
+            loss = train_step_tokens(model, frozen, base, sc, seed=step_id[0], base_lens=None if lens_arg is None else lens_np,
+                                     prefix_reuse=prefix, base_ready=base_ready, micro_index=step_id[0] % args.accum_freq)
             step_id[0] += 1
             if mark:
                 e = torch.cuda.Event(enable_timing=True)
@@ -308,8 +412,11 @@ def main():
                 step_marks.append(e)
         return loss
 
-    run_steps(args.warmup, base_lens, not args.no_prefix_reuse)
+    base_lens = None if args.dense else True          # run_steps: None = dense rows, else the batch's own kept-row counts
     lib = _lib.lib()
+    if args.rank_sim:
+        return rank_sim(args, model, frozen, sc, batch_for, dev, B)
+    run_steps(args.warmup, base_lens, not args.no_prefix_reuse)
     from leaf_amd.step import get_reducer
     reducer = get_reducer(model)
     reducer.timing = use_dist
@@ -420,7 +527,8 @@ def main():
             **({"rehearsal": f"gloo transport, {world} rank(s) on {ndev} device(s): functional rehearsal of the multi-rank step, "
                              "NOT the metric (RCCL, one device per rank, is)"} if rehearsal else {}),
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype + " MFMA operands, f32 accumulate", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype + " MFMA operands, f32 accumulate",
+            "data": "synthetic" + (" (one fixed batch for all steps: --fixed-batch)" if args.fixed_batch else " (a new batch per step, seeded by rank and step)"),
             "config": {"workload": (f"CLIP {args.model} text encoder, LEAF step k={args.k_adv} rho={args.rho}, "
                                     f"B={B} per GPU" + (f" x accum {args.accum_freq}" if args.accum_freq > 1 else "") +
                                     f", seq=77 (BASELINE.json configs[1]; {args.dtype} operands run the MFMA at the bf16 rate -- "
@@ -449,7 +557,7 @@ def main():
             "algorithmic_tflop_per_sample": flops_per_sample / 1e12,
             "exact_work_skipping": "none (dense, 77 rows per sequence)" if args.dense else
                                    "EOT trimming: rows after EOT are not computed (bit-identical outputs); "
-                                   f"mean kept rows {float(lens_np.mean()):.1f} of 77" +
+                                   f"mean kept rows {sum(lens_seen) / len(lens_seen):.1f} of 77" +
                                    ("" if args.no_prefix_reuse else "; prefix reuse: rows before the edited token come "
                                     "from the clean caption's per-layer K/V cache (bit-identical outputs)"),
             "executed_gemm_tflop_per_step": gemm_total_fl / psteps / 1e12,

@@ -15,7 +15,9 @@ import argparse
 import csv
 import os
 
-os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # before torch loads the HIP runtime (leaf_amd/__init__.py says why)
+from leaf_amd import configure_runtime
+
+configure_runtime()   # HIP_FORCE_DEV_KERNARG=1, before torch loads the HIP runtime (leaf_amd/__init__.py says why)
 import string
 import sys
 

@@ -290,12 +290,13 @@ def get_reducer(model) -> GradReducer:
 
 def train_step_tokens(model, frozen, base: torch.Tensor, cfg: StepConfig, seed: int, lr: Optional[float] = None,
                       micro_index: int = 0, base_lens=None, prefix_reuse: bool = True,
-                      base_ready: Optional["torch.cuda.Event"] = None) -> torch.Tensor:
+                      base_ready: Optional["torch.cuda.Event"] = None, optimizer_step: Optional[bool] = None) -> torch.Tensor:
     """Full outer step on token ids (int32 [B, ctx] on the model's device).  Returns the TextFARE loss (0-d).
     ``base_ready``: event after which ``base`` is valid.  The anchor forward depends only on ``base`` and the FROZEN
     weights, so with this event its side stream need not wait for the previous step's backward / all-reduce / AdamW
     still queued on the current stream and the anchor of step i+1 overlaps the tail of step i; without it the side
-    stream waits for everything queued so far (always safe)."""
+    stream waits for everything queued so far (always safe).  ``optimizer_step``: None = after the last micro-batch of
+    ``cfg.accum_freq`` (the trainer's rule); False = never (the caller reduces / steps itself: bench.py --rank-sim)."""
     model.eval()
     # The frozen model's anchor forward depends on nothing but the captions and the FROZEN weights: it runs on a side stream and the
     # search waits for it right before its first scoring call.  The side stream also waits for the PREVIOUS step's search
@@ -308,6 +309,7 @@ def train_step_tokens(model, frozen, base: torch.Tensor, cfg: StepConfig, seed: 
     side = _side_stream(base.device)
     if base_ready is not None:
         side.wait_event(base_ready)
+        cur.wait_event(base_ready)      # the search reads ``base`` on this stream (a batch built on a third stream, one step ahead)
     else:
         side.wait_stream(cur)
     prev = getattr(model, "_search_done", None)
@@ -336,7 +338,7 @@ def train_step_tokens(model, frozen, base: torch.Tensor, cfg: StepConfig, seed: 
         feat = model.forward_train(adv, seq_lens=base_lens)
     if micro_index % cfg.accum_freq == 0:
         model.zero_grad()
-    last = (micro_index + 1) % cfg.accum_freq == 0
+    last = (micro_index + 1) % cfg.accum_freq == 0 if optimizer_step is None else bool(optimizer_step)
     red = get_reducer(model)
     loss = red.backward(feat, anchor, accum_scale=1.0 / cfg.accum_freq, last_micro=last)   # + bucketed all-reduce behind it
     if last:

@@ -9,6 +9,10 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+import leaf_amd  # noqa: E402
+
+leaf_amd.configure_runtime()      # what the entry scripts do before their first HIP call (the GPU tests import those scripts later)
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box via gpurun)")

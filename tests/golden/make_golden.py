@@ -57,6 +57,8 @@ def install_stubs():
     sys.path.insert(0, REF)
 
 
+V_DEFAULT = [-1] + [ord(c) for c in string.ascii_lowercase + ' ' + string.ascii_uppercase + string.digits + string.punctuation]
+
 TINY = dict(embed_dim=64, vision_cfg=dict(image_size=32, layers=1, width=64, patch_size=16),
             text_cfg=dict(context_length=77, vocab_size=49408, width=128, heads=2, layers=2))
 

@@ -307,3 +307,34 @@ def test_native_tokenizer_survives_fork():
     p.join(timeout=30)
     assert ok and p.exitcode == 0
     assert tok.encode_batch(texts).tobytes() == want.tobytes()
+
+
+def test_configure_runtime_is_explicit_and_warns_when_too_late():
+    """importing the package has no process-wide side effect; ``configure_runtime()`` sets HIP_FORCE_DEV_KERNARG=1
+    only when the user has not exported it, and says so when the HIP runtime is already up (the setting would be ignored)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import os, sys, types, warnings
+os.environ.pop("HIP_FORCE_DEV_KERNARG", None)
+import leaf_amd
+assert "HIP_FORCE_DEV_KERNARG" not in os.environ, "import leaf_amd must not touch the environment"
+assert "torch" not in sys.modules, "import leaf_amd must not import torch"
+r = leaf_amd.configure_runtime()
+assert r == {"HIP_FORCE_DEV_KERNARG": "1", "applied": True, "hip_initialised": False}, r
+os.environ["HIP_FORCE_DEV_KERNARG"] = "0"
+r = leaf_amd.configure_runtime()
+assert r["HIP_FORCE_DEV_KERNARG"] == "0" and not r["applied"]          # an exported value wins
+del os.environ["HIP_FORCE_DEV_KERNARG"]
+fake = types.ModuleType("torch"); fake.cuda = types.SimpleNamespace(is_initialized=lambda: True)
+sys.modules["torch"] = fake
+with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter("always")
+    r = leaf_amd.configure_runtime()
+assert r["hip_initialised"] and not r["applied"] and "HIP_FORCE_DEV_KERNARG" not in os.environ
+assert len(w) == 1 and "already initialised" in str(w[0].message)
+print("ok")
+"""
+    p = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and p.stdout.strip() == "ok", p.stdout + p.stderr

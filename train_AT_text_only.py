@@ -16,7 +16,9 @@ utils_AT.py:428-556) is not run; ``hf-hub:`` ids select the architecture but wei
 import logging
 import os
 
-os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # before torch loads the HIP runtime (leaf_amd/__init__.py says why)
+from leaf_amd import configure_runtime
+
+configure_runtime()   # HIP_FORCE_DEV_KERNARG=1, before torch loads the HIP runtime (leaf_amd/__init__.py says why)
 import random
 import string
 import sys
