@@ -40,7 +40,7 @@ configure_runtime()   # HIP_FORCE_DEV_KERNARG=1, before the HIP runtime initiali
 
 PEAK_TFLOPS_16BIT = 2500.0  # MI355X dense bf16/fp16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_HBM_GBS = 8000.0       # HBM3E spec peak (same table; ~6.3 TB/s achievable)
-TRAFFIC_GLOB = "r04_traffic*.json"   # PMC summaries, one per workload (tools/pmc_passes.sh, tools/pmc_summary.py)
+TRAFFIC_GLOB = "r05_traffic*.json"   # PMC summaries, one per workload (tools/pmc_passes.sh, tools/pmc_summary.py)
 FAMILY = {0: "gemm_nt_kernel", 1: "gemm_nt256_kernel", 4: "gemm_nt256_half_kernel", 6: "gemm_nt64_ring_kernel", 7: "gemm_nt128pp_kernel",
           8: "qkv_attn_kernel"}
 EPI_NAMES = {0: "store16", 1: "act16", 2: "resid32", 3: "store32", 4: "actgrad16", 5: "lnfold16", 6: "lnfold_act16", 7: "resid32+x16+stats"}
@@ -489,8 +489,8 @@ def main():
         traffic, traffic_note, traffic_kernels = None, "no PMC summary under profiles/ for this kernel build and workload", None
         # workload a PMC summary belongs to: tools/pmc_summary.py copies this key from the line of its own FETCH pass
         wkey = (f"{args.model}|B{B}|accum{args.accum_freq}|k{args.k_adv}|rho{args.rho}|{args.attack}|"
-                f"{'dense' if args.dense else 'trimmed'}|{'noprefix' if args.no_prefix_reuse else 'prefix'}")
-        default_key = "ViT-L-14-quickgelu|B128|accum1|k1|rho50|leaf|trimmed|prefix"
+                f"{'dense' if args.dense else 'trimmed'}|{'noprefix' if args.no_prefix_reuse else 'prefix'}|{'fixedbatch' if args.fixed_batch else 'freshbatch'}")
+        default_key = "ViT-L-14-quickgelu|B128|accum1|k1|rho50|leaf|trimmed|prefix|freshbatch"
         try:    # HBM bytes per launch of the dominant kernel from the committed PMC passes; only for the build AND workload they were taken on
             import glob
             stale = False

@@ -352,6 +352,9 @@ hipError_t leaf_launch_gemm(const GemmArgs& p_in, int dtype, int epi, hipStream_
     const int fam = leaf_gemm_family(p, epi);
 #ifdef LEAF_VARIANTS
     if (fam == 7) return leaf_launch_gemm128pp(p, dtype, epi, s);
+    static int use_w4 = -1;    // LEAF_GEMM_W4=1: the four-wave 128 x 128-per-wave experiment (variants/gemm256w4.hip) where it is eligible
+    if (use_w4 < 0) { const char* e = getenv("LEAF_GEMM_W4"); use_w4 = (e && e[0] == '1') ? 1 : 0; }
+    if (use_w4 && fam == 4 && leaf_gemm256w4_eligible(p, epi)) return leaf_launch_gemm256w4(p, dtype, epi, s);
 #endif
     if (fam == 4) return leaf_launch_gemm256h(p, dtype, epi, s);
     if (fam == 6) return leaf_launch_gemm64(p, dtype, epi, s);

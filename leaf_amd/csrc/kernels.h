@@ -59,6 +59,9 @@ hipError_t leaf_launch_gemm256h(const GemmArgs& p, int dtype, int epi, hipStream
 bool leaf_gemm128pp_eligible(const GemmArgs& p, int epi);
 void leaf_gemm128pp_set_min_tiles(int n);
 hipError_t leaf_launch_gemm128pp(const GemmArgs& p, int dtype, int epi, hipStream_t s);
+// round-5 experiment: 256 x 256 tile as FOUR waves of 128 x 128 (variants/gemm256w4.hip: diagnostic builds only, LEAF_GEMM_W4=1)
+bool leaf_gemm256w4_eligible(const GemmArgs& p, int epi);
+hipError_t leaf_launch_gemm256w4(const GemmArgs& p, int dtype, int epi, hipStream_t s);
 // 64 x 128 tiles on a 3-slot LDS-DMA ring for small launches (gemm64.hip)
 bool leaf_gemm64_eligible(const GemmArgs& p);
 hipError_t leaf_launch_gemm64(const GemmArgs& p, int dtype, int epi, hipStream_t s);

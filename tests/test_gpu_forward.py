@@ -40,9 +40,11 @@ def test_encode_text_tiny_golden(torch_mod, golden_dir, name, seed, model):
     out = m.encode_text(torch_mod.from_numpy(z["tokens"].astype(np.int64))).cpu().numpy()
     assert np.isfinite(out).all()
     assert rel_l2(out, z["out"]) < TOL_GLOBAL
-    # d = 128: eight times fewer terms per dot product than ViT-L, so the per-row figure scatters more (measured max 1.28e-3
-    # over these 15 rows); the BASELINE.json shapes keep TOL_ROW (test_encode_text_vitl_golden, ..._large_towers_vs_oracle)
-    assert row_rel_l2(out, z["out"]).max() < 1.5e-3
+    # d = 128: eight times fewer terms per dot product than ViT-L, so the per-row figure scatters more -- the FORMAT's own noise
+    # exceeds 1e-3 here: the oracle's emulation of fp16 operands gives row max 9.1e-4 / 1.09e-3 on these two fixtures
+    # (tests/test_oracle_golden.py::test_fp16_operand_noise_of_the_tiny_config; BASELINE.md section 4 says why d = 128 is exempt
+    # from north_star's per-row figure); measured on the GPU: 1.28e-3.  The BASELINE.json towers keep TOL_ROW.
+    assert row_rel_l2(out, z["out"]).max() < 1.4e-3
     outn = m.encode_text(torch_mod.from_numpy(z["tokens"].astype(np.int64)), normalize=True).cpu().numpy()
     assert rel_l2(outn, z["out_norm"]) < TOL_GLOBAL
 

@@ -493,3 +493,47 @@ def test_config0_vitl_constrained_search_replays_reference_trace(torch_mod, gold
         loss_r = z["loss"][s_div - 1]
         pick = loss_r[np.arange(B), np.asarray(picks[s_div - 1], dtype=int)]
         assert np.all(pick >= loss_r.max(-1) * (1 - 5e-3)), (s_div, pick, loss_r.max(-1))
+
+
+def test_vitl_trained_like_spectrum_is_as_accurate_as_16_bit_operands_allow(torch_mod):
+    """every embedding gate so far is on N(0, sigma) random init.  A tower with a TRAINED-LIKE weight structure
+    (tests/util.py:trained_like_weights: power-law singular spectra, log-normal LayerNorm gains with outlier channels, non-zero
+    biases, heavy-tailed token norms -- pretrained weights need the network) is less forgiving: the oracle's emulation of 16-bit
+    operands with fp32 accumulation (what the MFMA path computes, up to summation order) is itself 1.1e-3 (median row) / 1.8e-3
+    (worst of 12 rows) away from fp32 on it, and so is the emulation of the REFERENCE's own GPU arithmetic (TF32 operands, fp32
+    stored intermediates: 1.2e-3 / 1.7e-3) -- north_star's 1e-3 is a statement about random-init towers.  The worst row is not a
+    stable statistic here: some captions are ill-conditioned (making single sites EXACT in the emulation moves the worst row up as
+    often as down, 1.5e-3 ... 2.4e-3; the GPU, a different summation order, measured 2.4e-3 with a median of 9.6e-4).  What is gated:
+    the engine is as close to fp32 as its operand format allows (row median within 1.3x of the emulation's, worst row within 2x),
+    stays finite, and the search still picks the oracle's candidates under the margin rule."""
+    from leaf_amd.model import create_model
+    from tests.util import trained_like_weights
+    name = "ViT-L-14-quickgelu"
+    cfg = O.CONFIGS[name]
+    w = trained_like_weights(cfg, seed=0)
+    B, rho = 12, 8
+    base = O.synthetic_tokens(B, seed=71, min_len=4, max_len=40)
+    L = int(base.argmax(-1).max()) + 1
+    want = O.encode_text(w, cfg, base[:, :L])
+    emu = O.encode_text(w, cfg, base[:, :L], rnd=O.RoundPolicy(O.round_fp16, lambda l, s, wh: s == "final"))
+    r_emu = row_rel_l2(emu, want)
+    m = create_model(name, seed=1)
+    m.load_state_dict(w)
+    got_t = m.encode_text(base)
+    assert bool(torch_mod.isfinite(got_t).all())
+    r = row_rel_l2(got_t.cpu().numpy(), want)
+    print(f"[trained-like] GPU rows: max {r.max():.3e} median {np.median(r):.3e} | fp16-operand emulation: max {r_emu.max():.3e} "
+          f"median {np.median(r_emu):.3e} | ||f|| {np.linalg.norm(want, axis=-1).mean():.3g}")
+    assert r_emu.max() > 1.2e-3, "the emulation says this tower is no harder than random init: the generator changed"
+    assert np.median(r) < 1.3 * np.median(r_emu) and r.max() < 2.0 * r_emu.max()
+    assert r.max() < 4e-3
+    cand = O.synthetic_candidates(base, rho, seed=72)
+    idx_o, _, loss_o = O.score_candidates(w, cfg, cand[:, :, :L], want)
+    idx, feat, loss = m.score_candidates(cand.reshape(-1, 77), torch_mod.from_numpy(want).cuda(), rho, "l2", want_loss=True)
+    idx, loss = idx.cpu().numpy(), loss.cpu().numpy()
+    err = np.abs(loss - loss_o).max(-1)
+    srt = np.sort(loss_o, -1)
+    for b in range(B):
+        if srt[b, -1] - srt[b, -2] > 4 * err[b]:
+            assert idx[b] == idx_o[b]
+        assert loss_o[b, idx[b]] >= loss_o[b, idx_o[b]] - 4 * err[b] - 1e-6

@@ -142,3 +142,34 @@ def test_fused_caption_pass_falls_back_when_the_rows_do_not_fit_one_chunk():
     assert m.score_candidates_fused(base, lens, cand.view(80, -1), anchor, 10, np.repeat(lens, 10), pos.reshape(-1)) is None
     got = search_synthetic(m, anchor, base, sc, seed=9, base_lens=lens)
     assert torch.equal(got, want)
+
+
+def test_bench_fresh_batches_fixed_batch_and_rank_sim():
+    """bench.py round 5: by default every step trains on a NEW synthetic batch (seeded by rank and step,
+    built on a side stream one step ahead) -- the line says so and two runs give the same loss; --fixed-batch restores the rounds 1-4
+    form; --rank-sim R runs R ranks' batches one after another on the same weights (gradient sum, one AdamW) and prints the predicted
+    R-GPU efficiency with its ingredients instead of the metric line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    common = ["--model", "tiny-test-quickgelu", "--batch", "16", "--rho", "8", "--no-cpu-baseline", "--no-dense-leg"]
+
+    def run(extra):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common + extra, env=env, capture_output=True, text=True,
+                           timeout=600, cwd=root)
+        assert p.returncode == 0, p.stderr[-3000:]
+        line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        assert len(line) == 1, p.stdout[-2000:]
+        return json.loads(line[0])
+    fresh, again, fixed = run(["--steps", "6", "--warmup", "2"]), run(["--steps", "6", "--warmup", "2"]), run(["--steps", "6", "--warmup", "2", "--fixed-batch"])
+    assert "new batch per step" in fresh["data"] and "fixed batch" in fixed["data"]
+    assert fresh["loss"] == again["loss"] and np.isfinite(fresh["loss"]) and fresh["loss"] != fixed["loss"]
+    assert fresh["config"]["workload_key"].endswith("freshbatch") and fixed["config"]["workload_key"].endswith("fixedbatch")
+    sim = run(["--rank-sim", "3", "--steps", "4", "--warmup", "1"])
+    assert sim["rank_sim"] == 3 and len(sim["ms_per_rank_step_by_rank"]) == 3 and sim["steps"] == 4
+    assert sim["ms_max_over_ranks_mean"] >= sim["ms_per_rank_step_mean"] > 0 and sim["skew_ratio_max_over_mean"] >= 1.0
+    assert 0.0 < sim["pred_eff"] <= sim["pred_eff_skew_only"] <= 1.0
+    assert sim["scored_rows_per_rank_step_min_mean_max"][0] > 0

@@ -37,3 +37,17 @@ def test_gemm_variant(env):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_gemm_variant.py")], env=full, cwd=ROOT,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_four_wave_gemm_experiment_has_the_same_bits_as_the_shipped_kernel():
+    """variants/gemm256w4.hip (round 5: the 256 x 256 tile as FOUR waves of 128 x 128, the wave shape of the vendor's hipBLASLt kernel;
+    measured no faster, profiles/r05_w4_experiment.txt, kept as a documented experiment in the diagnostic build): same bits as the
+    eight-wave kernel on every shape it takes (SHA-1 of the whole output, tools/w4_bench.py), incl. a ragged last M tile."""
+    out = {}
+    for w4 in ("0", "1"):
+        env = dict(os.environ, LEAF_HIP_LIB=VARIANTS_LIB, LEAF_GEMM_W4=w4, ROWS="33001")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "w4_bench.py")], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        out[w4] = [l.split("sha1")[1].strip() for l in r.stdout.splitlines() if "sha1" in l]
+        assert all(float(l.split("max|err| vs torch (512 rows)")[1].split()[0]) < 0.02 for l in r.stdout.splitlines() if "sha1" in l)
+    assert len(out["0"]) == 4 and out["0"] == out["1"], out

@@ -203,3 +203,20 @@ def test_round_policy_default_equals_a_plain_rounding_callable():
     assert np.array_equal(plain, O.encode_text(w, cfg, toks, rnd=O.RoundPolicy(O.round_fp16)))
     assert np.array_equal(O.encode_text(w, cfg, toks), O.encode_text(w, cfg, toks, rnd=O.RoundPolicy(O.round_fp16, lambda l, s, wh: True)))
     assert not np.array_equal(plain, O.encode_text(w, cfg, toks))
+
+
+def test_fp16_operand_noise_of_the_tiny_config(golden_dir):
+    """Why the d = 128 test config is gated per row at 1.4e-3 and not at north_star's 1e-3: rounding every MFMA
+    operand and stored 16-bit tensor to fp16 -- nothing else, fp32 accumulation, numpy -- already puts single rows of the tiny
+    fixtures at 0.9e-3 ... 1.1e-3 from the reference's fp32 output.  A dot product over d = 128 averages eight times fewer rounding
+    errors than one over d = 768 ... 1280, so rows scatter more; the batch figure (7.4e-4 / 8.3e-4) is where ViT-L's is."""
+    worst = []
+    for name, seed, qg in (("tiny_gelu", 11, False), ("tiny_quickgelu", 12, True)):
+        z = np.load(os.path.join(golden_dir, name + ".npz"))
+        cfg = O.TextCfg(128, 2, 2, 64, quick_gelu=qg)
+        w = O.init_weights(cfg, seed=seed)
+        out = O.encode_text(w, cfg, z["tokens"], rnd=O.RoundPolicy(O.round_fp16, lambda l, s, wh: s == "final"))
+        rows = np.linalg.norm(out - z["out"], axis=1) / np.linalg.norm(z["out"], axis=1)
+        assert np.linalg.norm(out - z["out"]) / np.linalg.norm(z["out"]) < 9e-4
+        worst.append(float(rows.max()))
+    assert 8e-4 < min(worst) and max(worst) > 1.0e-3 and max(worst) < 1.3e-3, worst
