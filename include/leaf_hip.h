@@ -62,6 +62,17 @@ int leaf_text_param_info(leaf_text_t h, int index, char* name, size_t name_len, 
 size_t leaf_text_w16_bytes(leaf_text_t h);
 int leaf_text_pack_weights(leaf_text_t h, const float* params, void* w16_fwd, void* w16_bwd, leaf_stream_t s);
 
+/* OPTIONAL precision escape hatch of the forward-only passes (encode_text, score_candidates*, forward_kv; the training forward is
+ * untouched -- the reference trains under fp16 autocast, utils_AT.py:317-319): the four GEMMs of the first `blocks` transformer
+ * blocks multiply hi + lo 16-bit splits of BOTH operands (x_hi W_hi + x_lo W_hi + x_hi W_lo in the fp32 accumulator, over a
+ * three times longer K through the unchanged GEMM kernels; stored q|k|v / attention / hidden rows stay 16-bit).  The embedding's
+ * error is made early: on the random-init ViT-L fixture blocks = 1 takes the worst row from 9.6e-4 to 8.3e-4,
+ * blocks = 2 to 7.1e-4 (oracle emulation), at +13 % of the search's GEMM work per block.  `buf` (DEVICE, leaf_text_split_bytes(h,
+ * blocks) bytes, caller-owned, must outlive the calls that use it) receives the split weight copies; call again after every
+ * optimizer step (as leaf_text_pack_weights).  blocks = 0 (buf ignored) switches the mode off.  0 <= blocks <= layers - 1. */
+size_t leaf_text_split_bytes(leaf_text_t h, int blocks);
+int leaf_text_split_pack(leaf_text_t h, const float* params, int blocks, void* buf, leaf_stream_t s);
+
 /* workspace sizes (bytes): mode 0 = forward, 1 = score_candidates, 2 = train backward */
 size_t leaf_text_workspace_bytes(leaf_text_t h, int n_seq, int mode);
 size_t leaf_text_stash_bytes(leaf_text_t h, int n_seq);

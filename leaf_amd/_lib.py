@@ -71,6 +71,8 @@ _SIGS = {
                                       C.c_void_p, C.c_void_p]),
     "leaf_adamw_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_float,
                                   C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_void_p]),
+    "leaf_text_split_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
+    "leaf_text_split_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "leaf_tok_create": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "leaf_tok_destroy": (None, [C.c_void_p]),
     "leaf_tok_encode_batch": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.c_void_p, C.c_int, C.c_int, C.c_void_p,

@@ -132,6 +132,27 @@ extern "C" int leaf_text_param_info(leaf_text_t h, int index, char* name, size_t
 
 extern "C" size_t leaf_text_w16_bytes(leaf_text_t h) { return h->w16_total_bytes(); }
 
+extern "C" size_t leaf_text_split_bytes(leaf_text_t h, int blocks) { return (h && blocks > 0) ? h->split_bytes(blocks) : 0; }
+
+extern "C" int leaf_text_split_pack(leaf_text_t h, const float* params, int blocks, void* buf, leaf_stream_t s_) {
+    if (!h) { leaf_set_error("null handle"); return 1; }
+    if (blocks == 0) { h->split_blocks = 0; h->split_buf = nullptr; return 0; }
+    if (blocks < 0 || blocks > h->cfg.layers - 1) { leaf_set_error("split blocks %d out of range 0..%d", blocks, h->cfg.layers - 1); return 1; }
+    if (!params || !buf) { leaf_set_error("leaf_text_split_pack: params / buf is null"); return 1; }
+    hipStream_t s = (hipStream_t)s_;
+    const int d = h->cfg.width, dt = h->fwd_dtype;
+    h->split_blocks = blocks;
+    h->split_buf = buf;
+    for (int l = 0; l < blocks; ++l) {
+        const LayerOff& o = h->layer[l];
+        LEAF_TRY(leaf_launch_split_pack(params + o.qkv_w, params + o.ln1_w, (void*)h->split_qkv3(l), (float*)h->split_s_qkv(l), 3 * d, d, 1, dt, s));
+        LEAF_TRY(leaf_launch_split_pack(params + o.fc_w, params + o.ln2_w, (void*)h->split_fc3(l), (float*)h->split_s_fc(l), 4 * d, d, 1, dt, s));
+        LEAF_TRY(leaf_launch_split_pack(params + o.out_w, nullptr, (void*)h->split_out_lo(l), nullptr, d, d, 0, dt, s));
+        LEAF_TRY(leaf_launch_split_pack(params + o.proj_w, nullptr, (void*)h->split_proj_lo(l), nullptr, d, 4 * d, 0, dt, s));
+    }
+    return 0;
+}
+
 extern "C" int leaf_text_pack_weights(leaf_text_t h, const float* params, void* w16_fwd, void* w16_bwd,
                                       leaf_stream_t s_) {
     hipStream_t s = (hipStream_t)s_;
@@ -356,10 +377,20 @@ int forward_chunk(const leaf_text* h, const float* P, const uint16_t* W, const i
     GemmLn ln;                       // statistics / 16-bit copy of the FULL row set of this chunk
     ln.rowstat = b.rowstat; ln.stat_out = b.stat; ln.stat_ld = rows; ln.x16 = b.x16; ln.ldx16 = d; ln.eps = c.ln_eps;
     // x = residual stream; qkv_gemm / fc_gemm: LN + linear of `m` rows whose (folded) statistics live in `g`
+    // optional higher-precision leading blocks (leaf_text_split_pack): hi + lo splits of both operands over a 3x longer K.  The
+    // [rows, 3d] split copy of the fp32 residual rows lives in buffers that are dead at that point: the hidden buffer in front of
+    // the QKV GEMM, the chunk's own q|k|v scratch in front of c_fc (these blocks run the two-kernel attention path).
+    const int nsplit = (fold && h->split_buf) ? h->split_blocks : 0;
     auto qkv_gemm = [&](int l, int m, const GemmLn& g, const void* xn) -> int {
         const LayerOff& o = h->layer[l];
         if (!fold) return leaf_gemm(dt, EPI_STORE_T, xn, d, W + h->w16_qkv(l), d, b.qkv, 3 * d, P + o.qkv_b, nullptr, m, 3 * d, d, 0, s);
         GemmLn q = g; q.ln_s = h->fold_s_qkv(W, l);
+        if (l < nsplit) {
+            LEAF_TRY(leaf_launch_split16_rows(b.x, b.hh, m, d, dt, s));
+            q.ln_s = h->split_s_qkv(l);
+            return leaf_gemm(dt, EPI_LNFOLD_T, b.hh, 3 * d, h->split_qkv3(l), 3 * d, b.qkv, 3 * d, h->fold_c_qkv(W, l), nullptr, m, 3 * d,
+                             3 * d, 0, s, 0.f, 0, nullptr, &q);
+        }
         return leaf_gemm(dt, EPI_LNFOLD_T, g.x16, d, W + h->w16_fold_qkv(l), d, b.qkv, 3 * d, h->fold_c_qkv(W, l), nullptr, m, 3 * d, d,
                          0, s, 0.f, 0, nullptr, &q);
     };
@@ -367,14 +398,28 @@ int forward_chunk(const leaf_text* h, const float* P, const uint16_t* W, const i
         const LayerOff& o = h->layer[l];
         if (!fold) return leaf_gemm(dt, EPI_ACT_T, xn, d, W + h->w16_fc(l), d, hid, 4 * d, P + o.fc_b, nullptr, m, 4 * d, d, c.activation, s);
         GemmLn q = g; q.ln_s = h->fold_s_fc(W, l);
+        if (l < nsplit) {
+            LEAF_TRY(leaf_launch_split16_rows(b.x, b_in.qkv, m, d, dt, s));
+            q.ln_s = h->split_s_fc(l);
+            return leaf_gemm(dt, EPI_LNFOLD_ACT_T, b_in.qkv, 3 * d, h->split_fc3(l), 3 * d, hid, 4 * d, h->fold_c_fc(W, l), nullptr, m, 4 * d,
+                             3 * d, c.activation, s, 0.f, 0, nullptr, &q);
+        }
         return leaf_gemm(dt, EPI_LNFOLD_ACT_T, g.x16, d, W + h->w16_fold_fc(l), d, hid, 4 * d, h->fold_c_fc(W, l), nullptr, m, 4 * d, d,
                          c.activation, s, 0.f, 0, nullptr, &q);
     };
     // residual GEMM x += A W^T + bias; with folding (and a LayerNorm following) it also emits x16 / statistics
-    // ... and the tiny finalize launch turns the [group][row] partials into (mean, rstd) per row for the consuming GEMM
-    auto resid_gemm = [&](const void* A, int K, size_t w_off, const float* bias, float* x, int m, const GemmLn* g) -> int {
-        if (!(fold && g)) return leaf_gemm(dt, EPI_RESID_F32, A, K, W + w_off, K, x, d, bias, nullptr, m, d, K, 0, s);
-        if (leaf_gemm(dt, EPI_RESID_LN, A, K, W + w_off, K, x, d, bias, nullptr, m, d, K, 0, s, 0.f, 0, nullptr, g)) return 1;
+    // ... and the tiny finalize launch turns the [group][row] partials into (mean, rstd) per row for the consuming GEMM.
+    // w_lo (split blocks): the A operand is a stored 16-bit tensor (exact as it is), so only the weights are split: x += A W_hi^T +
+    // bias, then x += A W_lo^T in a second launch, which is the one that emits x16 / statistics of the finished rows
+    auto resid_gemm = [&](const void* A, int K, size_t w_off, const float* bias, float* x, int m, const GemmLn* g,
+                          const uint16_t* w_lo = nullptr) -> int {
+        const uint16_t* Wl = W + w_off;
+        if (w_lo) {
+            if (leaf_gemm(dt, EPI_RESID_F32, A, K, Wl, K, x, d, bias, nullptr, m, d, K, 0, s)) return 1;
+            Wl = w_lo; bias = nullptr;
+        }
+        if (!(fold && g)) return leaf_gemm(dt, EPI_RESID_F32, A, K, Wl, K, x, d, bias, nullptr, m, d, K, 0, s);
+        if (leaf_gemm(dt, EPI_RESID_LN, A, K, Wl, K, x, d, bias, nullptr, m, d, K, 0, s, 0.f, 0, nullptr, g)) return 1;
         return leaf_check(leaf_launch_ln_finalize(g->stat_out, g->stat_ld, m, d / 64, g->eps, const_cast<float2*>(g->rowstat), s), "ln_finalize");
     };
     if (fold) {
@@ -394,7 +439,7 @@ int forward_chunk(const leaf_text* h, const float* P, const uint16_t* W, const i
         // QKV GEMM -> attention in one launch (qkv_attn.hip): q|k|v stay on chip, b.a receives the attention output.  In the fused
         // first stage the captions' q|k|v rows -- which their candidates' attention reads as cached prefix and the second stage
         // reads again -- come from a small GEMM of their own straight into the cache (the same bits as from any other kernel).
-        const bool fused_attn = kv.attn_tiles > 0;
+        const bool fused_attn = kv.attn_tiles > 0 && l >= nsplit;     // split blocks: QKV GEMM (3x K) + attention as two kernels
         if (fused_attn) {
             if (kv.kv_self_rows) {
                 // only the K and V thirds: nothing ever reads a caption's q rows from the cache (its own attention runs inside the
@@ -456,10 +501,11 @@ int forward_chunk(const leaf_text* h, const float* P, const uint16_t* W, const i
             return 0;
         }
         if (!fused_attn) LEAF_TRY(leaf_launch_attention_fwd(b.qkv, kvl, b.a, cs, map, c.heads, d, dt, s, nullptr, max_len));
-        if (resid_gemm(b.a, d, h->w16_out(l), P + o.out_b, b.x, rows, &ln)) return 1;
+        if (resid_gemm(b.a, d, h->w16_out(l), P + o.out_b, b.x, rows, &ln, l < nsplit ? h->split_out_lo(l) : nullptr)) return 1;
         if (!fold) LEAF_TRY(leaf_launch_layernorm(b.x, P + o.ln2_w, P + o.ln2_b, c.ln_eps, b.a, rows, d, dt, s));
         if (fc_gemm(l, rows, ln, b.a, b.hh)) return 1;
-        if (resid_gemm(b.hh, 4 * d, h->w16_proj(l), P + o.proj_b, b.x, rows, last ? nullptr : &ln)) return 1;   // ln_final runs on the pooled rows
+        if (resid_gemm(b.hh, 4 * d, h->w16_proj(l), P + o.proj_b, b.x, rows, last ? nullptr : &ln,   // ln_final runs on the pooled rows
+                       l < nsplit ? h->split_proj_lo(l) : nullptr)) return 1;
     }
     if (out && leaf_project_rows_ok(d, c.embed_dim)) {
         // same op sequence as the trimmed path (bit-identical features): gather the pooled rows, LN, fp32 projection.

@@ -524,6 +524,73 @@ hipError_t leaf_launch_copy_bytes(const void* src, void* dst, size_t bytes, hipS
     return hipGetLastError();
 }
 
+// ---- operand splits of the optional higher-precision blocks (leaf_text_split_pack / option "split blocks"):
+// a fp32 value v as hi = 16-bit(v), lo = 16-bit(v - hi); hi + lo carries ~22 significand bits.  The GEMM then multiplies
+// [x_hi | x_lo | x_hi] by [W_hi | W_hi | W_lo] over a three times longer K: the fp32 accumulator receives x_hi W_hi + x_lo W_hi +
+// x_hi W_lo (the missing x_lo W_lo is 2^-22 relative) -- the unchanged GEMM kernels, no new arithmetic.
+namespace {
+template <class TT>
+__global__ __launch_bounds__(256) void split16_rows_kernel(const float* __restrict__ x, u16* __restrict__ out, size_t n4, int d4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const size_t r = i / d4;
+        const int c = (int)(i - r * d4);
+        const float4 v = ((const float4*)x)[i];
+        const uint2 hi = pack4<TT>(v.x, v.y, v.z, v.w);
+        float h[4];
+        unpack4<TT>(hi, h);
+        const uint2 lo = pack4<TT>(v.x - h[0], v.y - h[1], v.z - h[2], v.w - h[3]);
+        uint2* o = (uint2*)(out + r * (size_t)(12 * d4)) + c;        // row stride 3 d elements = 12 d4
+        o[0] = hi; o[d4] = lo; o[2 * d4] = hi;
+    }
+}
+
+// one workgroup per weight row n: W'[n, k] = g[k] * W[n, k] (g == nullptr: W itself) split into hi / lo;
+// triple != 0: out row = [hi | hi | lo] (3 K elements) and s[n] = sum_k (hi + lo) in fp32; triple == 0: out row = lo only (K elements)
+template <class TT>
+__global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict__ W, const float* __restrict__ g, u16* __restrict__ out,
+                                                         float* __restrict__ srow, int K, int triple) {
+    __shared__ float red[256];
+    const int n = blockIdx.x;
+    const float* w = W + (size_t)n * K;
+    u16* o = out + (size_t)n * (triple ? 3 * K : K);
+    float acc = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const float v = g ? g[k] * w[k] : w[k];
+        const typename TT::elem hi = TT::from_f32(v);
+        const float hf = TT::to_f32(hi);
+        const typename TT::elem lo = TT::from_f32(v - hf);
+        const u16 hb = __builtin_bit_cast(u16, hi), lb = __builtin_bit_cast(u16, lo);
+        if (triple) { o[k] = hb; o[K + k] = hb; o[2 * K + k] = lb; acc += hf + TT::to_f32(lo); }
+        else o[k] = lb;
+    }
+    if (triple) {
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) srow[n] = red[0];
+    }
+}
+}  // namespace
+
+hipError_t leaf_launch_split16_rows(const float* x, void* out, int rows, int d, int dtype, hipStream_t s) {
+    if (d % 4 || rows < 1) return hipErrorInvalidValue;
+    const size_t n4 = (size_t)rows * (d / 4);
+    const int grid = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+    if (dtype == LEAF_F16) hipLaunchKernelGGL((split16_rows_kernel<F16>), dim3(grid), dim3(256), 0, s, x, (u16*)out, n4, d / 4);
+    else hipLaunchKernelGGL((split16_rows_kernel<BF16>), dim3(grid), dim3(256), 0, s, x, (u16*)out, n4, d / 4);
+    return hipGetLastError();
+}
+
+hipError_t leaf_launch_split_pack(const float* W, const float* g, void* out, float* srow, int N, int K, int triple, int dtype, hipStream_t s) {
+    if (N < 1 || K < 1) return hipErrorInvalidValue;
+    if (dtype == LEAF_F16) hipLaunchKernelGGL((split_pack_kernel<F16>), dim3(N), dim3(256), 0, s, W, g, (u16*)out, srow, K, triple);
+    else hipLaunchKernelGGL((split_pack_kernel<BF16>), dim3(N), dim3(256), 0, s, W, g, (u16*)out, srow, K, triple);
+    return hipGetLastError();
+}
+
 hipError_t leaf_launch_cast(const float* src, void* dst, size_t n, int dtype, hipStream_t s) {
     if (n % 4) return hipErrorInvalidValue;
     size_t n4 = n / 4;

@@ -66,6 +66,21 @@ struct leaf_text {
     const float* fold_c_qkv(const void* w16, int l) const { return fold_aux(w16, l) + 3 * cfg.width; }
     const float* fold_s_fc(const void* w16, int l) const { return fold_aux(w16, l) + 6 * cfg.width; }
     const float* fold_c_fc(const void* w16, int l) const { return fold_aux(w16, l) + 10 * cfg.width; }
+    // ---- optional higher-precision leading blocks (leaf_text_split_pack): hi + lo operand splits for the four GEMMs of blocks
+    // [0, split_blocks) of the forward-only passes.  Caller-owned buffer: per block 26 d^2 16-bit elements -- QKV' [3d][3d] and
+    // c_fc' [4d][3d] as [hi | hi | lo] of the gamma-scaled weights, the lo halves of out_proj [d][d] and c_proj [d][4d] -- then
+    // (256-B aligned) per block the fp32 row sums s_qkv[3d], s_fc[4d] of hi + lo.
+    int split_blocks = 0;
+    const void* split_buf = nullptr;
+    size_t split_block_elems() const { return (size_t)26 * cfg.width * cfg.width; }
+    size_t split_aux_byte_off(int n) const { return ((size_t)n * split_block_elems() * 2 + 255) / 256 * 256; }
+    size_t split_bytes(int n) const { return split_aux_byte_off(n) + (size_t)n * 7 * cfg.width * 4; }
+    const uint16_t* split_qkv3(int l) const { return (const uint16_t*)split_buf + (size_t)l * split_block_elems(); }
+    const uint16_t* split_fc3(int l) const { return split_qkv3(l) + (size_t)9 * cfg.width * cfg.width; }
+    const uint16_t* split_out_lo(int l) const { return split_fc3(l) + (size_t)12 * cfg.width * cfg.width; }
+    const uint16_t* split_proj_lo(int l) const { return split_out_lo(l) + (size_t)cfg.width * cfg.width; }
+    const float* split_s_qkv(int l) const { return (const float*)((const char*)split_buf + split_aux_byte_off(split_blocks)) + (size_t)l * 7 * cfg.width; }
+    const float* split_s_fc(int l) const { return split_s_qkv(l) + 3 * cfg.width; }
 };
 
 size_t leaf_train_ws_bytes(const leaf_text* h, int n_seq);  // api_train.hip

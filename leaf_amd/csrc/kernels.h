@@ -126,6 +126,10 @@ hipError_t leaf_launch_score(const float* feat, const float* anchor, int B, int 
                              int32_t* best_idx, float* best_feat, float* loss, hipStream_t s);
 // device-to-device byte copy in one launch
 hipError_t leaf_launch_copy_bytes(const void* src, void* dst, size_t bytes, hipStream_t s);
+// optional higher-precision blocks (hi + lo operand splits over a 3x longer K): out[rows, 3 d] = [hi | lo | hi] of x[rows, d];
+// weight rows W'[n,:] = (g .* W)[n,:] as [hi | hi | lo] + s[n] = sum (hi + lo) (triple), or the lo halves alone
+hipError_t leaf_launch_split16_rows(const float* x, void* out, int rows, int d, int dtype, hipStream_t s);
+hipError_t leaf_launch_split_pack(const float* W, const float* g, void* out, float* srow, int N, int K, int triple, int dtype, hipStream_t s);
 // fp32 -> 16-bit straight copy (weight packing)
 hipError_t leaf_launch_cast(const float* src, void* dst, size_t n, int dtype, hipStream_t s);
 

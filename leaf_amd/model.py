@@ -222,6 +222,28 @@ class LeafCLIPText:
         out.update(self.extra_state)
         return out
 
+    def set_split_blocks(self, blocks: int):
+        """Precision escape hatch of the forward-only passes (include/leaf_hip.h, leaf_text_split_pack): the four GEMMs of the
+        first ``blocks`` transformer blocks multiply hi + lo 16-bit splits of both operands (three MFMA passes through the
+        unchanged kernels; those blocks run the two-kernel attention path).  0 switches it off.  ``pack()`` refreshes the split
+        weight copies after every optimizer step.  Costs about +13 % of the search's GEMM work per block; on the random-init ViT-L
+        fixture the worst embedding row goes 9.6e-4 -> 8.3e-4 (1 block) -> 7.1e-4 (2 blocks)."""
+        blocks = int(blocks)
+        if blocks < 0 or blocks > self.cfg.layers - 1:
+            raise ValueError(f"split blocks {blocks} out of range 0..{self.cfg.layers - 1}")
+        self.split_blocks = blocks
+        self._split_buf = None
+        if blocks:
+            with torch.cuda.device(self.device):
+                self._split_buf = torch.empty(self._lib.leaf_text_split_bytes(self._h, blocks), dtype=torch.uint8, device=self.device)
+        self._split_pack()
+        return self
+
+    def _split_pack(self):
+        n = getattr(self, "split_blocks", 0)
+        _lib.check(self._lib.leaf_text_split_pack(self._h, _ptr(self.flat), n, _ptr(getattr(self, "_split_buf", None)), self._stream()),
+                   "leaf_text_split_pack")
+
     def copy_from(self, other: "LeafCLIPText"):
         self.flat.copy_(other.flat)
         self.logit_scale = other.logit_scale.clone()
@@ -233,6 +255,8 @@ class LeafCLIPText:
         """fp32 masters -> 16-bit MFMA operand copies (forward dtype; + transposed bf16 when training)."""
         _lib.check(self._lib.leaf_text_pack_weights(self._h, _ptr(self.flat), _ptr(self.w16), _ptr(self.w16_bwd),
                                                     self._stream()), "leaf_text_pack_weights")
+        if getattr(self, "split_blocks", 0):
+            self._split_pack()
         self._packed = True
 
     # ------------------------------------------------------------------ inference

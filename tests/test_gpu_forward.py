@@ -391,3 +391,64 @@ def test_random_shapes_dense_packed_prefix_agree(torch_mod, seed):
     i2, f2, l2 = m.score_candidates(flat, anchor, rho, "l2", want_loss=True, seq_lens=cl, prefix_lens=pl.reshape(-1), kv=kv)
     assert torch_mod.equal(l0, l1) and torch_mod.equal(i0, i1) and torch_mod.equal(f0, f1)
     assert torch_mod.equal(l0, l2) and torch_mod.equal(i0, i2) and torch_mod.equal(f0, f2)
+
+
+def test_split_blocks_precision_escape_hatch(torch_mod, golden_dir):
+    """``set_split_blocks(n)`` -- hi + lo 16-bit splits of both operands in the four GEMMs of the first n
+    transformer blocks of the forward-only passes (three MFMA passes over a 3x longer K through the unchanged kernels; q|k|v,
+    attention and hidden rows stay 16-bit).  On the reference-generated ViT-L fixture (tests/golden/vitl_quickgelu.npz) the worst
+    row falls with every block (oracle emulation: 9.6e-4 -> 8.3e-4 -> 7.1e-4 for n = 0, 1, 2) and is <= 8e-4 at n = 2; n = 0 gives
+    the shipped bits back; EOT trimming, prefix reuse and the fused caption pass stay bit-exact with the option on."""
+    from leaf_amd.model import create_model
+    z = np.load(os.path.join(golden_dir, "vitl_quickgelu.npz"))
+    m = create_model("ViT-L-14-quickgelu", seed=1)
+    toks = z["tokens"]
+    base_out = m.encode_text(toks).cpu().numpy()
+    rows = {0: row_rel_l2(base_out, z["out"])}
+    for n in (1, 2):
+        m.set_split_blocks(n)
+        rows[n] = row_rel_l2(m.encode_text(toks).cpu().numpy(), z["out"])
+    print("[split blocks] worst / median row rel-L2:", {n: (f"{r.max():.3e}", f"{np.median(r):.3e}") for n, r in rows.items()})
+    assert rows[0].max() < TOL_ROW
+    assert rows[1].max() < rows[0].max() - 5e-5 and rows[2].max() < rows[1].max() - 5e-5
+    assert rows[2].max() <= 8.0e-4 and np.median(rows[2]) < 7.0e-4
+    # exactness properties with the option on (ViT-L, 2 split blocks): dense == trimmed == prefix reuse; fused caption pass
+    B, rho = 6, 50
+    base = O.synthetic_tokens(B, seed=61, min_len=20, max_len=50)
+    cand = O.synthetic_candidates(base, rho, seed=62)
+    flat = cand.reshape(-1, 77)
+    neq = cand != base[:, None, :]
+    pl = neq.argmax(-1)
+    pl[~neq.any(-1)] = 77
+    anchor = m.encode_text(base) + 0.2
+    lens = np.repeat(base.argmax(-1) + 1, rho)
+    i0, f0, l0 = m.score_candidates(flat, anchor, rho, "l2", want_loss=True, seq_lens=lens)
+    kv = m.encode_text_kv(base)
+    i1, f1, l1 = m.score_candidates(flat, anchor, rho, "l2", want_loss=True, seq_lens=lens, prefix_lens=pl.reshape(-1), kv=kv)
+    assert torch_mod.equal(l0, l1) and torch_mod.equal(i0, i1) and torch_mod.equal(f0, f1)
+    fused = m.score_candidates_fused(torch_mod.from_numpy(base.astype(np.int32)).cuda(), (base.argmax(-1) + 1).astype(np.int32), flat, anchor,
+                                     rho, lens, pl.reshape(-1), want_features=True, want_loss=True)
+    assert fused is not None and torch_mod.equal(fused[0], i0) and torch_mod.equal(fused[1], f0) and torch_mod.equal(fused[3], l0)
+    m.trim_rows = False
+    i2, f2, l2 = m.score_candidates(flat, anchor, rho, "l2", want_loss=True)
+    m.trim_rows = True
+    assert torch_mod.equal(l0, l2) and torch_mod.equal(i0, i2) and torch_mod.equal(f0, f2)
+    # a weight change reaches the split copies through pack(); option off = the shipped bits
+    m.params["transformer.resblocks.0.mlp.c_fc.weight"].mul_(1.01)
+    m.pack()
+    changed = m.encode_text(toks).cpu().numpy()
+    m.set_split_blocks(0)
+    plain = create_model("ViT-L-14-quickgelu", seed=1)
+    plain.params["transformer.resblocks.0.mlp.c_fc.weight"].mul_(1.01)
+    ref2 = plain.encode_text(toks).cpu().numpy()
+    assert rel_l2(changed, ref2) < 2e-3 and not np.array_equal(changed, ref2)
+    assert np.array_equal(m.encode_text(toks).cpu().numpy(), ref2)
+    # tiny config (2 layers: one split block, K = 3 x 128 through the small-launch kernels)
+    t = _model("tiny-test-quickgelu", 12)
+    zt = np.load(os.path.join(golden_dir, "tiny_quickgelu.npz"))
+    e0 = rel_l2(t.encode_text(zt["tokens"]).cpu().numpy(), zt["out"])
+    t.set_split_blocks(1)
+    e1 = rel_l2(t.encode_text(zt["tokens"]).cpu().numpy(), zt["out"])
+    assert e1 < e0 < TOL_GLOBAL
+    with pytest.raises(ValueError):
+        t.set_split_blocks(2)
