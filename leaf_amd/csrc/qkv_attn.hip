@@ -334,7 +334,11 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QkvAttnArgs p) {
             char* dst = smem + part * HALF + row * 128 + ((chunk ^ sw) << 4) + (fq & 1) * 8;
             const unsigned off = (unsigned)(uintptr_t)(lds_char_t*)dst;
             const unsigned long long pk64 = __builtin_bit_cast(unsigned long long, pk);
+#ifdef LEAF_DIAG_QA_NOSTAGE   // diagnostic only (garbage results): the q|k|v staging stores are not issued -- attributes the launch's LDS bank conflicts
+            asm volatile("" ::"v"(off), "v"(pk64));
+#else
             asm volatile("ds_write_b64 %0, %1" ::"v"(off), "v"(pk64) : "memory");
+#endif
         }
     }
     STAMP(3)
@@ -345,7 +349,11 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QkvAttnArgs p) {
 
     // ================================================================ attention: one wave per sequence, attn_fwd_kernel's body
     const int r16 = lane & 15, g = lane >> 4;
+#ifdef LEAF_DIAG_QA_NOATTN    // diagnostic only (garbage results): no attention stage at all
+    for (int si = wid; si < 0; si += 8) {
+#else
     for (int si = wid; si < nseq; si += 8) {
+#endif
         const unsigned sq = *(const unsigned*)(smem + SEQ_OFF + si * 4);
         const int row_s = sq & 511, len = (sq >> 9) & 127, pfx = (sq >> 16) & 127, slot = (sq >> 23) & 3;
         const int ctx = pfx + len;
