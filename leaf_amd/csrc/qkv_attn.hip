@@ -43,10 +43,15 @@ static_assert(MAXT * 16 == CAPROWS && CAPROWS <= 96, "caption image rows");
 
 // In-kernel stamps (diagnostic builds only: -DLEAF_GEMM_STAMPS): s_memtime at phase boundaries, one 8-slot record per workgroup
 #ifdef LEAF_GEMM_STAMPS
+#ifdef LEAF_QA_PHASES
+constexpr int STAMP_SLOTS = 16;
+#else
+constexpr int STAMP_SLOTS = 8;
+#endif
 #define STAMP(i)                                                                                          \
     if (p.stamps && tid == 0) {                                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                                \
-        ((unsigned long long*)p.stamps)[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime();    \
+        ((unsigned long long*)p.stamps)[(size_t)blockIdx.x * STAMP_SLOTS + (i)] = __builtin_amdgcn_s_memtime();    \
         __builtin_amdgcn_sched_barrier(0);                                                                \
     }
 #else
@@ -349,6 +354,25 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QkvAttnArgs p) {
 
     // ================================================================ attention: one wave per sequence, attn_fwd_kernel's body
     const int r16 = lane & 15, g = lane >> 4;
+    // diagnostic build (make qa_phases: -DLEAF_GEMM_STAMPS -DLEAF_QA_PHASES, caller's buffer 16 slots per workgroup): where wave 0's
+    // attention time goes, summed over its sequences, into slots 8..13 -- 0 table + K fragments, 1 Q + S + mask + max, 2 exp2 + sum +
+    // rcp, 3 P + V^T + PV, 4 pack + store issue, 5 loop overhead.  Every boundary waits for the LDS and for the stamp itself
+    // (~150 ticks, counted in the phase that follows): shares, not times.
+#if defined(LEAF_GEMM_STAMPS) && defined(LEAF_QA_PHASES)
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long ph_prev = __builtin_amdgcn_s_memtime();
+#define PH(i)                                                                             \
+    {                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                       \
+        ph[i] += t_ - ph_prev;                                                            \
+        ph_prev = t_;                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+    }
+#else
+#define PH(i)
+#endif
 #ifdef LEAF_DIAG_QA_NOATTN    // diagnostic only (garbage results): no attention stage at all
     for (int si = wid; si < 0; si += 8) {
 #else
@@ -378,6 +402,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QkvAttnArgs p) {
                 kf[kt][1] = *(const typename TT::vec8*)krow(row, g + 4);
             }
         }
+        PH(0)
 #pragma unroll
         for (int qt = 0; qt < MAXT; ++qt) {
             if (qt < ntl && qt >= qt0 && qt <= qt1) {
@@ -404,6 +429,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QkvAttnArgs p) {
                     sc[kt] = a;
                 }
                 m = rows4_max(m);
+                PH(1)
                 float sum = 0.f;
 #pragma unroll
                 for (int kt = 0; kt <= qt; ++kt)
@@ -415,6 +441,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QkvAttnArgs p) {
                     }
                 sum = rows4_sum(sum);
                 const float inv = __builtin_amdgcn_rcpf(sum);   // (attention.hip: the same v_rcp_f32, not the IEEE division sequence)
+                PH(2)
                 f32x4 o[4];
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -440,6 +467,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QkvAttnArgs p) {
                         }
                     }
                 }
+                PH(3)
                 if (eot >= 0 ? qidx == eot : (qidx < ctx && qidx >= pfx)) {
                     // (32-bit element offset: rows * d * 2 B < 4 GiB is checked by the launcher)
                     u16* op = (u16*)p.out + (unsigned)((eot >= 0 ? s_b + si : r0 + row_s + qidx - pfx) * d + h * HD + 4 * g);
@@ -447,9 +475,16 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QkvAttnArgs p) {
                     for (int dt = 0; dt < 4; ++dt)
                         *(uint2*)(op + dt * 16) = pack4_bounded<TT>(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
                 }
+                PH(4)
             }
         }
+        PH(5)
     }
+#if defined(LEAF_GEMM_STAMPS) && defined(LEAF_QA_PHASES)
+    if (p.stamps && tid == 0)
+        for (int i = 0; i < 6; ++i) ((unsigned long long*)p.stamps)[(size_t)blockIdx.x * 16 + 8 + i] = ph[i];
+#endif
+#undef PH
 #ifdef LEAF_GEMM_STAMPS
     __syncthreads();      // the stamp below then is the end of the SLOWEST wave's sequences
 #endif

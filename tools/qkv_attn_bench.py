@@ -36,6 +36,7 @@ def main():
     svec = Wp.float().sum(1).contiguous()
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     stamps_on = "stamps" in os.environ.get("LEAF_HIP_LIB", "")
+    phases_on = "phases" in os.environ.get("LEAF_HIP_LIB", "")      # make -C leaf_amd/csrc qa_phases
     for stage in (1, 2):
         if stage == 1:
             pfx = np.concatenate([rng.integers(1, L - 1, rho) for L in cap_len]).astype(np.int32)
@@ -70,18 +71,26 @@ def main():
               f"sequences each, max {per_tile.max()}) x {heads} heads: {ms:.3f} ms, {fl / ms / 1e9:.0f} TFLOP/s of projection work", flush=True)
         if stamps_on:
             nblk = nt * heads
-            stamps = torch.zeros(nblk * 8, dtype=torch.int64, device=dev)
+            slots = 16 if phases_on else 8
+            stamps = torch.zeros(nblk * slots, dtype=torch.int64, device=dev)
             lib.leaf_debug_gemm_stamps(C.c_void_p(stamps.data_ptr()))
             lib.leaf_op_qkv_attn(*args)
             torch.cuda.synchronize()
             lib.leaf_debug_gemm_stamps(None)
-            s = stamps.cpu().numpy().reshape(nblk, 8)[:, :6].astype(np.float64)
+            raw = stamps.cpu().numpy().reshape(nblk, slots)
+            s = raw[:, :6].astype(np.float64)
             seg = np.diff(s, axis=1)
             tot = s[:, 5] - s[:, 0]
             names = ["first DMA wait", "K loop", "tables + caption DMA issue + staging", "wait for DMA / barrier", "attention"]
             print(f"   median workgroup {np.median(tot):.0f} ticks ({nblk} workgroups)")
             for i, nm in enumerate(names):
                 print(f"   {nm:40s} median {np.median(seg[:, i]):8.0f}  mean {seg[:, i].mean():8.0f}  ({100 * seg[:, i].sum() / tot.sum():5.1f}%)")
+            if phases_on:
+                ph = raw[:, 8:14].astype(np.float64)
+                pn = ["table + K fragments", "Q + S MFMAs + mask + max", "exp2 + sum + rcp", "P + V^T reads + PV MFMAs", "pack + store issue", "loop overhead"]
+                print(f"   wave 0's attention stage, phases serialised by waits (shares, not times): total mean {ph.sum(1).mean():.0f} ticks")
+                for i, nm in enumerate(pn):
+                    print(f"      {nm:36s} mean {ph[:, i].mean():8.0f}  ({100 * ph[:, i].sum() / ph.sum():5.1f}%)")
 
 
 if __name__ == "__main__":
