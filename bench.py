@@ -43,7 +43,7 @@ PEAK_HBM_GBS = 8000.0       # HBM3E spec peak (same table; ~6.3 TB/s achievable)
 TRAFFIC_GLOB = "r05_traffic*.json"   # PMC summaries, one per workload (tools/pmc_passes.sh, tools/pmc_summary.py)
 FAMILY = {0: "gemm_nt_kernel", 1: "gemm_nt256_kernel", 4: "gemm_nt256_half_kernel", 6: "gemm_nt64_ring_kernel", 7: "gemm_nt128pp_kernel",
           8: "qkv_attn_kernel"}
-EPI_NAMES = {0: "store16", 1: "act16", 2: "resid32", 3: "store32", 4: "actgrad16", 5: "lnfold16", 6: "lnfold_act16", 7: "resid32+x16+stats"}
+EPI_NAMES = {0: "store16", 1: "act16", 2: "resid32", 3: "store32", 4: "actgrad16", 5: "lnfold16", 6: "lnfold_act16", 7: "resid32+x16+stats", 8: "resid16+8+stats"}
 
 
 def kernel_sources_hash():
@@ -465,16 +465,16 @@ def main():
         psteps = max(prof["steps"], 1)          # timed steps whose launches carry events
         for i in range(n_out.value):
             key, N, K, cnt = info[4 * i], info[4 * i + 1], info[4 * i + 2], info[4 * i + 3]
-            big, key = key >= 256, key % 256          # launches of >= 16,384 rows (the scoring passes) are grouped apart
+            big, key = key >= 1024, key % 1024        # launches of >= 16,384 rows (the scoring passes) are grouped apart
             if ms[i] <= 0:
                 continue
-            kname = f"{FAMILY.get(key // 16, 'gemm?')}<{'F16' if (key // 8) % 2 == 1 else 'BF16'},{key % 8}>"
+            kname = f"{FAMILY.get(key // 32, 'gemm?')}<{'F16' if (key // 16) % 2 == 1 else 'BF16'},{key % 16}>"
             tf = fl[i] / (ms[i] * 1e-3) / 1e12
             gbs = by[i] / (ms[i] * 1e-3) / 1e9
             # which roofline bounds this shape: algorithmic FLOP per algorithmic byte against the machine balance
             intensity = fl[i] / by[i]
             bound = "hbm" if intensity < PEAK_TFLOPS_16BIT * 1e12 / (PEAK_HBM_GBS * 1e9) * 0.5 else "mfma"
-            shapes.append({"kernel": kname, "epilogue": EPI_NAMES.get(key % 8), "N": N, "K": K, "launches": cnt, "big_launches": big,
+            shapes.append({"kernel": kname, "epilogue": EPI_NAMES.get(key % 16), "N": N, "K": K, "launches": cnt, "big_launches": big,
                            "rows_per_launch": rows[i] / cnt, "ms_per_step": ms[i] / psteps, "tflops": tf,
                            "mfma_frac": tf / PEAK_TFLOPS_16BIT, "algorithmic_gbs": gbs, "hbm_frac": gbs / PEAK_HBM_GBS,
                            "flop_per_byte": intensity, "bound": bound, "algorithmic_bytes_per_launch": by[i] / cnt})
@@ -483,7 +483,7 @@ def main():
         shapes.sort(key=lambda s: -s["ms_per_step"])
         dom_key = max(per_key, key=lambda k: per_key[k][0])
         dom_ms, dom_fl, dom_bytes, dom_cnt = per_key[dom_key]
-        dom_name = f"{FAMILY.get(dom_key // 16, 'gemm?')}<{'F16' if (dom_key // 8) % 2 == 1 else 'BF16'},{dom_key % 8}>"
+        dom_name = f"{FAMILY.get(dom_key // 32, 'gemm?')}<{'F16' if (dom_key // 16) % 2 == 1 else 'BF16'},{dom_key % 16}>"
         achieved = dom_fl / (dom_ms * 1e-3) / 1e12
         gemm_total_ms = sum(v[0] for v in per_key.values())
         gemm_total_fl = sum(v[1] for v in per_key.values())
@@ -549,7 +549,7 @@ def main():
             "roofline": {
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS_16BIT, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_TFLOPS_16BIT, "traffic": traffic, "traffic_note": traffic_note, "traffic_kernels": traffic_kernels,
-                "kernel": f"{dom_name} {EPI_NAMES.get(dom_key % 8)}",
+                "kernel": f"{dom_name} {EPI_NAMES.get(dom_key % 16)}",
                 "algorithmic_bytes_per_launch": dom_bytes / dom_cnt if dom_bytes else None,
                 "launches": int(dom_cnt), "avg_launch_ms": dom_ms / dom_cnt,
                 "algorithmic_gflop_per_launch": dom_fl / dom_cnt / 1e9,

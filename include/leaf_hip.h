@@ -46,7 +46,10 @@ int leaf_text_create(const leaf_text_cfg* cfg, int fwd_dtype, leaf_text_t* out);
 void leaf_text_destroy(leaf_text_t h);
 int leaf_text_set_chunk(leaf_text_t h, int seqs_per_chunk); /* sequences processed per pass through the layers */
 /* options: "chunk" (as above), "last_layer_trim" (0/1, default 1: the last block's attention output, out-projection and
- * MLP are computed for the pooled EOT row only -- exact, every op after attention is row-wise) */
+ * MLP are computed for the pooled EOT row only -- exact, every op after attention is row-wise), "compact_resid" (0/1, default 1:
+ * the residual stream of the LN-folded forward-only passes as the 16-bit copy + a remainder byte per element instead of an fp32
+ * row beside that copy -- see leaf_op_gemm_resid_ln8 below; 0, or LEAF_COMPACT_RESID=0, keeps fp32 rows; the split blocks of
+ * leaf_text_split_pack always run on fp32 rows), and the A/B switches "streams", "ln_fold", "fuse_attn", "normalize_fare" */
 int leaf_text_set_option(leaf_text_t h, const char* name, int value);
 
 /* flat parameter layout */
@@ -314,6 +317,16 @@ int leaf_op_gemm_ld(int dtype, int epi, const void* A, int lda, const void* B, i
  * sum_k Bp[n,k], c[n] = beta . W[n,:] + bias[n]; act: -1 none, 0 GELU, 1 QuickGELU. */
 int leaf_op_gemm_resid_ln(int dtype, const void* A, const void* B, float* C, const float* bias, void* x16, void* stat, int M, int N,
                           int K, leaf_stream_t s);
+/* The residual stream of the LN-folded forward-only passes in 16 + 8 bits (option 'compact_resid', default on): a residual value x is
+ * held as x16 = 16-bit(x) -- the copy the next GEMM multiplies anyway -- and lo8 = the remainder x - x16 as a signed byte in 1/256ths of x16's unit in the last place, i.e.
+ * to 2^-19 relative (fp16) in 3 bytes instead of an fp32 row beside the 16-bit copy (6 bytes).  leaf_op_gemm_resid_ln8: the producer above
+ * on that format, (x16, lo8) [M,N] updated IN PLACE, stat as above.  leaf_op_resid_pack / _unpack: the format itself, element-wise
+ * (n % 4 == 0).  The reference's residual stream is fp32 (transformer.py:254-265); the difference is far inside the 16-bit operand
+ * rounding of every GEMM (tests/test_gpu_kernels.py, test_compact_residual_*). */
+int leaf_op_gemm_resid_ln8(int dtype, const void* A, const void* B, void* lo8, const float* bias, void* x16, void* stat, int M, int N,
+                           int K, leaf_stream_t s);
+int leaf_op_resid_pack(int dtype, const float* x, void* x16, void* lo8, size_t n, leaf_stream_t s);
+int leaf_op_resid_unpack(int dtype, const void* x16, const void* lo8, float* x, size_t n, leaf_stream_t s);
 int leaf_op_ln_finalize(const void* stat, int ld, int rows, int ngroups, float eps, void* rowstat, leaf_stream_t s);
 int leaf_op_gemm_lnfold(int dtype, int act, const void* A, const void* Bp, void* C16, const float* c_vec, const float* s_vec,
                         const void* rowstat, int M, int N, int K, leaf_stream_t s);

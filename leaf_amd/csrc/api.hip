@@ -42,6 +42,7 @@ extern "C" int leaf_text_create(const leaf_text_cfg* cfg, int fwd_dtype, leaf_te
     { const char* e = getenv("LEAF_LAST_TRIM"); h->last_trim = (e && e[0] == '0') ? 0 : 1; }
     { const char* e = getenv("LEAF_LN_FOLD"); h->ln_fold = (e && e[0] == '0') ? 0 : 1; }
     { const char* e = getenv("LEAF_FUSE_ATTN"); h->fuse_attn = (e && e[0] == '0') ? 0 : 1; }
+    { const char* e = getenv("LEAF_COMPACT_RESID"); h->compact_resid = (e && e[0] == '0') ? 0 : 1; }
     {   // gradient path: fp16 + per-step power-of-two loss scale unless LEAF_GRAD_DTYPE=bf16
         const char* e = getenv("LEAF_GRAD_DTYPE");
         h->grad_dtype = (e && (e[0] == 'b' || e[0] == 'B')) ? LEAF_DTYPE_BF16 : LEAF_DTYPE_FP16;
@@ -112,6 +113,7 @@ extern "C" int leaf_text_set_option(leaf_text_t h, const char* name, int value) 
     if (!strcmp(name, "normalize_fare")) { h->normalize_fare = value ? 1 : 0; return 0; }
     if (!strcmp(name, "ln_fold")) { h->ln_fold = (value && h->cfg.width % 64 == 0) ? 1 : 0; return 0; }
     if (!strcmp(name, "fuse_attn")) { h->fuse_attn = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "compact_resid")) { h->compact_resid = value ? 1 : 0; return 0; }
     leaf_set_error("unknown option '%s'", name);
     return 1;
 }
@@ -200,8 +202,8 @@ int leaf_gemm(int dtype, int epi, const void* A, int lda, const void* B, int ldb
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.act = act; g.aux_f16 = aux_f16; g.beta = beta; g.stamps = nullptr; g.alpha = alpha; g.ngroup = 0;
     g.ln_s = nullptr; g.rowstat = nullptr; g.stat_out = nullptr; g.x16 = nullptr; g.stat_ld = 0; g.ldx16 = 0; g.ln_eps = 0.f; g.stagger = 0;
-    if (epi == EPI_LNFOLD_T || epi == EPI_LNFOLD_ACT_T || epi == EPI_RESID_LN) {
-        const bool fold = epi != EPI_RESID_LN;
+    if (epi == EPI_LNFOLD_T || epi == EPI_LNFOLD_ACT_T || epi == EPI_RESID_LN || epi == EPI_RESID_LN8) {
+        const bool fold = epi != EPI_RESID_LN && epi != EPI_RESID_LN8;
         if (!ln || (fold && (!ln->ln_s || !ln->rowstat || !bias)) || (!fold && (!ln->x16 || !ln->stat_out || N % 64 || ln->stat_ld < M))) {
             leaf_set_error("gemm: LN-folding operands missing or misshapen (epilogue %d)", epi);
             return 1;
@@ -211,7 +213,7 @@ int leaf_gemm(int dtype, int epi, const void* A, int lda, const void* B, int ldb
     }
     if (!g_prof_on) return leaf_check(leaf_launch_gemm(g, dtype, epi, s), "gemm");
     ProfRec r;
-    r.key = leaf_gemm_family(g, epi) * 16 + dtype * 8 + epi;
+    r.key = LEAF_PROF_KEY(leaf_gemm_family(g, epi), dtype, epi);
     r.M = M; r.N = N; r.K = K;
     r.flops = 2.0 * (double)M * (double)N * (double)K;
     {   // algorithmic bytes of the launch: both operands once + the output (+ the fp32 read of a residual/accumulate)
@@ -222,6 +224,8 @@ int leaf_gemm(int dtype, int epi, const void* A, int lda, const void* B, int ldb
                   (epi == EPI_RESID_LN ? 2.0 * M * N + 8.0 * M * (N / 64) : 0.0) +                    // 16-bit copy + statistics
                   ((epi == EPI_LNFOLD_T || epi == EPI_LNFOLD_ACT_T) ? 8.0 * M : 0.0);                  // (mean, rstd) per row
     }
+    // 16 + 8-bit residual stream: 3 bytes read + 3 written per output element, statistics
+    if (epi == EPI_RESID_LN8) r.bytes = 2.0 * ((double)M * K + (double)N * K) + 6.0 * (double)M * N + 8.0 * M * (N / 64);
     LEAF_TRY(hipEventCreate(&r.a));
     LEAF_TRY(hipEventCreate(&r.b));
     LEAF_TRY(hipEventRecord(r.a, s));
@@ -236,7 +240,7 @@ int leaf_gemm(int dtype, int epi, const void* A, int lda, const void* B, int ldb
 int leaf_qkv_attn(const QkvAttnArgs& a, int dtype, hipStream_t s) {
     if (!g_prof_on) return leaf_check(leaf_launch_qkv_attn(a, dtype, s), "qkv_attn");
     ProfRec r;
-    r.key = 8 * 16 + dtype * 8 + EPI_LNFOLD_T;
+    r.key = LEAF_PROF_KEY(8, dtype, EPI_LNFOLD_T);
     r.M = a.M; r.N = 3 * a.d; r.K = a.K;
     r.flops = 2.0 * (double)a.M * (3.0 * a.d) * (double)a.K;
     r.bytes = 2.0 * ((double)a.M * a.K + 3.0 * a.d * a.K) + 2.0 * (double)(a.eot_pos ? a.n_seq : a.M) * a.d + 8.0 * a.M;
@@ -263,7 +267,7 @@ extern "C" int leaf_prof_pause(int paused) {
     return 0;
 }
 
-// Stops recording, waits for the recorded events and sums per key (= kernel_family*16 + dtype*8 + epilogue id, < 128):
+// Stops recording, waits for the recorded events and sums per key (= LEAF_PROF_KEY: kernel_family*32 + dtype*16 + epilogue id, < 512):
 // ms[key], flops[key], bytes[key] (algorithmic operand + output bytes, may be null), count[key].
 extern "C" int leaf_prof_end(double* ms, double* flops, double* bytes, int64_t* count, int n_keys) {
     g_prof_on = false;
@@ -281,7 +285,7 @@ extern "C" int leaf_prof_end(double* ms, double* flops, double* bytes, int64_t* 
 
 // Same as leaf_prof_end but grouped by (key, N, K) -- one line per GEMM SHAPE of each kernel, so that e.g. the two
 // residual GEMMs (out_proj: N = K = d, HBM-bound; c_proj: K = 4d, MFMA-bound) are reported separately.  info[i] =
-// {key (+ 256 for launches of >= 16,384 rows), N, K, launches}; rows[i] = sum of M over the launches.  Returns the number of groups in *n_out (<= max_groups).
+// {key (+ LEAF_PROF_BIG = 1024 for launches of >= 16,384 rows), N, K, launches}; rows[i] = sum of M over the launches.  Returns the number of groups in *n_out (<= max_groups).
 extern "C" int leaf_prof_end_shapes(double* ms, double* flops, double* bytes, int64_t* rows, int32_t* info, int max_groups,
                                     int* n_out) {
     g_prof_on = false;
@@ -291,8 +295,8 @@ extern "C" int leaf_prof_end_shapes(double* ms, double* flops, double* bytes, in
         float t = 0.f;
         LEAF_TRY(hipEventElapsedTime(&t, r.a, r.b));
         // launches of >= 16,384 rows (the scoring passes) and the small B-caption launches of the same kernel and shape are
-        // reported apart: group key = key + 256 for the big ones
-        const int gkey = r.key + (r.M >= 16384 ? 256 : 0);
+        // reported apart: group key = key + LEAF_PROF_BIG for the big ones
+        const int gkey = r.key + (r.M >= 16384 ? LEAF_PROF_BIG : 0);
         int i = 0;
         for (; i < n; ++i)
             if (info[4 * i] == gkey && info[4 * i + 1] == r.N && info[4 * i + 2] == r.K) break;
@@ -381,6 +385,8 @@ int forward_chunk(const leaf_text* h, const float* P, const uint16_t* W, const i
     // [rows, 3d] split copy of the fp32 residual rows lives in buffers that are dead at that point: the hidden buffer in front of
     // the QKV GEMM, the chunk's own q|k|v scratch in front of c_fc (these blocks run the two-kernel attention path).
     const int nsplit = (fold && h->split_buf) ? h->split_blocks : 0;
+    // 16 + 8-bit residual stream (engine.h compact_resid): b.x holds the [rows, d] remainder bytes, b.x16 is the other half
+    const bool lo8 = fold && h->compact_resid && nsplit == 0 && leaf_project_rows_ok(d, c.embed_dim);
     auto qkv_gemm = [&](int l, int m, const GemmLn& g, const void* xn) -> int {
         const LayerOff& o = h->layer[l];
         if (!fold) return leaf_gemm(dt, EPI_STORE_T, xn, d, W + h->w16_qkv(l), d, b.qkv, 3 * d, P + o.qkv_b, nullptr, m, 3 * d, d, 0, s);
@@ -418,13 +424,18 @@ int forward_chunk(const leaf_text* h, const float* P, const uint16_t* W, const i
             if (leaf_gemm(dt, EPI_RESID_F32, A, K, Wl, K, x, d, bias, nullptr, m, d, K, 0, s)) return 1;
             Wl = w_lo; bias = nullptr;
         }
+        if (lo8 && x == b.x) {
+            // (the last block's c_proj has no LayerNorm behind it: its statistics go to the chunk's buffers all the same, unread)
+            if (leaf_gemm(dt, EPI_RESID_LN8, A, K, Wl, K, x, d, bias, nullptr, m, d, K, 0, s, 0.f, 0, nullptr, &ln)) return 1;
+            return g ? leaf_check(leaf_launch_ln_finalize(ln.stat_out, ln.stat_ld, m, d / 64, ln.eps, const_cast<float2*>(ln.rowstat), s), "ln_finalize") : 0;
+        }
         if (!(fold && g)) return leaf_gemm(dt, EPI_RESID_F32, A, K, Wl, K, x, d, bias, nullptr, m, d, K, 0, s);
         if (leaf_gemm(dt, EPI_RESID_LN, A, K, Wl, K, x, d, bias, nullptr, m, d, K, 0, s, 0.f, 0, nullptr, g)) return 1;
         return leaf_check(leaf_launch_ln_finalize(g->stat_out, g->stat_ld, m, d / 64, g->eps, const_cast<float2*>(g->rowstat), s), "ln_finalize");
     };
     if (fold) {
         LEAF_TRY(leaf_launch_embed_fold(tokens, P + h->tok_emb, P + h->pos_emb, b.x, b.x16, b.stat, rows, rows, cs, map, d,
-                                        c.vocab_size, dt, s));
+                                        c.vocab_size, dt, s, nullptr, lo8));
         LEAF_TRY(leaf_launch_ln_finalize(b.stat, rows, rows, d / 64, c.ln_eps, b.rowstat, s));
     }
     else
@@ -482,6 +493,26 @@ int forward_chunk(const leaf_text* h, const float* P, const uint16_t* W, const i
                 LEAF_TRY(leaf_launch_eot_positions(tokens, b.eot, cs, map, s));
                 LEAF_TRY(leaf_launch_attention_fwd(b.qkv, kvl, b.a, cs, map, c.heads, d, dt, s, b.eot, max_len));
             }
+            if (lo8) {
+                // 16 + 8-bit stream: the pooled rows stay in that format through the block (the same EPI_RESID_LN8 arithmetic as the
+                // untrimmed pass: bit-identical), scratch = [x16 rows | remainder rows | hidden rows], 11 d cs bytes; the fp32 rows the
+                // final LayerNorm + projection read are decoded into the hidden rows' space once c_proj has consumed them
+                uint16_t* g16 = (uint16_t*)b.qkv;
+                unsigned char* g8 = (unsigned char*)b.qkv + align_up((size_t)cs * d * 2, 256);
+                uint16_t* hb = (uint16_t*)(g8 + align_up((size_t)cs * d, 256));
+                LEAF_TRY(leaf_launch_gather_rows_pair(b.x16, b.x, b.eot, g16, g8, cs, map, d, s));
+                GemmLn lg = ln;
+                lg.stat_ld = cs; lg.x16 = g16;
+                if (leaf_gemm(dt, EPI_RESID_LN8, b.a, d, W + h->w16_out(l), d, g8, d, P + o.out_b, nullptr, cs, d, d, 0, s, 0.f, 0, nullptr, &lg)) return 1;
+                LEAF_TRY(leaf_launch_ln_finalize(lg.stat_out, lg.stat_ld, cs, d / 64, lg.eps, const_cast<float2*>(lg.rowstat), s));
+                if (fc_gemm(l, cs, lg, b.a, hb)) return 1;
+                if (leaf_gemm(dt, EPI_RESID_LN8, hb, 4 * d, W + h->w16_proj(l), 4 * d, g8, d, P + o.proj_b, nullptr, cs, d, 4 * d, 0, s, 0.f, 0, nullptr, &lg)) return 1;
+                float* xg = (float*)hb;
+                LEAF_TRY(leaf_launch_resid_unpack(g16, g8, xg, (size_t)cs * d, dt, s));
+                LEAF_TRY(leaf_launch_project_rows(xg, P + h->lnf_w, P + h->lnf_b, c.ln_eps, P + h->text_proj, xg + (size_t)cs * d, out,
+                                                  cs, d, c.embed_dim, normalize, s));
+                return 0;
+            }
             float* xg = (float*)b.qkv;
             uint16_t* hb = (uint16_t*)((char*)b.qkv + align_up((size_t)cs * d * 4, 256));
             LEAF_TRY(leaf_launch_gather_rows(b.x, b.eot, xg, cs, map, d, s));
@@ -514,7 +545,8 @@ int forward_chunk(const leaf_text* h, const float* P, const uint16_t* W, const i
         float* xg = (float*)b_in.qkv;
         float* xn = (float*)((char*)b_in.qkv + align_up((size_t)cs * d * 4, 256));
         LEAF_TRY(leaf_launch_eot_positions(tokens, b.eot, cs, map, s));
-        LEAF_TRY(leaf_launch_gather_rows(b.x, b.eot, xg, cs, map, d, s));
+        if (lo8) LEAF_TRY(leaf_launch_gather_rows_lo8(b.x16, b.x, b.eot, xg, cs, map, d, dt, s));
+        else LEAF_TRY(leaf_launch_gather_rows(b.x, b.eot, xg, cs, map, d, s));
         LEAF_TRY(leaf_launch_project_rows(xg, P + h->lnf_w, P + h->lnf_b, c.ln_eps, P + h->text_proj, xn, out, cs, d,
                                           c.embed_dim, normalize, s));
         return 0;
@@ -792,6 +824,19 @@ extern "C" int leaf_op_gemm_resid_ln(int dtype, const void* A, const void* B, fl
     GemmLn ln;
     ln.x16 = x16; ln.ldx16 = N; ln.stat_out = (float2*)stat; ln.stat_ld = M;
     return leaf_gemm(dtype, EPI_RESID_LN, A, K, B, K, C, N, bias, nullptr, M, N, K, 0, (hipStream_t)s, 0.f, 0, nullptr, &ln);
+}
+// the same on the 16 + 8-bit residual stream: (x16, lo8) <- encode(decode(x16, lo8) + A B^T + bias) in place, statistics as above
+extern "C" int leaf_op_gemm_resid_ln8(int dtype, const void* A, const void* B, void* lo8, const float* bias, void* x16, void* stat,
+                                      int M, int N, int K, leaf_stream_t s) {
+    GemmLn ln;
+    ln.x16 = x16; ln.ldx16 = N; ln.stat_out = (float2*)stat; ln.stat_ld = M;
+    return leaf_gemm(dtype, EPI_RESID_LN8, A, K, B, K, lo8, N, bias, nullptr, M, N, K, 0, (hipStream_t)s, 0.f, 0, nullptr, &ln);
+}
+extern "C" int leaf_op_resid_pack(int dtype, const float* x, void* x16, void* lo8, size_t n, leaf_stream_t s) {
+    return leaf_check(leaf_launch_resid_pack(x, x16, lo8, n, dtype, (hipStream_t)s), "resid_pack");
+}
+extern "C" int leaf_op_resid_unpack(int dtype, const void* x16, const void* lo8, float* x, size_t n, leaf_stream_t s) {
+    return leaf_check(leaf_launch_resid_unpack(x16, lo8, x, n, dtype, (hipStream_t)s), "resid_unpack");
 }
 // ... the merge of the partials into rowstat[M] = (mean, rstd), and the consuming GEMM: C16 = [act](rstd[m] (A Bp^T - mean[m] s[n]) + c[n]); act < 0: none
 extern "C" int leaf_op_ln_finalize(const void* stat, int ld, int rows, int ngroups, float eps, void* rowstat, leaf_stream_t s) {

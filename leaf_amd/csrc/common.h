@@ -1,5 +1,6 @@
 // Shared device helpers for the LEAF text-path kernels (gfx950 / CDNA4 only).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -78,6 +79,46 @@ __device__ __forceinline__ void unpack4(uint2 u, float (&o)[4]) {
     typename TT::vec4 v = __builtin_bit_cast(typename TT::vec4, u);
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[i] = TT::to_f32(v[i]);
+}
+
+// ---- Residual stream of the forward-only passes in 16 + 8 bits (api.hip "compact residual").  A residual value x is kept as
+// hi = the 16-bit copy the next GEMM multiplies anyway (x16) and lo8 = the remainder x - hi in 1/256ths of hi's unit in the last
+// place, a signed byte: x - hi is exact in fp32 and at most half an ulp of hi, so q = rne((x - hi) * 2^(8 + MANT - e)) lies in
+// [-128, 128] (e = hi's binary exponent, MANT = 10 for fp16, 7 for bf16; clamped to +-127) and x comes back to 2^-(MANT + 9)
+// relative -- 2^-19 for fp16, against fp32's 2^-24 and the 2^-11 of every GEMM operand -- from 3 bytes instead of the 6 of an
+// fp32 row beside its 16-bit copy.  Both scale factors are powers of two built from the exponent field of float(hi) (for hi = 0
+// and for fp16-subnormal hi the factors are off, the remainder then clamps or vanishes: |x| < 2^-14, an error below 2^-25).
+template <class TT> struct ResidLo;
+template <> struct ResidLo<F16> { static constexpr int mant = 10; };
+template <> struct ResidLo<BF16> { static constexpr int mant = 7; };
+template <class TT>
+__device__ __forceinline__ unsigned resid_lo1(float x, float h) {
+    const unsigned e8 = __builtin_bit_cast(unsigned, h) & 0x7F800000u;
+    const float up = __builtin_bit_cast(float, ((unsigned)(254 + 8 + ResidLo<TT>::mant) << 23) - e8);      // 2^(8 + mant - e)
+    const float r = __builtin_amdgcn_fmed3f((x - h) * up, -127.f, 127.f);
+    // + 1.5 * 2^23: the sum's rounding IS round-to-nearest-even to an integer, which then sits in the low mantissa bits (two's complement)
+    return __builtin_bit_cast(unsigned, r + 12582912.f) & 0xFFu;
+}
+// four residual values + their packed 16-bit copy -> the four remainder bytes (one dword)
+template <class TT>
+__device__ __forceinline__ unsigned resid_lo4(float a, float b, float c, float d, uint2 hi) {
+    float h[4];
+    unpack4<TT>(hi, h);
+    return resid_lo1<TT>(a, h[0]) | (resid_lo1<TT>(b, h[1]) << 8) | (resid_lo1<TT>(c, h[2]) << 16) | (resid_lo1<TT>(d, h[3]) << 24);
+}
+template <class TT>
+__device__ __forceinline__ float resid_decode1(float h, int q) {
+    const unsigned e8 = __builtin_bit_cast(unsigned, h) & 0x7F800000u;
+    const float down = __builtin_bit_cast(float, e8 - ((unsigned)(8 + ResidLo<TT>::mant) << 23));         // 2^(e - 8 - mant)
+    return __builtin_fmaf((float)q, down, h);
+}
+template <class TT>
+__device__ __forceinline__ float4 resid_decode4(uint2 hi, unsigned lo) {
+    float h[4];
+    unpack4<TT>(hi, h);
+    const int w = (int)lo;
+    return float4{resid_decode1<TT>(h[0], (int)(signed char)(w & 0xFF)), resid_decode1<TT>(h[1], (int)(signed char)((w >> 8) & 0xFF)),
+                  resid_decode1<TT>(h[2], (int)(signed char)((w >> 16) & 0xFF)), resid_decode1<TT>(h[3], w >> 24)};
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

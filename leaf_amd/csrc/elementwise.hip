@@ -92,7 +92,8 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x_in,
 // operand of the first QKV GEMM) and the (sum, M2) statistics of each 64-column group.  One wave per row; a lane holds the
 // 4-element chunks lane, lane + 64, ...: a group is 16 consecutive lanes of one iteration, reduced in the same tree as the
 // GEMM epilogues (row16_sum).
-template <class TT>
+// LO8: the residual stream in 16 + 8 bits (common.h resid_lo4): x_out is the [rows, d] BYTE matrix of remainders, no fp32 row is written
+template <class TT, bool LO8>
 __global__ __launch_bounds__(256) void embed_fold_kernel(const float* __restrict__ delta, const int32_t* __restrict__ tokens,
                                                          const float* __restrict__ tok_emb, const float* __restrict__ pos_emb,
                                                          float* __restrict__ x_out, u16* __restrict__ x16,
@@ -121,8 +122,10 @@ __global__ __launch_bounds__(256) void embed_fold_kernel(const float* __restrict
                 a = float4{a.x + dl.x, a.y + dl.y, a.z + dl.z, a.w + dl.w};
             }
             v = float4{a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w};
-            *(float4*)(xo + 4 * c) = v;
-            *(uint2*)(x16 + (size_t)row * d + 4 * c) = pack4<TT>(v.x, v.y, v.z, v.w);
+            const uint2 hi = pack4<TT>(v.x, v.y, v.z, v.w);
+            if constexpr (LO8) *(unsigned*)((unsigned char*)x_out + (size_t)row * d + 4 * c) = resid_lo4<TT>(v.x, v.y, v.z, v.w, hi);
+            else *(float4*)(xo + 4 * c) = v;
+            *(uint2*)(x16 + (size_t)row * d + 4 * c) = hi;
         }
         const float gs = row16_sum(lnfold_sum4(v.x, v.y, v.z, v.w));
         const float gq = row16_sum(lnfold_dev4(v.x, v.y, v.z, v.w, gs * (1.0f / 64.0f)));
@@ -394,6 +397,49 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
     for (int c = lane; c < (d >> 2); c += 64) *(float4*)(out + (size_t)n * d + 4 * c) = *(const float4*)(src + 4 * c);
 }
 
+// the same out of the 16 + 8-bit residual stream: fp32 rows = decode(x16, lo8)
+template <class TT>
+__global__ __launch_bounds__(256) void gather_rows_lo8_kernel(const u16* __restrict__ x16, const unsigned char* __restrict__ lo8,
+                                                              const int32_t* __restrict__ eot_pos, float* __restrict__ out, int n_seq,
+                                                              RowMap map, int d) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= n_seq) return;
+    const int sg = map.s0 + n;
+    const size_t r = (size_t)seq_row(map, sg) + eot_pos[n] - seq_prefix(map, sg);
+    for (int c = lane; c < (d >> 2); c += 64)
+        *(float4*)(out + (size_t)n * d + 4 * c) = resid_decode4<TT>(*(const uint2*)(x16 + r * d + 4 * c), *(const unsigned*)(lo8 + r * d + 4 * c));
+}
+
+// the pooled rows of the 16 + 8-bit stream as they are (both halves copied): the last block then runs on them in the same format
+__global__ __launch_bounds__(256) void gather_rows_pair_kernel(const u16* __restrict__ x16, const unsigned char* __restrict__ lo8,
+                                                               const int32_t* __restrict__ eot_pos, u16* __restrict__ o16,
+                                                               unsigned char* __restrict__ o8, int n_seq, RowMap map, int d) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= n_seq) return;
+    const int sg = map.s0 + n;
+    const size_t r = (size_t)seq_row(map, sg) + eot_pos[n] - seq_prefix(map, sg);
+    for (int c = lane; c < (d >> 2); c += 64) {
+        *(uint2*)(o16 + (size_t)n * d + 4 * c) = *(const uint2*)(x16 + r * d + 4 * c);
+        *(unsigned*)(o8 + (size_t)n * d + 4 * c) = *(const unsigned*)(lo8 + r * d + 4 * c);
+    }
+}
+
+// kernel hooks of the 16 + 8-bit residual format itself (tests): fp32 -> (x16, lo8) and back
+template <class TT>
+__global__ __launch_bounds__(256) void resid_pack_kernel(const float* __restrict__ x, u16* __restrict__ x16, unsigned char* __restrict__ lo8, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = *(const float4*)(x + 4 * i);
+        const uint2 hi = pack4<TT>(v.x, v.y, v.z, v.w);
+        *(uint2*)(x16 + 4 * i) = hi;
+        *(unsigned*)(lo8 + 4 * i) = resid_lo4<TT>(v.x, v.y, v.z, v.w, hi);
+    }
+}
+template <class TT>
+__global__ __launch_bounds__(256) void resid_unpack_kernel(const u16* __restrict__ x16, const unsigned char* __restrict__ lo8, float* __restrict__ x, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256)
+        *(float4*)(x + 4 * i) = resid_decode4<TT>(*(const uint2*)(x16 + 4 * i), *(const unsigned*)(lo8 + 4 * i));
+}
+
 template <class TT>
 __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, u16* __restrict__ dst, size_t n4) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -422,15 +468,13 @@ hipError_t leaf_launch_embed_ln(const int32_t* tokens, const float* tok_emb, con
 
 hipError_t leaf_launch_embed_fold(const int32_t* tokens, const float* tok_emb, const float* pos_emb, float* x, void* x16,
                                   float2* stat, int stat_ld, int rows, int n_seq, RowMap map, int d, int vocab, int dtype,
-                                  hipStream_t s, const float* delta) {
+                                  hipStream_t s, const float* delta, bool lo8) {
     if (d % 64 || d > 256 * MAXCH) return hipErrorInvalidValue;
     dim3 grid((rows + 3) / 4), blk(256);
-    if (dtype == LEAF_F16)
-        hipLaunchKernelGGL((embed_fold_kernel<F16>), grid, blk, 0, s, delta, tokens, tok_emb, pos_emb, x, (u16*)x16, stat, stat_ld,
-                           rows, n_seq, map, d, vocab);
-    else
-        hipLaunchKernelGGL((embed_fold_kernel<BF16>), grid, blk, 0, s, delta, tokens, tok_emb, pos_emb, x, (u16*)x16, stat, stat_ld,
-                           rows, n_seq, map, d, vocab);
+#define LEAF_EF(TT, L8) hipLaunchKernelGGL((embed_fold_kernel<TT, L8>), grid, blk, 0, s, delta, tokens, tok_emb, pos_emb, x, (u16*)x16, stat, stat_ld, rows, n_seq, map, d, vocab)
+    if (dtype == LEAF_F16) { if (lo8) LEAF_EF(F16, true); else LEAF_EF(F16, false); }
+    else { if (lo8) LEAF_EF(BF16, true); else LEAF_EF(BF16, false); }
+#undef LEAF_EF
     return hipGetLastError();
 }
 
@@ -493,6 +537,41 @@ hipError_t leaf_launch_eot_positions(const int32_t* tokens, int32_t* eot_pos, in
 hipError_t leaf_launch_gather_rows(const float* x, const int32_t* eot_pos, float* out, int n_seq, RowMap map, int d,
                                    hipStream_t s) {
     hipLaunchKernelGGL(gather_rows_kernel, dim3((n_seq + 3) / 4), dim3(256), 0, s, x, eot_pos, out, n_seq, map, d);
+    return hipGetLastError();
+}
+
+hipError_t leaf_launch_gather_rows_pair(const void* x16, const void* lo8, const int32_t* eot_pos, void* o16, void* o8, int n_seq, RowMap map,
+                                        int d, hipStream_t s) {
+    if (d % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gather_rows_pair_kernel, dim3((n_seq + 3) / 4), dim3(256), 0, s, (const u16*)x16, (const unsigned char*)lo8, eot_pos,
+                       (u16*)o16, (unsigned char*)o8, n_seq, map, d);
+    return hipGetLastError();
+}
+
+hipError_t leaf_launch_resid_pack(const float* x, void* x16, void* lo8, size_t n, int dtype, hipStream_t s) {
+    if (n % 4) return hipErrorInvalidValue;
+    const size_t n4 = n / 4;
+    const dim3 grid((unsigned)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096));
+    if (dtype == LEAF_F16) hipLaunchKernelGGL((resid_pack_kernel<F16>), grid, dim3(256), 0, s, x, (u16*)x16, (unsigned char*)lo8, n4);
+    else hipLaunchKernelGGL((resid_pack_kernel<BF16>), grid, dim3(256), 0, s, x, (u16*)x16, (unsigned char*)lo8, n4);
+    return hipGetLastError();
+}
+hipError_t leaf_launch_resid_unpack(const void* x16, const void* lo8, float* x, size_t n, int dtype, hipStream_t s) {
+    if (n % 4) return hipErrorInvalidValue;
+    const size_t n4 = n / 4;
+    const dim3 grid((unsigned)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096));
+    if (dtype == LEAF_F16) hipLaunchKernelGGL((resid_unpack_kernel<F16>), grid, dim3(256), 0, s, (const u16*)x16, (const unsigned char*)lo8, x, n4);
+    else hipLaunchKernelGGL((resid_unpack_kernel<BF16>), grid, dim3(256), 0, s, (const u16*)x16, (const unsigned char*)lo8, x, n4);
+    return hipGetLastError();
+}
+
+hipError_t leaf_launch_gather_rows_lo8(const void* x16, const void* lo8, const int32_t* eot_pos, float* out, int n_seq, RowMap map, int d,
+                                       int dtype, hipStream_t s) {
+    if (d % 4) return hipErrorInvalidValue;
+    if (dtype == LEAF_F16)
+        hipLaunchKernelGGL((gather_rows_lo8_kernel<F16>), dim3((n_seq + 3) / 4), dim3(256), 0, s, (const u16*)x16, (const unsigned char*)lo8, eot_pos, out, n_seq, map, d);
+    else
+        hipLaunchKernelGGL((gather_rows_lo8_kernel<BF16>), dim3((n_seq + 3) / 4), dim3(256), 0, s, (const u16*)x16, (const unsigned char*)lo8, eot_pos, out, n_seq, map, d);
     return hipGetLastError();
 }
 

@@ -303,6 +303,7 @@ hipError_t launch_t(const GemmArgs& p, int epi, hipStream_t s) {
         LEAF_GEMM_CASE(EPI_LNFOLD_T)
         LEAF_GEMM_CASE(EPI_LNFOLD_ACT_T)
         LEAF_GEMM_CASE(EPI_RESID_LN)
+        LEAF_GEMM_CASE(EPI_RESID_LN8)
         default: return hipErrorInvalidValue;
     }
 #undef LEAF_GEMM_CASE

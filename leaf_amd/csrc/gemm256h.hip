@@ -451,6 +451,54 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
             else stage16(pass, Gelu());
             flush16(pass, (u16*)p.C);
         }
+    } else if constexpr (EPI == EPI_RESID_LN8) {
+        // the residual stream in 16 + 8 bits (common.h resid_lo4): the passes of the fp32 epilogue below, but the residual rows come
+        // from -- and the finished rows go back to -- their 16-bit copy (8 B per lane and row) and remainder bytes (4 B): 8 d bytes
+        // per row cross HBM in the out-projection instead of 12 d, and no fp32 row is written at all
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            uint2 rh[8];
+            unsigned rl[8];
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = 4 * it + (elane >> 4), pc = elane & 15;
+                const int m = mb + 32 * pass + row;
+                const size_t o = (size_t)nb + ((pc ^ (row & 15)) << 2);
+                rh[it] = m < p.M ? *(const uint2*)((const u16*)p.x16 + (size_t)m * p.ldx16 + o) : uint2{0u, 0u};
+                rl[it] = m < p.M ? *(const unsigned*)((const unsigned char*)p.C + (size_t)m * p.ldc + o) : 0u;
+            }
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                const int i = 2 * pass + ii;
+                const int row = 16 * ii + efrow;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = 4 * j + fq;
+                    *(float4*)(sl + row * 256 + ((c ^ (row & 15)) << 4)) =
+                        float4{acc[i][j][0] + bias4[j].x, acc[i][j][1] + bias4[j].y, acc[i][j][2] + bias4[j].z,
+                               acc[i][j][3] + bias4[j].w};
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = 4 * it + (elane >> 4), pc = elane & 15;
+                float4 v = *(const float4*)(sl + row * 256 + (pc << 4));
+                const int m = mb + 32 * pass + row;
+                const float4 r = resid_decode4<TT>(rh[it], rl[it]);
+                v.x = __builtin_fmaf(r.x, 1.f, v.x); v.y = __builtin_fmaf(r.y, 1.f, v.y);
+                v.z = __builtin_fmaf(r.z, 1.f, v.z); v.w = __builtin_fmaf(r.w, 1.f, v.w);
+                const float gs = row16_sum(lnfold_sum4(v.x, v.y, v.z, v.w));
+                const float gq = row16_sum(lnfold_dev4(v.x, v.y, v.z, v.w, gs * (1.0f / 64.0f)));
+                if (m < p.M) {
+                    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                    const size_t o = (size_t)nb + ((pc ^ (row & 15)) << 2);
+                    const uint2 hi = pack4<TT>(v.x, v.y, v.z, v.w);
+                    __builtin_nontemporal_store(__builtin_bit_cast(u32x2_t, hi), (u32x2_t*)((u16*)p.x16 + (size_t)m * p.ldx16 + o));
+                    __builtin_nontemporal_store(resid_lo4<TT>(v.x, v.y, v.z, v.w, hi), (unsigned*)((unsigned char*)p.C + (size_t)m * p.ldc + o));
+                    if (pc == 0) p.stat_out[(size_t)(nb >> 6) * p.stat_ld + m] = float2{gs, gq};
+                }
+            }
+        }
     } else {
         // fp32 outputs: four passes of 32 rows x 64 cols: LDS rows of 256 B, 16-B chunks XOR-swizzled by (row & 15)
         constexpr bool RESID = (EPI == EPI_RESID_F32 || EPI == EPI_RESID_LN);
@@ -489,7 +537,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
                     v.x = __builtin_fmaf(res[it].x, beta, v.x); v.y = __builtin_fmaf(res[it].y, beta, v.y);
                     v.z = __builtin_fmaf(res[it].z, beta, v.z); v.w = __builtin_fmaf(res[it].w, beta, v.w);
                 }
+#ifdef LEAF_DIAG_NOF32STORE   // diagnostic only (garbage results): the residual GEMM with statistics never stores its fp32 rows -- the byte
+                              // volume of a residual stream kept as the 16-bit copy + an 8-bit extension (8 d instead of 12 d per row)
+                if (m < p.M && EPI != EPI_RESID_LN) {
+#else
                 if (m < p.M) {
+#endif
                     typedef float f32x4_t __attribute__((ext_vector_type(4)));
                     __builtin_nontemporal_store(f32x4_t{v.x, v.y, v.z, v.w}, (f32x4_t*)((float*)p.C + (size_t)m * p.ldc + nb + ((pc ^ (row & 15)) << 2)));
                 }
@@ -619,6 +672,7 @@ hipError_t launch256h(const GemmArgs& p_in, int epi, hipStream_t s) {
         LEAF_CASE_P(EPI_LNFOLD_T)
         LEAF_CASE_P(EPI_LNFOLD_ACT_T)
         LEAF_CASE(EPI_RESID_LN)
+        LEAF_CASE(EPI_RESID_LN8)
         default: return hipErrorInvalidValue;
     }
 #undef LEAF_CASE

@@ -195,6 +195,7 @@ hipError_t launch64(const GemmArgs& p, int epi, hipStream_t s) {
         LEAF_CASE(EPI_LNFOLD_T)
         LEAF_CASE(EPI_LNFOLD_ACT_T)
         LEAF_CASE(EPI_RESID_LN)
+        LEAF_CASE(EPI_RESID_LN8)
         default: return hipErrorInvalidValue;
     }
 #undef LEAF_CASE

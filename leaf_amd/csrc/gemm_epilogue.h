@@ -22,7 +22,57 @@ __device__ __forceinline__ void epilogue_block(const GemmArgs& p, const int (&m)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) acc[i][j] *= al;
     }
-    if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32 || EPI == EPI_RESID_LN) {
+    if constexpr (EPI == EPI_RESID_LN8) {
+        // the residual rows come from (and go back to) their 16-bit copy + remainder byte; everything else as EPI_RESID_LN below
+        static_assert(EPI != EPI_RESID_LN8 || NJ == 4, "a wave owns whole 64-column groups");
+        uint2 rh[NI][NJ];
+        unsigned rl[NI][NJ];
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const bool ok = m[i] < p.M;
+                rh[i][j] = ok ? *(const uint2*)((const u16*)p.x16 + (size_t)m[i] * p.ldx16 + nbase + 16 * j) : uint2{0u, 0u};
+                rl[i][j] = ok ? *(const unsigned*)((const unsigned char*)p.C + (size_t)m[i] * p.ldc + nbase + 16 * j) : 0u;
+            }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            float4 o[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const float4 r = resid_decode4<TT>(rh[i][j], rl[i][j]);
+                o[j].x = __builtin_fmaf(r.x, 1.f, acc[i][j][0] + bias[j].x);
+                o[j].y = __builtin_fmaf(r.y, 1.f, acc[i][j][1] + bias[j].y);
+                o[j].z = __builtin_fmaf(r.z, 1.f, acc[i][j][2] + bias[j].z);
+                o[j].w = __builtin_fmaf(r.w, 1.f, acc[i][j][3] + bias[j].w);
+            }
+            float t[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                t[j] = lnfold_sum4(o[j].x, o[j].y, o[j].z, o[j].w);
+                t[j] += __shfl_xor(t[j], 16, 64);
+                t[j] += __shfl_xor(t[j], 32, 64);
+            }
+            const float gs = (t[0] + t[1]) + (t[2] + t[3]);
+            const float gm = gs * (1.0f / 64.0f);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                t[j] = lnfold_dev4(o[j].x, o[j].y, o[j].z, o[j].w, gm);
+                t[j] += __shfl_xor(t[j], 16, 64);
+                t[j] += __shfl_xor(t[j], 32, 64);
+            }
+            const float gq = (t[0] + t[1]) + (t[2] + t[3]);
+            if (m[i] < p.M) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const uint2 hi = pack4<TT>(o[j].x, o[j].y, o[j].z, o[j].w);
+                    *(uint2*)((u16*)p.x16 + (size_t)m[i] * p.ldx16 + nbase + 16 * j) = hi;
+                    *(unsigned*)((unsigned char*)p.C + (size_t)m[i] * p.ldc + nbase + 16 * j) = resid_lo4<TT>(o[j].x, o[j].y, o[j].z, o[j].w, hi);
+                }
+                if ((threadIdx.x & 63) < 16) p.stat_out[(size_t)((nbase & ~63) >> 6) * p.stat_ld + m[i]] = float2{gs, gq};
+            }
+        }
+    } else if constexpr (EPI == EPI_RESID_F32 || EPI == EPI_STORE_F32 || EPI == EPI_RESID_LN) {
         constexpr bool RESID = (EPI == EPI_RESID_F32 || EPI == EPI_RESID_LN);
         float4 r[NI][NJ];
         const bool rd = RESID || p.beta != 0.f;

@@ -20,7 +20,14 @@ enum {
     EPI_LNFOLD_T = 5,     // C16 = rstd[m] * (acc - mean[m] * ln_s[n]) + bias[n]   ((mean, rstd) = rowstat[m]; bias = LN-beta . W^T + linear bias)
     EPI_LNFOLD_ACT_T = 6, // C16 = act(the same)
     EPI_RESID_LN = 7,     // C32 += acc + bias;  x16[m,n] = 16-bit(C32);  stat_out[n / 64][m] = (sum, M2) of that row's 64 columns
+    // the same on the 16 + 8-bit residual stream (common.h resid_lo4): x = decode(x16, C8) + acc + bias; x16 = 16-bit(x), C8 = its
+    // remainder byte, both IN PLACE (C = the [M, ldc] byte matrix of remainders); statistics of x as for EPI_RESID_LN
+    EPI_RESID_LN8 = 8,
+    EPI_COUNT = 9
 };
+// profiler / bench key of a GEMM launch: kernel family, operand type, epilogue id
+#define LEAF_PROF_KEY(family, dtype, epi) ((family) * 32 + (dtype) * 16 + (epi))
+#define LEAF_PROF_BIG 1024     // added to the key of launches of >= 16,384 rows (leaf_prof_end_shapes)
 
 
 struct GemmArgs {
@@ -100,10 +107,11 @@ hipError_t leaf_launch_embed_ln(const int32_t* tokens, const float* tok_emb, con
                                 int vocab, int dtype, hipStream_t s, const float* delta = nullptr /* [rows,d] additive embedding perturbation */);
 hipError_t leaf_launch_layernorm(const float* x, const float* g, const float* b, float eps, void* xn, int rows, int d,
                                  int dtype, hipStream_t s);
-// LN-folded forward (lnfold.h): x = tok_emb[token] + pos_emb[pos] (+ delta), its 16-bit copy and per-64-column (sum, M2)
+// LN-folded forward (lnfold.h): x = tok_emb[token] + pos_emb[pos] (+ delta), its 16-bit copy and per-64-column (sum, M2);
+// lo8: x is the [rows, d] byte matrix of remainders of the 16 + 8-bit residual stream (common.h resid_lo4), no fp32 row is written
 hipError_t leaf_launch_embed_fold(const int32_t* tokens, const float* tok_emb, const float* pos_emb, float* x, void* x16,
                                   float2* stat, int stat_ld, int rows, int n_seq, RowMap map, int d, int vocab, int dtype,
-                                  hipStream_t s, const float* delta = nullptr);
+                                  hipStream_t s, const float* delta = nullptr, bool lo8 = false);
 // rowstat[m] = (mean, rstd) of row m from the [ngroups][ld] (sum, M2) partials (Chan merge, lnfold.h)
 hipError_t leaf_launch_ln_finalize(const float2* stat, int ld, int rows, int ngroups, float eps, float2* rowstat, hipStream_t s);
 // gamma-scaled 16-bit QKV / c_fc weights W'[n,:] = 16-bit(g * W[n,:]) of ALL layers and their vectors s[n] = sum W'[n,:],
@@ -144,6 +152,15 @@ hipError_t leaf_launch_eot_positions(const int32_t* tokens, int32_t* eot_pos, in
 // out[n,:] = x[row of position eot_pos[n] of sequence n,:]   (fp32)
 hipError_t leaf_launch_gather_rows(const float* x, const int32_t* eot_pos, float* out, int n_seq, RowMap map, int d,
                                    hipStream_t s);
+// ... and as they are: o16[n,:], o8[n,:] = both halves of that row
+hipError_t leaf_launch_gather_rows_pair(const void* x16, const void* lo8, const int32_t* eot_pos, void* o16, void* o8, int n_seq, RowMap map,
+                                        int d, hipStream_t s);
+// the 16 + 8-bit residual format (common.h resid_lo4), element-wise: fp32 -> (x16, lo8) and back (n % 4 == 0)
+hipError_t leaf_launch_resid_pack(const float* x, void* x16, void* lo8, size_t n, int dtype, hipStream_t s);
+hipError_t leaf_launch_resid_unpack(const void* x16, const void* lo8, float* x, size_t n, int dtype, hipStream_t s);
+// the same out of the 16 + 8-bit residual stream: out[n,:] = decode(x16, lo8) of that row
+hipError_t leaf_launch_gather_rows_lo8(const void* x16, const void* lo8, const int32_t* eot_pos, float* out, int n_seq, RowMap map, int d,
+                                       int dtype, hipStream_t s);
 
 // ---- training-only kernels (train.hip)
 hipError_t leaf_launch_cast16(const void* src, int src_kind, void* dst, int dst_kind, size_t n, hipStream_t s);

@@ -427,7 +427,7 @@ bool leaf_gemm128pp_eligible(const GemmArgs& p, int epi) {
     const long tiles = (long)((p.M + BM - 1) / BM) * (p.N / BN);
     // the DMA sources are 32-bit byte offsets from the (uniform) operand bases: both operands must span < 4 GiB
     const bool fits32 = (unsigned long long)p.M * p.lda * 2ull < (1ull << 32) && (unsigned long long)p.N * p.ldb * 2ull < (1ull << 32);
-    return p.N % BN == 0 && tiles >= g_min_tiles && p.K % BK == 0 && p.K >= 2 * BK && p.ldc % 8 == 0 && fits32;
+    return epi < EPI_RESID_LN8 && p.N % BN == 0 && tiles >= g_min_tiles && p.K % BK == 0 && p.K >= 2 * BK && p.ldc % 8 == 0 && fits32;
 }
 
 hipError_t leaf_launch_gemm128pp(const GemmArgs& p, int dtype, int epi, hipStream_t s) {

@@ -131,7 +131,9 @@ class LeafCLIPText:
 
     def set_option(self, name: str, value: int):
         """Engine switches (leaf_text_set_option): 'chunk', 'last_layer_trim', 'streams' (1 | 2: two-stream
-        chunk pipeline of the forward-only passes), 'normalize_fare' (training forward / backward on normalised features)."""
+        chunk pipeline of the forward-only passes), 'normalize_fare' (training forward / backward on normalised features),
+        'compact_resid' (1 default: the residual stream of the forward-only passes as the 16-bit copy + an 8-bit remainder per
+        element instead of fp32 rows; 0 = fp32 rows)."""
         _lib.check(self._lib.leaf_text_set_option(self._h, name.encode(), int(value)), "leaf_text_set_option")
         return self
 

@@ -226,10 +226,12 @@ def _mha(cfg, xn, wqkv, bqkv, wo, bo, rnd: Round, stash=None, layer=-1):
 
 
 def encode_text(w: Dict[str, np.ndarray], cfg: TextCfg, tokens: np.ndarray, normalize: bool = False,
-                rnd: Round = None, stash: Optional[list] = None, delta: Optional[np.ndarray] = None) -> np.ndarray:
+                rnd: Round = None, stash: Optional[list] = None, delta: Optional[np.ndarray] = None,
+                resid: Round = None) -> np.ndarray:
     """[N,ctx] int ids -> [N,embed_dim] fp32 (src/open_clip/model.py:269-284).  ``delta`` [N,ctx,width]: additive
     perturbation of the token embeddings (the embedding-input forward of src/pez/open_clip_pez/model.py:210-228),
-    SURVEY.md 8a row a12."""
+    SURVEY.md 8a row a12.  ``resid``: emulation only -- a storage rounding applied to the residual stream every time it is
+    written (the engine's 16 + 8-bit stream: ``lambda x: resid_unpack(*resid_pack(x))``); None = the reference's fp32 stream."""
     tokens = np.asarray(tokens)
     N, L = tokens.shape
     d = cfg.width
@@ -238,6 +240,8 @@ def encode_text(w: Dict[str, np.ndarray], cfg: TextCfg, tokens: np.ndarray, norm
     if delta is not None:
         x = x + np.asarray(delta, dtype=F32)
     x = (x + w["positional_embedding"][:L]).astype(F32)
+    if resid is not None:
+        x = resid(x)
     for i in range(cfg.layers):
         p = f"transformer.resblocks.{i}."
         st = {} if stash is not None else None
@@ -245,6 +249,8 @@ def encode_text(w: Dict[str, np.ndarray], cfg: TextCfg, tokens: np.ndarray, norm
         a = _mha(cfg, xn, w[p + "attn.in_proj_weight"], w[p + "attn.in_proj_bias"],
                  w[p + "attn.out_proj.weight"], w[p + "attn.out_proj.bias"], rnd, st, layer=i)
         x1 = (x + a).astype(F32)
+        if resid is not None:
+            x1 = resid(x1)
         xn2, mu2, rs2 = layer_norm(x1, w[p + "ln_2.weight"], w[p + "ln_2.bias"], cfg.eps)
         pre = _mm(xn2.reshape(N * L, d), w[p + "mlp.c_fc.weight"], rnd, i, "fc") + w[p + "mlp.c_fc.bias"]
         h = act(pre)
@@ -252,6 +258,8 @@ def encode_text(w: Dict[str, np.ndarray], cfg: TextCfg, tokens: np.ndarray, norm
             h = _r(rnd, i, "fc", "out")(h)
         m = _mm(h, w[p + "mlp.c_proj.weight"], rnd, i, "proj") + w[p + "mlp.c_proj.bias"]
         x2 = (x1 + m.reshape(N, L, d)).astype(F32)
+        if resid is not None:
+            x2 = resid(x2)
         if stash is not None:
             st.update(x0=x, xn1=xn, mu1=mu1, rs1=rs1, x1=x1, xn2=xn2, mu2=mu2, rs2=rs2, pre=pre, h=h)
             stash.append(st)
@@ -474,3 +482,28 @@ def round_bf16(a: np.ndarray) -> np.ndarray:
 
 def round_fp16(a: np.ndarray) -> np.ndarray:
     return np.asarray(a, dtype=F32).astype(np.float16).astype(F32)
+
+
+# ---- the 16 + 8-bit residual format of the engine's forward-only passes (leaf_amd/csrc/common.h resid_lo4 / resid_decode4; no
+# counterpart in the reference, whose residual stream is fp32, src/open_clip/transformer.py:254-265).  Test infrastructure: the
+# GPU suite holds the kernels to these byte-exact definitions.
+def resid_pack(x: np.ndarray, mant: int = 10):
+    """x (fp32) -> (hi: fp16(x) saturated, as fp32 values; lo8: int8 remainder in 1/256ths of hi's unit in the last place):
+    q = clip(rne((x - hi) * 2^(8 + mant - e)), -127, 127), e = the binary exponent of float(hi) (its fp32 exponent field, also for
+    fp16-subnormal hi and hi = 0 -- the same bit arithmetic as the kernel)."""
+    x = np.ascontiguousarray(x, dtype=F32)
+    hi = np.clip(x, -65504.0, 65504.0).astype(np.float16).astype(F32)
+    e8 = hi.view(np.uint32) & np.uint32(0x7F800000)
+    up = ((np.uint32((254 + 8 + mant) << 23) - e8) & np.uint32(0xFFFFFFFF)).astype(np.uint32).view(F32)
+    with np.errstate(over="ignore", invalid="ignore"):
+        r = ((x - hi).astype(F32) * up).astype(F32)
+    r = np.clip(np.nan_to_num(r, nan=0.0, posinf=127.0, neginf=-127.0), -127.0, 127.0)
+    return hi, np.rint(r).astype(np.int8)
+
+
+def resid_unpack(hi: np.ndarray, lo8: np.ndarray, mant: int = 10) -> np.ndarray:
+    hi = np.ascontiguousarray(hi, dtype=F32)
+    e8 = hi.view(np.uint32) & np.uint32(0x7F800000)
+    down = ((e8 - np.uint32((8 + mant) << 23)) & np.uint32(0xFFFFFFFF)).astype(np.uint32).view(F32)
+    with np.errstate(over="ignore", invalid="ignore"):
+        return (np.asarray(lo8, dtype=np.int8).astype(np.float64) * down.astype(np.float64) + hi.astype(np.float64)).astype(F32)

@@ -414,3 +414,106 @@ def test_lnfold_rows_do_not_depend_on_the_kernel(env, d, N):
         got = run(rp, rc)
         for name, a, b in zip(("x", "x16", "stat", "y"), ref, got):
             assert torch.equal(a, b), f"{name} differs between launch sizes producer={rp} consumer={rc}"
+
+
+# ---------------------------------------------------------------- the 16 + 8-bit residual stream (round 5)
+def test_resid16_8_format_is_the_oracles_byte_for_byte(env):
+    """common.h resid_lo4 / resid_decode4 against oracle.resid_pack / resid_unpack: the 16-bit half is fp16(x) (saturating), the
+    remainder byte is rne((x - hi) * 256 / ulp(hi)) clamped to +-127, decoding is exact -- over twenty decades of magnitudes, ties,
+    binade boundaries, fp16 subnormals, zero, the largest fp16 and beyond it (finite, never inf)."""
+    lib, torch, dev = env
+    from leaf_amd import _lib
+    rng = np.random.default_rng(7)
+    x = (rng.standard_normal(1 << 18) * np.exp(rng.uniform(-25, 11, 1 << 18))).astype(np.float32)
+    hi_grid = rng.standard_normal(4096).astype(np.float16).astype(np.float32)
+    ties = hi_grid + np.abs(hi_grid) * np.float32(2.0 ** -11) * rng.choice(np.float32([0.125, 0.375, 0.5, 0.625, 0.875, -0.375]), 4096)
+    x = np.concatenate([x, ties.astype(np.float32), np.float32([0, -0.0, 65504, -65504, 65519.9, -65519.9, 6e-8, 2e-8, 6.1e-5, 1, -1, 0.5,
+                                                                1e9, -1e9, 0.99999994, 1.0000001, 2047.9999, 2048.5])])
+    x = x[: x.size // 4 * 4].copy()
+    tx = torch.from_numpy(x).to(dev)
+    x16 = torch.zeros(x.size, dtype=torch.float16, device=dev)
+    lo8 = torch.zeros(x.size, dtype=torch.uint8, device=dev)
+    back = torch.zeros(x.size, dtype=torch.float32, device=dev)
+    _lib.check(lib.leaf_op_resid_pack(1, ptr(tx), ptr(x16), ptr(lo8), x.size, stream()), "resid_pack")
+    _lib.check(lib.leaf_op_resid_unpack(1, ptr(x16), ptr(lo8), ptr(back), x.size, stream()), "resid_unpack")
+    torch.cuda.synchronize()
+    hi, lo = O.resid_pack(x)
+    assert np.array_equal(x16.float().cpu().numpy(), hi)
+    got_lo = lo8.cpu().numpy().view(np.int8)
+    same = got_lo == lo
+    assert same.all(), (x[~same][:8], got_lo[~same][:8], lo[~same][:8])
+    want = O.resid_unpack(hi, got_lo)
+    assert np.array_equal(back.cpu().numpy(), want) and np.isfinite(want).all()
+    big = np.abs(x) > 1e-3
+    big &= np.abs(x) < 65504
+    assert np.max(np.abs(want[big].astype(np.float64) - x[big]) / np.abs(x[big])) <= 2.0 ** -18 * 1.0001
+
+
+@pytest.mark.parametrize("M,d,K", [(300, 128, 128), (3000, 768, 768), (3000, 768, 3072), (40000, 768, 768), (33000, 768, 3072)])
+def test_resid16_8_gemm_vs_numpy(env, M, d, K):
+    """EPI_RESID_LN8 (the residual GEMMs of the scoring passes on the 16 + 8-bit stream): decode(x16, lo8) + A W^T + bias in float64,
+    re-encoded -- the stored pair must be the oracle's packing of the kernel's own fp32 value, i.e. the 16-bit half the rounding of
+    something within fp32 accumulation noise of the float64 result and the pair within 2^-18 of it; statistics as for EPI_RESID_LN.
+    Small launches run the register-direct kernels, the large ones the 256^2 half-stage kernel."""
+    lib, torch, dev = env
+    from leaf_amd import _lib
+    rng = np.random.default_rng(M + d + K)
+    A = rng.standard_normal((M, K), dtype=np.float32)
+    Wo = (rng.standard_normal((d, K), dtype=np.float32) * 0.05).astype(np.float32)
+    bo = rng.standard_normal(d).astype(np.float32)
+    x0 = (rng.standard_normal((M, d)) * 2.0 + rng.standard_normal((M, 1)) * 3.0).astype(np.float32)
+    x0[:, 5] += 300.0
+    hi0, lo0 = O.resid_pack(x0)
+    a16, wo16 = to16(A, "fp16", dev), to16(Wo, "fp16", dev)
+    x16 = torch.from_numpy(hi0).to(dev).half()
+    lo8 = torch.from_numpy(lo0.view(np.uint8)).to(dev)
+    stat = torch.zeros(d // 64, M, 2, dtype=torch.float32, device=dev)
+    _lib.check(lib.leaf_op_gemm_resid_ln8(1, ptr(a16), ptr(wo16), ptr(lo8), ptr(torch.from_numpy(bo).to(dev)), ptr(x16), ptr(stat),
+                                          M, d, K, stream()), "resid_ln8")
+    torch.cuda.synchronize()
+    want = O.resid_unpack(hi0, lo0).astype(np.float64) + O.round_fp16(A).astype(np.float64) @ O.round_fp16(Wo).astype(np.float64).T + bo
+    got_hi, got_lo = x16.float().cpu().numpy(), lo8.cpu().numpy().view(np.int8)
+    got = O.resid_unpack(got_hi, got_lo).astype(np.float64)
+    assert rel_l2(got, want) < 3e-6
+    # per element: the remainder byte leaves at most 2^-18 of the value (a clamped tie; 2^-19 otherwise), plus the fp32 accumulation
+    # noise of the sum itself (terms of size ~10 that may cancel)
+    noise = 1e-5
+    assert np.all(np.abs(got - want) <= 2.0 ** -18 * np.abs(want) + noise)
+    assert np.all(np.abs(got_hi - want) <= 2.0 ** -11 * np.abs(want) + noise)          # the 16-bit half alone: an fp16 rounding
+    grp = want.reshape(M, d // 64, 64)
+    st = stat.cpu().numpy()
+    assert np.allclose(st[:, :, 0].T, grp.sum(-1), rtol=1e-5, atol=2e-3)
+    assert np.allclose(st[:, :, 1].T, ((grp - grp.mean(-1, keepdims=True)) ** 2).sum(-1), rtol=1e-4)
+
+
+def test_resid16_8_rows_do_not_depend_on_the_kernel(env):
+    """The 16 + 8-bit producer gives BIT-identical rows (both halves and the statistics) from the 256^2 half-stage kernel (one launch)
+    and from the 64 x 128 ring (chunks of 1,500 rows), for both residual shapes -- what lets candidates and their captions' cached
+    prefixes come from different launches."""
+    lib, torch, dev = env
+    from leaf_amd import _lib
+    M, CH, d = 24000, 1500, 768
+    for K in (768, 3072):
+        rng = np.random.default_rng(K)
+        A = rng.standard_normal((M, K), dtype=np.float32)
+        Wo = (rng.standard_normal((d, K), dtype=np.float32) * 0.05).astype(np.float32)
+        tbo = torch.from_numpy(rng.standard_normal(d).astype(np.float32)).to(dev)
+        hi0, lo0 = O.resid_pack((rng.standard_normal((M, d)) * 2.0).astype(np.float32))
+        a16, wo16 = to16(A, "fp16", dev), to16(Wo, "fp16", dev)
+
+        def run(rows):
+            x16 = torch.from_numpy(hi0).to(dev).half()
+            lo8 = torch.from_numpy(lo0.view(np.uint8)).to(dev)
+            stats = []
+            for r0 in range(0, M, rows):
+                r1 = min(M, r0 + rows)
+                st = torch.zeros(d // 64, r1 - r0, 2, dtype=torch.float32, device=dev)
+                _lib.check(lib.leaf_op_gemm_resid_ln8(1, ptr(a16[r0:r1]), ptr(wo16), ptr(lo8[r0:r1]), ptr(tbo), ptr(x16[r0:r1]), ptr(st),
+                                                      r1 - r0, d, K, stream()), "resid_ln8")
+                stats.append(st)
+            torch.cuda.synchronize()
+            return x16, lo8, torch.cat(stats, 1)
+
+        ref, got = run(M), run(CH)
+        for name, a, b in zip(("x16", "lo8", "stat"), ref, got):
+            assert torch.equal(a, b), f"K={K}: {name} differs between the two kernels"
