@@ -262,6 +262,9 @@ def main():
     ap.add_argument("--split-blocks", type=int, default=0,
                     help="precision escape hatch (leaf_text_split_pack): hi + lo operand splits in the GEMMs of the first N blocks of the "
                          "forward-only passes, on the attacked AND the frozen model; 0 = the shipped arithmetic (the metric)")
+    ap.add_argument("--fp32-residual", action="store_true",
+                    help="A/B: keep the residual stream of the forward-only passes as fp32 rows beside their 16-bit copy (option compact_resid = 0) "
+                         "instead of the 16-bit copy + a remainder byte per element")
     ap.add_argument("--fixed-batch", action="store_true",
                     help="train on ONE synthetic batch for all steps (the rounds 1-4 form; A/B work).  Default: a NEW batch per step, seeded "
                          "by (rank, step), built on a side stream one step ahead -- the step is data dependent and must not depend on how far "
@@ -343,6 +346,10 @@ def main():
     if args.split_blocks:
         model.set_split_blocks(args.split_blocks)
         frozen.set_split_blocks(args.split_blocks)
+    if args.fp32_residual:
+        model.set_option("compact_resid", 0)
+        frozen.set_option("compact_resid", 0)
+    compact = not args.fp32_residual and not args.split_blocks and os.environ.get("LEAF_COMPACT_RESID") != "0"
     sc = StepConfig(rho=args.rho, k_adv=args.k_adv, lr=1e-5, wd=1e-4, attack=args.attack, pgd_eps=args.pgd_eps,
                     pgd_alpha=args.pgd_alpha, pgd_norm=args.pgd_norm, accum_freq=args.accum_freq)
     # synthetic captions: SOT, U{8..40} ids, EOT, zero pad; a different shard per rank (seed + rank) and -- unless
@@ -496,7 +503,7 @@ def main():
         # workload a PMC summary belongs to: tools/pmc_summary.py copies this key from the line of its own FETCH pass
         wkey = (f"{args.model}|B{B}|accum{args.accum_freq}|k{args.k_adv}|rho{args.rho}|{args.attack}|"
                 f"{'dense' if args.dense else 'trimmed'}|{'noprefix' if args.no_prefix_reuse else 'prefix'}|{'fixedbatch' if args.fixed_batch else 'freshbatch'}"
-                + (f"|split{args.split_blocks}" if args.split_blocks else ""))
+                + (f"|split{args.split_blocks}" if args.split_blocks else "") + ("" if compact else "|fp32resid"))
         default_key = "ViT-L-14-quickgelu|B128|accum1|k1|rho50|leaf|trimmed|prefix|freshbatch"
         try:    # HBM bytes per launch of the dominant kernel from the committed PMC passes; only for the build AND workload they were taken on
             import glob
@@ -543,7 +550,9 @@ def main():
                                    (f"CLIP {args.model} text encoder, OPTIONAL embedding-space PGD mode (SURVEY 8a row a12, NOT "
                                     f"the reference's text attack): k={args.k_adv} steps, {args.pgd_norm} eps={args.pgd_eps} "
                                     f"alpha={args.pgd_alpha}, B={B} per GPU, seq=77"),
-                       "attack": args.attack, "split_blocks": args.split_blocks, "accum_freq": args.accum_freq, "baseline_config_index": args.config or None, "workload_key": wkey,
+                       "attack": args.attack, "split_blocks": args.split_blocks,
+                       "residual_stream": ("16-bit copy + remainder byte (2^-19 per store) in the forward-only passes; fp32 in the training forward / backward"
+                                           if compact else "fp32"), "accum_freq": args.accum_freq, "baseline_config_index": args.config or None, "workload_key": wkey,
                        "global_batch": B * world, "seq_len": cfg.context_length, "rho": args.rho, "k": args.k_adv,
                        "parallelism": f"dp{world}", "candidate_forwards_per_step_per_gpu": 2 * args.rho * args.k_adv * B},
             "roofline": {

@@ -454,18 +454,30 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
     } else if constexpr (EPI == EPI_RESID_LN8) {
         // the residual stream in 16 + 8 bits (common.h resid_lo4): the passes of the fp32 epilogue below, but the residual rows come
         // from -- and the finished rows go back to -- their 16-bit copy (8 B per lane and row) and remainder bytes (4 B): 8 d bytes
-        // per row cross HBM in the out-projection instead of 12 d, and no fp32 row is written at all
+        // per row cross HBM in the out-projection instead of 12 d, and no fp32 row is written at all.
+        // Addresses: 32-bit byte offsets from the two (uniform) bases -- lane part (its first row, its column for each of the four
+        // values of row & 15 >> 2) once per tile, the row steps of the passes are uniform adds; the launcher checks both spans < 4 GiB.
+        const unsigned lr = (unsigned)elane >> 4, pc = (unsigned)elane & 15;
+        unsigned o16[4], o8[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned col = (unsigned)nb + ((pc ^ (4 * k + lr)) << 2);
+            o16[k] = ((unsigned)(mb + lr) * (unsigned)p.ldx16 + col) * 2u;
+            o8[k] = (unsigned)(mb + lr) * (unsigned)p.ldc + col;
+        }
+        const char* __restrict__ x16b = (const char*)p.x16;
+        const char* __restrict__ lo8b = (const char*)p.C;
+        const bool full = mb + 128 <= p.M;     // wave-uniform: every row of this wave's 128 exists (all but the last M tile)
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
             uint2 rh[8];
             unsigned rl[8];
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
-                const int row = 4 * it + (elane >> 4), pc = elane & 15;
-                const int m = mb + 32 * pass + row;
-                const size_t o = (size_t)nb + ((pc ^ (row & 15)) << 2);
-                rh[it] = m < p.M ? *(const uint2*)((const u16*)p.x16 + (size_t)m * p.ldx16 + o) : uint2{0u, 0u};
-                rl[it] = m < p.M ? *(const unsigned*)((const unsigned char*)p.C + (size_t)m * p.ldc + o) : 0u;
+                const unsigned step = (unsigned)(32 * pass + 4 * it);
+                const bool ok = full || mb + (int)step + (int)lr < p.M;
+                rh[it] = ok ? *(const uint2*)(x16b + (size_t)(o16[it & 3] + step * (unsigned)p.ldx16 * 2u)) : uint2{0u, 0u};
+                rl[it] = ok ? *(const unsigned*)(lo8b + (size_t)(o8[it & 3] + step * (unsigned)p.ldc)) : 0u;
             }
 #pragma unroll
             for (int ii = 0; ii < 2; ++ii) {
@@ -481,21 +493,20 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
             }
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
-                const int row = 4 * it + (elane >> 4), pc = elane & 15;
+                const int row = 4 * it + (int)lr;
                 float4 v = *(const float4*)(sl + row * 256 + (pc << 4));
-                const int m = mb + 32 * pass + row;
+                const unsigned step = (unsigned)(32 * pass + 4 * it);
                 const float4 r = resid_decode4<TT>(rh[it], rl[it]);
                 v.x = __builtin_fmaf(r.x, 1.f, v.x); v.y = __builtin_fmaf(r.y, 1.f, v.y);
                 v.z = __builtin_fmaf(r.z, 1.f, v.z); v.w = __builtin_fmaf(r.w, 1.f, v.w);
                 const float gs = row16_sum(lnfold_sum4(v.x, v.y, v.z, v.w));
                 const float gq = row16_sum(lnfold_dev4(v.x, v.y, v.z, v.w, gs * (1.0f / 64.0f)));
-                if (m < p.M) {
+                if (full || mb + (int)step + (int)lr < p.M) {
                     typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-                    const size_t o = (size_t)nb + ((pc ^ (row & 15)) << 2);
                     const uint2 hi = pack4<TT>(v.x, v.y, v.z, v.w);
-                    __builtin_nontemporal_store(__builtin_bit_cast(u32x2_t, hi), (u32x2_t*)((u16*)p.x16 + (size_t)m * p.ldx16 + o));
-                    __builtin_nontemporal_store(resid_lo4<TT>(v.x, v.y, v.z, v.w, hi), (unsigned*)((unsigned char*)p.C + (size_t)m * p.ldc + o));
-                    if (pc == 0) p.stat_out[(size_t)(nb >> 6) * p.stat_ld + m] = float2{gs, gq};
+                    __builtin_nontemporal_store(__builtin_bit_cast(u32x2_t, hi), (u32x2_t*)(const_cast<char*>(x16b) + (size_t)(o16[it & 3] + step * (unsigned)p.ldx16 * 2u)));
+                    __builtin_nontemporal_store(resid_lo4<TT>(v.x, v.y, v.z, v.w, hi), (unsigned*)(const_cast<char*>(lo8b) + (size_t)(o8[it & 3] + step * (unsigned)p.ldc)));
+                    if (pc == 0) p.stat_out[(size_t)(nb >> 6) * p.stat_ld + (mb + (int)step + (int)lr)] = float2{gs, gq};
                 }
             }
         }
@@ -694,7 +705,9 @@ bool leaf_gemm256h_eligible(const GemmArgs& p, int epi) {
     const long tiles = (long)((p.M + BM - 1) / BM) * (p.N / BN);
     // the DMA sources are 32-bit byte offsets from the operand bases (saddr + voffset): both operands must span < 4 GiB
     const bool fits32 = (unsigned long long)p.M * p.lda * 2ull < (1ull << 32) && (unsigned long long)p.N * p.ldb * 2ull < (1ull << 32);
-    return p.N % BN == 0 && tiles >= g_min_tiles && p.K % BK == 0 && p.K >= 4 * BK && p.ldc % 8 == 0 && fits32;
+    // EPI_RESID_LN8 addresses its 16-bit rows and remainder bytes by 32-bit byte offsets too
+    const bool fits8 = epi != EPI_RESID_LN8 || ((unsigned long long)p.M * p.ldx16 * 2ull < (1ull << 32) && (unsigned long long)p.M * p.ldc < (1ull << 32));
+    return p.N % BN == 0 && tiles >= g_min_tiles && p.K % BK == 0 && p.K >= 4 * BK && p.ldc % 8 == 0 && fits32 && fits8;
 }
 
 hipError_t leaf_launch_gemm256h(const GemmArgs& p, int dtype, int epi, hipStream_t s) {

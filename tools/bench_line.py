@@ -6,7 +6,8 @@ import sys
 
 NAMES = {("gemm_nt256_half_kernel<F16,6>", 3072, 768): "c_fc", ("gemm_nt256_half_kernel<F16,5>", 2304, 768): "qkv",
          ("qkv_attn_kernel<F16,5>", 2304, 768): "fused", ("gemm_nt256_half_kernel<F16,7>", 768, 3072): "c_proj",
-         ("gemm_nt256_half_kernel<F16,7>", 768, 768): "out_proj"}
+         ("gemm_nt256_half_kernel<F16,7>", 768, 768): "out_proj", ("gemm_nt256_half_kernel<F16,8>", 768, 3072): "c_proj",
+         ("gemm_nt256_half_kernel<F16,8>", 768, 768): "out_proj"}
 
 
 def main():
