@@ -91,20 +91,24 @@ __device__ __forceinline__ void unpack4(uint2 u, float (&o)[4]) {
 template <class TT> struct ResidLo;
 template <> struct ResidLo<F16> { static constexpr int mant = 10; };
 template <> struct ResidLo<BF16> { static constexpr int mant = 7; };
+// (returns the byte in bits 0-7 of a dword whose upper bits are the magic constant's: the caller picks byte 0)
 template <class TT>
 __device__ __forceinline__ unsigned resid_lo1(float x, float h) {
     const unsigned e8 = __builtin_bit_cast(unsigned, h) & 0x7F800000u;
     const float up = __builtin_bit_cast(float, ((unsigned)(254 + 8 + ResidLo<TT>::mant) << 23) - e8);      // 2^(8 + mant - e)
     const float r = __builtin_amdgcn_fmed3f((x - h) * up, -127.f, 127.f);
     // + 1.5 * 2^23: the sum's rounding IS round-to-nearest-even to an integer, which then sits in the low mantissa bits (two's complement)
-    return __builtin_bit_cast(unsigned, r + 12582912.f) & 0xFFu;
+    return __builtin_bit_cast(unsigned, r + 12582912.f);
 }
-// four residual values + their packed 16-bit copy -> the four remainder bytes (one dword)
+// four residual values + their packed 16-bit copy -> the four remainder bytes (one dword): byte 0 of each of the four results,
+// gathered by three byte permutes (v_perm_b32 selector: 0-3 = bytes of the second operand, 4-7 of the first)
 template <class TT>
 __device__ __forceinline__ unsigned resid_lo4(float a, float b, float c, float d, uint2 hi) {
     float h[4];
     unpack4<TT>(hi, h);
-    return resid_lo1<TT>(a, h[0]) | (resid_lo1<TT>(b, h[1]) << 8) | (resid_lo1<TT>(c, h[2]) << 16) | (resid_lo1<TT>(d, h[3]) << 24);
+    const unsigned ab = __builtin_amdgcn_perm(resid_lo1<TT>(b, h[1]), resid_lo1<TT>(a, h[0]), 0x0c0c0400u);   // (0, 0, b, a)
+    const unsigned cd = __builtin_amdgcn_perm(resid_lo1<TT>(d, h[3]), resid_lo1<TT>(c, h[2]), 0x0c0c0400u);
+    return __builtin_amdgcn_perm(cd, ab, 0x05040100u);                                                           // (d, c, b, a)
 }
 template <class TT>
 __device__ __forceinline__ float resid_decode1(float h, int q) {

@@ -462,11 +462,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const unsigned col = (unsigned)nb + ((pc ^ (4 * k + lr)) << 2);
-            o16[k] = ((unsigned)(mb + lr) * (unsigned)p.ldx16 + col) * 2u;
-            o8[k] = (unsigned)(mb + lr) * (unsigned)p.ldc + col;
+            o16[k] = (lr * (unsigned)p.ldx16 + col) * 2u;
+            o8[k] = lr * (unsigned)p.ldc + col;
         }
-        const char* __restrict__ x16b = (const char*)p.x16;
-        const char* __restrict__ lo8b = (const char*)p.C;
+        // (uniform row bases: scalar arithmetic; the lane offsets above never change)
+        const char* __restrict__ x16b = (const char*)p.x16 + (size_t)mb * p.ldx16 * 2;
+        const char* __restrict__ lo8b = (const char*)p.C + (size_t)mb * p.ldc;
         const bool full = mb + 128 <= p.M;     // wave-uniform: every row of this wave's 128 exists (all but the last M tile)
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
@@ -474,10 +475,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
             unsigned rl[8];
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
-                const unsigned step = (unsigned)(32 * pass + 4 * it);
-                const bool ok = full || mb + (int)step + (int)lr < p.M;
-                rh[it] = ok ? *(const uint2*)(x16b + (size_t)(o16[it & 3] + step * (unsigned)p.ldx16 * 2u)) : uint2{0u, 0u};
-                rl[it] = ok ? *(const unsigned*)(lo8b + (size_t)(o8[it & 3] + step * (unsigned)p.ldc)) : 0u;
+                const int step = 32 * pass + 4 * it;
+                const bool ok = full || mb + step + (int)lr < p.M;
+                rh[it] = ok ? *(const uint2*)(x16b + (size_t)step * p.ldx16 * 2 + o16[it & 3]) : uint2{0u, 0u};
+                rl[it] = ok ? *(const unsigned*)(lo8b + (size_t)step * p.ldc + o8[it & 3]) : 0u;
             }
 #pragma unroll
             for (int ii = 0; ii < 2; ++ii) {
@@ -495,18 +496,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
             for (int it = 0; it < 8; ++it) {
                 const int row = 4 * it + (int)lr;
                 float4 v = *(const float4*)(sl + row * 256 + (pc << 4));
-                const unsigned step = (unsigned)(32 * pass + 4 * it);
+                const int step = 32 * pass + 4 * it;
                 const float4 r = resid_decode4<TT>(rh[it], rl[it]);
                 v.x = __builtin_fmaf(r.x, 1.f, v.x); v.y = __builtin_fmaf(r.y, 1.f, v.y);
                 v.z = __builtin_fmaf(r.z, 1.f, v.z); v.w = __builtin_fmaf(r.w, 1.f, v.w);
                 const float gs = row16_sum(lnfold_sum4(v.x, v.y, v.z, v.w));
                 const float gq = row16_sum(lnfold_dev4(v.x, v.y, v.z, v.w, gs * (1.0f / 64.0f)));
-                if (full || mb + (int)step + (int)lr < p.M) {
+                if (full || mb + step + (int)lr < p.M) {
                     typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
                     const uint2 hi = pack4<TT>(v.x, v.y, v.z, v.w);
-                    __builtin_nontemporal_store(__builtin_bit_cast(u32x2_t, hi), (u32x2_t*)(const_cast<char*>(x16b) + (size_t)(o16[it & 3] + step * (unsigned)p.ldx16 * 2u)));
-                    __builtin_nontemporal_store(resid_lo4<TT>(v.x, v.y, v.z, v.w, hi), (unsigned*)(const_cast<char*>(lo8b) + (size_t)(o8[it & 3] + step * (unsigned)p.ldc)));
-                    if (pc == 0) p.stat_out[(size_t)(nb >> 6) * p.stat_ld + (mb + (int)step + (int)lr)] = float2{gs, gq};
+                    __builtin_nontemporal_store(__builtin_bit_cast(u32x2_t, hi), (u32x2_t*)(const_cast<char*>(x16b) + (size_t)step * p.ldx16 * 2 + o16[it & 3]));
+                    __builtin_nontemporal_store(resid_lo4<TT>(v.x, v.y, v.z, v.w, hi), (unsigned*)(const_cast<char*>(lo8b) + (size_t)step * p.ldc + o8[it & 3]));
+                    if (pc == 0) p.stat_out[(size_t)(nb >> 6) * p.stat_ld + (mb + step + (int)lr)] = float2{gs, gq};
                 }
             }
         }
