@@ -50,7 +50,7 @@ def kernel_sources_hash():
     """sha256 over the GEMM kernel sources: a traffic summary under profiles/ is only attached to a line produced by the
     same kernels."""
     h = hashlib.sha256()
-    for f in ("gemm256h.hip", "gemm64.hip", "gemm.hip", "qkv_attn.hip", "gemm_epilogue.h", "common.h"):
+    for f in ("gemm256h.hip", "gemm64.hip", "gemm.hip", "qkv_attn.hip", "gemm_epilogue.h", "common.h", "lnfold.h"):
         p = os.path.join(ROOT, "leaf_amd", "csrc", f)
         if os.path.exists(p):
             with open(p, "rb") as fh:

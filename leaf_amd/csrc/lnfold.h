@@ -14,7 +14,7 @@
 // counts), which does not cancel when |mean| >> std, by a tiny kernel (ln_finalize_kernel, elementwise.hip) that turns the
 // [group][row] partials into one (mean, rstd) pair per row; the consuming GEMM loads that pair at kernel START (2 registers)
 // so its epilogue waits for nothing.  Every producer reduces a group in the SAME tree (4-element chunks
-// (x0+x2)+(x1+x3) -- register pairs, see lnfold_sum4 --, then a butterfly over the chunk index bits 0,1,2,3) and every consumer merges the groups in ascending
+// (x0+x1)+(x2+x3), then a butterfly over the chunk index bits 0,1,2,3) and every consumer merges the groups in ascending
 // order with the same expressions, so a row's statistics -- and hence its GEMM output -- do not depend on which kernel or
 // tile computed them (the property prefix reuse rests on; the build uses -ffp-contract=off, fused operations are explicit).
 #pragma once
@@ -52,15 +52,8 @@ __device__ __forceinline__ f32x2 lnfold_apply2(f32x2 acc, float mean, float rstd
 }
 
 // chunk-level pieces of the producer's reduction: a lane holds 4 consecutive columns
-// (association (a + c) + (b + d): the two halves of a lane's chunk as register pairs, so that the producers' epilogues -- where
-// vector instructions are what a tile waits for -- run it on v_pk_add_f32 / v_pk_mul_f32: 2 + 5 instructions instead of 3 + 11)
-__device__ __forceinline__ float lnfold_sum4(float a, float b, float c, float d) {
-    const f32x2 p = f32x2{a, b} + f32x2{c, d};
-    return p.x + p.y;
-}
+__device__ __forceinline__ float lnfold_sum4(float a, float b, float c, float d) { return (a + b) + (c + d); }
 __device__ __forceinline__ float lnfold_dev4(float a, float b, float c, float d, float mean) {
-    const f32x2 m = f32x2{mean, mean};
-    const f32x2 d0 = f32x2{a, b} - m, d1 = f32x2{c, d} - m;
-    const f32x2 q = d0 * d0 + d1 * d1;          // (-ffp-contract=off: two multiplies and an add, as written)
-    return q.x + q.y;
+    const float a0 = a - mean, a1 = b - mean, a2 = c - mean, a3 = d - mean;
+    return (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
 }
