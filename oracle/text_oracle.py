@@ -488,11 +488,12 @@ def round_fp16(a: np.ndarray) -> np.ndarray:
 # counterpart in the reference, whose residual stream is fp32, src/open_clip/transformer.py:254-265).  Test infrastructure: the
 # GPU suite holds the kernels to these byte-exact definitions.
 def resid_pack(x: np.ndarray, mant: int = 10):
-    """x (fp32) -> (hi: fp16(x) saturated, as fp32 values; lo8: int8 remainder in 1/256ths of hi's unit in the last place):
+    """x (fp32) -> (hi: fp16(x) saturated -- bf16(x) for mant = 7 --, as fp32 values; lo8: int8 remainder in 1/256ths of hi's unit
+    in the last place):
     q = clip(rne((x - hi) * 2^(8 + mant - e)), -127, 127), e = the binary exponent of float(hi) (its fp32 exponent field, also for
     fp16-subnormal hi and hi = 0 -- the same bit arithmetic as the kernel)."""
     x = np.ascontiguousarray(x, dtype=F32)
-    hi = np.clip(x, -65504.0, 65504.0).astype(np.float16).astype(F32)
+    hi = np.clip(x, -65504.0, 65504.0).astype(np.float16).astype(F32) if mant == 10 else np.ascontiguousarray(round_bf16(x))
     e8 = hi.view(np.uint32) & np.uint32(0x7F800000)
     up = ((np.uint32((254 + 8 + mant) << 23) - e8) & np.uint32(0xFFFFFFFF)).astype(np.uint32).view(F32)
     with np.errstate(over="ignore", invalid="ignore"):

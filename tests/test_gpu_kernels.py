@@ -417,7 +417,8 @@ def test_lnfold_rows_do_not_depend_on_the_kernel(env, d, N):
 
 
 # ---------------------------------------------------------------- the 16 + 8-bit residual stream (round 5)
-def test_resid16_8_format_is_the_oracles_byte_for_byte(env):
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_resid16_8_format_is_the_oracles_byte_for_byte(env, dtype):
     """common.h resid_lo4 / resid_decode4 against oracle.resid_pack / resid_unpack: the 16-bit half is fp16(x) (saturating), the
     remainder byte is rne((x - hi) * 256 / ulp(hi)) clamped to +-127, decoding is exact -- over twenty decades of magnitudes, ties,
     binade boundaries, fp16 subnormals, zero, the largest fp16 and beyond it (finite, never inf)."""
@@ -430,23 +431,25 @@ def test_resid16_8_format_is_the_oracles_byte_for_byte(env):
     x = np.concatenate([x, ties.astype(np.float32), np.float32([0, -0.0, 65504, -65504, 65519.9, -65519.9, 6e-8, 2e-8, 6.1e-5, 1, -1, 0.5,
                                                                 1e9, -1e9, 0.99999994, 1.0000001, 2047.9999, 2048.5])])
     x = x[: x.size // 4 * 4].copy()
+    f16 = dtype == "fp16"
+    mant, did = (10, 1) if f16 else (7, 0)
     tx = torch.from_numpy(x).to(dev)
-    x16 = torch.zeros(x.size, dtype=torch.float16, device=dev)
+    x16 = torch.zeros(x.size, dtype=torch.float16 if f16 else torch.bfloat16, device=dev)
     lo8 = torch.zeros(x.size, dtype=torch.uint8, device=dev)
     back = torch.zeros(x.size, dtype=torch.float32, device=dev)
-    _lib.check(lib.leaf_op_resid_pack(1, ptr(tx), ptr(x16), ptr(lo8), x.size, stream()), "resid_pack")
-    _lib.check(lib.leaf_op_resid_unpack(1, ptr(x16), ptr(lo8), ptr(back), x.size, stream()), "resid_unpack")
+    _lib.check(lib.leaf_op_resid_pack(did, ptr(tx), ptr(x16), ptr(lo8), x.size, stream()), "resid_pack")
+    _lib.check(lib.leaf_op_resid_unpack(did, ptr(x16), ptr(lo8), ptr(back), x.size, stream()), "resid_unpack")
     torch.cuda.synchronize()
-    hi, lo = O.resid_pack(x)
+    hi, lo = O.resid_pack(x, mant)
     assert np.array_equal(x16.float().cpu().numpy(), hi)
     got_lo = lo8.cpu().numpy().view(np.int8)
     same = got_lo == lo
     assert same.all(), (x[~same][:8], got_lo[~same][:8], lo[~same][:8])
-    want = O.resid_unpack(hi, got_lo)
+    want = O.resid_unpack(hi, got_lo, mant)
     assert np.array_equal(back.cpu().numpy(), want) and np.isfinite(want).all()
     big = np.abs(x) > 1e-3
     big &= np.abs(x) < 65504
-    assert np.max(np.abs(want[big].astype(np.float64) - x[big]) / np.abs(x[big])) <= 2.0 ** -18 * 1.0001
+    assert np.max(np.abs(want[big].astype(np.float64) - x[big]) / np.abs(x[big])) <= 2.0 ** -(mant + 8) * 1.0001
 
 
 @pytest.mark.parametrize("M,d,K", [(300, 128, 128), (3000, 768, 768), (3000, 768, 3072), (40000, 768, 768), (33000, 768, 3072)])
