@@ -64,6 +64,7 @@ template <class TT, bool USE_TR, int MAXT>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const u16* __restrict__ qkv, const u16* __restrict__ kv_base,
                                                        u16* __restrict__ out, int n_items, RowMap map, int heads, int d,
                                                        const int32_t* __restrict__ eot_pos, int vrows) {
+    leaf_fp16_sat_mode();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int item = blockIdx.x * 4 + wid;

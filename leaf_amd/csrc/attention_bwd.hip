@@ -58,6 +58,7 @@ __device__ __forceinline__ uint4 cvt8(uint4 v) {
 template <class FT, class GT>
 __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(const u16* __restrict__ qkv, const u16* __restrict__ dO,
                                                            u16* __restrict__ dqkv, RowMap map, int heads, int d) {
+    leaf_fp16_sat_mode();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
     const int n = blockIdx.x / heads, h = blockIdx.x % heads;

@@ -18,6 +18,11 @@ typedef uint16_t u16;
 
 // 16-bit MFMA operand traits.  Both run v_mfma_f32_16x16x32_* at the same rate; F16 carries
 // 11 significand bits (forward / scoring path), BF16 carries fp32's exponent (gradient path).
+// MODE.FP16_OVFL = 1 for this wave (hwreg(HW_REG_MODE, 23, 1)): fp16 conversions saturate at +-65504 instead of overflowing to inf
+// (tools/fp16_ovfl_probe.hip: 65520.f, 1e6f, 3e38f -> 7bff; +-inf stay inf).  First statement of EVERY kernel: the wave's MODE
+// register starts from the kernel descriptor's default (0) and F16::pack2 relies on it.
+__device__ __forceinline__ void leaf_fp16_sat_mode() { __builtin_amdgcn_s_setreg((0 << 11) | (23 << 6) | 1, 1); }
+
 struct F16 {
     using elem = _Float16;
     using vec8 = f16x8;
@@ -34,13 +39,12 @@ struct F16 {
         return (_Float16)x;                                           // v_cvt_f16_f32, RTN-even
     }
     static __device__ __forceinline__ float to_f32(elem x) { return (float)x; }
-    // two elements: v_cvt_pk_f16_f32 (RTN-even, overflow -> inf) then the saturation on the PACKED halves (v_pk_min_f16 /
-    // v_pk_max_f16: one instruction per pair instead of one v_med3_f32 per element).  Same value as from_f32 for every
-    // non-NaN input: a float in (65504, 65520) rounds to 65504 either way, anything beyond saturates either way.
+    // two elements: v_cvt_pk_f16_f32 (RTN-even); the saturation at +-65504 is the hardware's -- every kernel sets MODE.FP16_OVFL at
+    // entry (leaf_fp16_sat_mode above: an overflowed fp16 result becomes +-MAX_FP16 instead of +-inf, a true inf stays inf) -- so the
+    // pair costs one instruction instead of three (v_pk_min_f16 / v_pk_max_f16 behind it: 15 % of the c_fc epilogue's vector
+    // instructions, 27 % of the fused launch's q|k|v staging).  Same value as from_f32 for every finite input.
     static __device__ __forceinline__ unsigned pack2(f32x2 v) {
         f16x2 h = {(_Float16)v.x, (_Float16)v.y};
-        h = __builtin_elementwise_min(h, (f16x2){(_Float16)65504.f, (_Float16)65504.f});
-        h = __builtin_elementwise_max(h, (f16x2){(_Float16)-65504.f, (_Float16)-65504.f});
         return __builtin_bit_cast(unsigned, h);
     }
 };

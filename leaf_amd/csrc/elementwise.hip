@@ -51,6 +51,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x_in,
                                                  const float* __restrict__ g, const float* __restrict__ b, float eps,
                                                  float* __restrict__ x_out, u16* __restrict__ xn, int rows, int n_seq,
                                                  RowMap map, int d, int vocab) {
+    leaf_fp16_sat_mode();
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -99,6 +100,7 @@ __global__ __launch_bounds__(256) void embed_fold_kernel(const float* __restrict
                                                          float* __restrict__ x_out, u16* __restrict__ x16,
                                                          float2* __restrict__ stat, int stat_ld, int rows, int n_seq, RowMap map,
                                                          int d, int vocab) {
+    leaf_fp16_sat_mode();
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -135,6 +137,7 @@ __global__ __launch_bounds__(256) void embed_fold_kernel(const float* __restrict
 
 __global__ __launch_bounds__(256) void ln_finalize_kernel(const float2* __restrict__ stat, int ld, int rows, int ngroups, float eps,
                                                           float2* __restrict__ rowstat) {
+    leaf_fp16_sat_mode();
     const int m = blockIdx.x * 256 + threadIdx.x;
     if (m < rows) rowstat[m] = lnfold_row_stat(stat, ld, m, ngroups, eps);
 }
@@ -151,6 +154,7 @@ struct FoldPackArgs {
 };
 template <class TT>
 __global__ __launch_bounds__(256) void fold_pack_kernel(FoldPackArgs a) {
+    leaf_fp16_sat_mode();
     const int lane = threadIdx.x & 63;
     const int l = blockIdx.y >> 1, w = blockIdx.y & 1;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -188,6 +192,7 @@ __global__ __launch_bounds__(256) void pool_project_kernel(const float* __restri
                                                            float* __restrict__ out, float* __restrict__ pooled,
                                                            int32_t* __restrict__ eot_idx, int n_seq, RowMap map, int d,
                                                            int D, int normalize, int rows_are_pooled) {
+    leaf_fp16_sat_mode();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* xs = (float*)smem;               // [PR][d]
     float* red = xs + PR * d;               // [4][PR]
@@ -313,6 +318,7 @@ __global__ __launch_bounds__(256) void pool_project_kernel(const float* __restri
 __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ feat, const float* __restrict__ anchor,
                                                     int rho, int D, int objective, int32_t* __restrict__ best_idx,
                                                     float* __restrict__ best_feat, float* __restrict__ loss_out) {
+    leaf_fp16_sat_mode();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* ls = (float*)smem;  // [rho]
     __shared__ int s_best;
@@ -372,6 +378,7 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ fe
 
 __global__ __launch_bounds__(256) void eot_positions_kernel(const int32_t* __restrict__ tokens, int32_t* __restrict__ eot_pos,
                                                             int n_seq, RowMap map) {
+    leaf_fp16_sat_mode();
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (n >= n_seq) return;
     const int sg = map.s0 + n, pfx = seq_prefix(map, sg), end = pfx + seq_len(map, sg);
@@ -390,6 +397,7 @@ __global__ __launch_bounds__(256) void eot_positions_kernel(const int32_t* __res
 
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ x, const int32_t* __restrict__ eot_pos,
                                                           float* __restrict__ out, int n_seq, RowMap map, int d) {
+    leaf_fp16_sat_mode();
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (n >= n_seq) return;
     const int sg = map.s0 + n;
@@ -402,6 +410,7 @@ template <class TT>
 __global__ __launch_bounds__(256) void gather_rows_lo8_kernel(const u16* __restrict__ x16, const unsigned char* __restrict__ lo8,
                                                               const int32_t* __restrict__ eot_pos, float* __restrict__ out, int n_seq,
                                                               RowMap map, int d) {
+    leaf_fp16_sat_mode();
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (n >= n_seq) return;
     const int sg = map.s0 + n;
@@ -414,6 +423,7 @@ __global__ __launch_bounds__(256) void gather_rows_lo8_kernel(const u16* __restr
 __global__ __launch_bounds__(256) void gather_rows_pair_kernel(const u16* __restrict__ x16, const unsigned char* __restrict__ lo8,
                                                                const int32_t* __restrict__ eot_pos, u16* __restrict__ o16,
                                                                unsigned char* __restrict__ o8, int n_seq, RowMap map, int d) {
+    leaf_fp16_sat_mode();
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (n >= n_seq) return;
     const int sg = map.s0 + n;
@@ -427,6 +437,7 @@ __global__ __launch_bounds__(256) void gather_rows_pair_kernel(const u16* __rest
 // kernel hooks of the 16 + 8-bit residual format itself (tests): fp32 -> (x16, lo8) and back
 template <class TT>
 __global__ __launch_bounds__(256) void resid_pack_kernel(const float* __restrict__ x, u16* __restrict__ x16, unsigned char* __restrict__ lo8, size_t n4) {
+    leaf_fp16_sat_mode();
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         const float4 v = *(const float4*)(x + 4 * i);
         const uint2 hi = pack4<TT>(v.x, v.y, v.z, v.w);
@@ -436,12 +447,14 @@ __global__ __launch_bounds__(256) void resid_pack_kernel(const float* __restrict
 }
 template <class TT>
 __global__ __launch_bounds__(256) void resid_unpack_kernel(const u16* __restrict__ x16, const unsigned char* __restrict__ lo8, float* __restrict__ x, size_t n4) {
+    leaf_fp16_sat_mode();
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256)
         *(float4*)(x + 4 * i) = resid_decode4<TT>(*(const uint2*)(x16 + 4 * i), *(const unsigned*)(lo8 + 4 * i));
 }
 
 template <class TT>
 __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, u16* __restrict__ dst, size_t n4) {
+    leaf_fp16_sat_mode();
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * 256;
     for (; i < n4; i += stride) {
@@ -587,6 +600,7 @@ hipError_t leaf_launch_score(const float* feat, const float* anchor, int B, int 
 namespace {
 __global__ __launch_bounds__(256) void copy16_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16,
                                                      const unsigned char* __restrict__ tsrc, unsigned char* __restrict__ tdst, int tail) {
+    leaf_fp16_sat_mode();
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
     if (blockIdx.x == 0 && (int)threadIdx.x < tail) tdst[threadIdx.x] = tsrc[threadIdx.x];
 }
@@ -610,6 +624,7 @@ hipError_t leaf_launch_copy_bytes(const void* src, void* dst, size_t bytes, hipS
 namespace {
 template <class TT>
 __global__ __launch_bounds__(256) void split16_rows_kernel(const float* __restrict__ x, u16* __restrict__ out, size_t n4, int d4) {
+    leaf_fp16_sat_mode();
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         const size_t r = i / d4;
         const int c = (int)(i - r * d4);
@@ -628,6 +643,7 @@ __global__ __launch_bounds__(256) void split16_rows_kernel(const float* __restri
 template <class TT>
 __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict__ W, const float* __restrict__ g, u16* __restrict__ out,
                                                          float* __restrict__ srow, int K, int triple) {
+    leaf_fp16_sat_mode();
     __shared__ float red[256];
     const int n = blockIdx.x;
     const float* w = W + (size_t)n * K;

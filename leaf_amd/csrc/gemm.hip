@@ -28,6 +28,7 @@ __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + 
 // would leave CUs idle (the B-caption passes: 3,200 rows x 768 columns = 150 tiles of 128^2 on 256 CUs).
 template <class TT, int EPI, int MI>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
+    leaf_fp16_sat_mode();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BMt = 32 * MI;                 // tile rows
     constexpr int ATILE = BMt * BK * 2;          // A tile bytes; the B tile stays TILE_BYTES
@@ -167,6 +168,7 @@ typedef __attribute__((address_space(1))) const void glb_void_t;
 
 template <class TT, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs p) {
+    leaf_fp16_sat_mode();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);

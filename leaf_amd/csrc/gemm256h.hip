@@ -43,6 +43,7 @@ __device__ __forceinline__ int lds_off_h(int row, int chunk) { return row * 128 
 // slots 3-4, slots 0-1 take the prefetch, slot 2 the LN-folding row table; the next tile's barrier protects all three.
 template <class TT, int EPI, bool PERSIST>
 __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
+    leaf_fp16_sat_mode();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);

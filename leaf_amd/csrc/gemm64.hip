@@ -31,6 +31,7 @@ __device__ __forceinline__ void wait_vm_lgkm0() {
 // workgroup per CU with a DMA latency of 4-5 stage times hidden, the better choice when a CU holds about one tile)
 template <class TT, int EPI, int MI, int NS>
 __global__ __launch_bounds__(256, 2) void gemm_nt64_ring_kernel(GemmArgs p) {
+    leaf_fp16_sat_mode();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BM = 32 * MI;
     constexpr int A_BYTES = BM * BK * 2;      // 8 / 12 / 16 KiB

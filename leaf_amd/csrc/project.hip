@@ -20,6 +20,7 @@ constexpr int MAXCH = 8;   // float4 chunks per lane -> d <= 2048
 __global__ __launch_bounds__(256) void ln_rows_f32_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                           const float* __restrict__ b, float eps, float* __restrict__ y,
                                                           int M, int d) {
+    leaf_fp16_sat_mode();
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const int nq = d >> 2;
@@ -63,6 +64,7 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // C[M,N] = A[M,K] B[K,N], all fp32 row-major; N % 128 == 0, K % 16 == 0, rows >= M masked
 __global__ __launch_bounds__(256) void proj_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                        float* __restrict__ C, int M, int N, int K) {
+    leaf_fp16_sat_mode();
     __shared__ float As[2][A_TILE];
     __shared__ float Bs[2][B_TILE];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -132,6 +134,7 @@ __global__ __launch_bounds__(256) void proj_f32_kernel(const float* __restrict__
 }
 
 __global__ __launch_bounds__(256) void l2norm_rows_kernel(float* __restrict__ x, int M, int D) {
+    leaf_fp16_sat_mode();
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     float* xr = x + (size_t)row * D;

@@ -95,6 +95,7 @@ __device__ __forceinline__ float rows4_sum(float x) {
 
 template <class TT>
 __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QkvAttnArgs p) {
+    leaf_fp16_sat_mode();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);

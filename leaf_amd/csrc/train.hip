@@ -32,6 +32,7 @@ __device__ __forceinline__ void unpack4k(int kind, uint2 u, float (&o)[4]) {
 // floats) and the 16-bit pack uses the same offsets; grid = (32 x 32 tiles of one layer = 12 d^2 / 1024, layers).
 __global__ __launch_bounds__(256) void pack_transpose_kernel(const float* __restrict__ src, void* __restrict__ dst,
                                                              int dkind, int d) {
+    leaf_fp16_sat_mode();
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int dt = d >> 5;                         // tiles along a d-wide side
@@ -54,6 +55,7 @@ __global__ __launch_bounds__(256) void pack_transpose_kernel(const float* __rest
 
 __global__ __launch_bounds__(256) void cast16_kernel(const void* __restrict__ src, int kind, void* __restrict__ dst,
                                                      int dkind, size_t n) {
+    leaf_fp16_sat_mode();
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * 256;
     for (; i < n; i += stride) store16(dst, dkind, i, load_as_f32(src, kind, i));
@@ -64,6 +66,7 @@ __global__ __launch_bounds__(256) void cast16_kernel(const void* __restrict__ sr
 __global__ __launch_bounds__(256) void fare_rows_kernel(const float* __restrict__ feat, const float* __restrict__ anchor,
                                                         int B, int D, float scale, float* __restrict__ dout,
                                                         float* __restrict__ partial, const float* __restrict__ norms) {
+    leaf_fp16_sat_mode();
     __shared__ float red[12];
     const int tid = threadIdx.x, b = blockIdx.x;
     const float k = 2.0f / (float)B * scale;
@@ -111,6 +114,7 @@ __global__ __launch_bounds__(256) void fare_rows_kernel(const float* __restrict_
 
 // in place: x[b] /= max(||x[b]||, 1e-12) and norms[b] = ||x[b]||   (F.normalize of the training features, one wave per row)
 __global__ __launch_bounds__(256) void normalize_rows_kernel(float* __restrict__ x, float* __restrict__ norms, int M, int D) {
+    leaf_fp16_sat_mode();
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     float* xr = x + (size_t)row * D;
@@ -125,6 +129,7 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(float* __restrict__
 __global__ __launch_bounds__(256) void fare_reduce_kernel(const float* __restrict__ partial, int B, float* __restrict__ loss,
                                                           float* __restrict__ gscale, int use_scaling,
                                                           const float* __restrict__ scaler) {
+    leaf_fp16_sat_mode();
     __shared__ float red[8];
     const int tid = threadIdx.x;
     float s = 0.f, amax = 0.f;
@@ -155,6 +160,7 @@ __global__ __launch_bounds__(256) void fare_reduce_kernel(const float* __restric
 // dproj[k][j] += sum_b pooled[b][k] * dout[b][j]      grid = d blocks
 __global__ __launch_bounds__(256) void proj_wgrad_kernel(const float* __restrict__ pooled, const float* __restrict__ dout,
                                                          float* __restrict__ dproj, int B, int d, int D) {
+    leaf_fp16_sat_mode();
     // column k of `pooled` goes through LDS once, the dout loads of eight captions are in flight together (the first form issued one
     // dependent pair of loads per caption: 107 us for 0.15 GFLOP); same single accumulator per (k, j), captions in ascending order
     __shared__ float pk[256];
@@ -199,6 +205,7 @@ __global__ __launch_bounds__(256) void proj_wgrad_kernel(const float* __restrict
 // dpooled[b][k] = sum_j dout[b][j] * proj[k][j];   grid (n_seq, d / 32): a wave owns 8 k with 8 independent sums
 __global__ __launch_bounds__(256) void dpooled_kernel(const float* __restrict__ dout, const float* __restrict__ proj,
                                                       float* __restrict__ dpooled, int d, int D) {
+    leaf_fp16_sat_mode();
     const int b = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int k0 = blockIdx.y * 32 + wid * 8;
     float acc[8];
@@ -223,6 +230,7 @@ __global__ __launch_bounds__(256) void pool_ln_bwd_kernel(const float* __restric
                                                           const int32_t* __restrict__ eot_idx, const float* __restrict__ g,
                                                           float eps, float* __restrict__ dx, float* __restrict__ stats,
                                                           const float* __restrict__ gscale, int n_seq, RowMap map, int d) {
+    leaf_fp16_sat_mode();
     const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= n_seq) return;
     const int nq = d >> 2;
@@ -276,6 +284,7 @@ __global__ __launch_bounds__(256) void pool_ln_wgrad_kernel(const float* __restr
                                                             const int32_t* __restrict__ eot_idx,
                                                             const float* __restrict__ stats, float* __restrict__ dg,
                                                             float* __restrict__ db, int n_seq, RowMap map, int d) {
+    leaf_fp16_sat_mode();
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= d) return;
     float sg = 0.f, sb = 0.f;
@@ -318,6 +327,7 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ g, float eps, float* __restrict__ dx,
                                                          void* __restrict__ dx16, int gkind, float* __restrict__ part,
                                                          int rows, int d) {
+    leaf_fp16_sat_mode();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int nq = d >> 2;
@@ -404,6 +414,7 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const float* __restrict
 // dg[i][c] += inv_s * sum_wg part[i][wg][0][c] (db likewise) for n LayerNorms in one launch: grid (n, 2d / 64), a workgroup
 // owns 64 columns, its four waves sum a quarter of the partial rows each (ascending), combined in wave order: deterministic
 __global__ __launch_bounds__(256) void ln_param_reduce_kernel(LnReduceArgs a) {
+    leaf_fp16_sat_mode();
     __shared__ float red[4][64];
     const int i = blockIdx.x, cg = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int c = blockIdx.y * 64 + cg;              // column of the [2][d] partial row
@@ -425,6 +436,7 @@ __global__ __launch_bounds__(256) void ln_param_reduce_kernel(LnReduceArgs a) {
 // dpos[p][:] += sum_n dx[n*ctx+p][:]   (grid = ctx) ; dtok via atomics (grid-stride over rows)
 __global__ __launch_bounds__(256) void pos_bwd_kernel(const float* __restrict__ dx, const float* __restrict__ gscale,
                                                       float* __restrict__ dpos, int n_seq, RowMap map, int d) {
+    leaf_fp16_sat_mode();
     const int p = blockIdx.x;
     const int c = blockIdx.y * 256 + threadIdx.x;     // grid (ctx, ceil(d / 256)): one column per thread
     if (c < d) {
@@ -447,6 +459,7 @@ __global__ __launch_bounds__(256) void pos_bwd_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void tok_bwd_kernel(const float* __restrict__ dx, const float* __restrict__ gscale,
                                                       const int32_t* __restrict__ tokens, float* __restrict__ dtok, int rows,
                                                       int n_seq, RowMap map, int d, int vocab) {
+    leaf_fp16_sat_mode();
     const int row = blockIdx.x;
     const int sq = seq_of_row(map, row, n_seq);
     int tok = tokens[(size_t)sq * map.ctx + (row - seq_row(map, sq))];
@@ -460,6 +473,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     size_t n_decay, float lr, float b1, float b2, float eps, float wd,
                                                     float bc1, float sqrt_bc2, float gscale_host,
                                                     const float* __restrict__ clip_coef) {
+    leaf_fp16_sat_mode();
     // clip_coef: optional device scalar from clip_coef_kernel (--grad-clip-norm / the non-finite guard): gradients are
     // multiplied by it; a NEGATIVE value means the gradient norm was inf / NaN and the whole step is skipped (what
     // torch.cuda.amp.GradScaler.step does, train_AT_text_only.py:347, utils_AT.py:339-362)
@@ -490,6 +504,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 // ---- --grad-clip-norm (utils_AT.py:348-357: torch.nn.utils.clip_grad_norm_(parameters, c, 2.0) before the step)
 // partial[b] = sum of squares of this block's grid-stride share of g
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, size_t n4, float* __restrict__ partial) {
+    leaf_fp16_sat_mode();
     __shared__ float red[4];
     float s = 0.f;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
@@ -506,6 +521,7 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restr
 __global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict__ partial, int nb, float grad_scale,
                                                         float max_norm, float* __restrict__ out, int step_host, float beta1,
                                                         float beta2) {
+    leaf_fp16_sat_mode();
     __shared__ double red[4];
     double s = 0.0;
     for (int b = threadIdx.x; b < nb; b += 256) s += (double)partial[b];
@@ -544,6 +560,7 @@ __global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict_
 // finite -- the optimizer step's guard then skips the step as it would have without this call.
 __global__ __launch_bounds__(256) void clip_inplace_coef_kernel(const float* __restrict__ partial, int nb, float pre, float max_norm,
                                                                 float* __restrict__ coef) {
+    leaf_fp16_sat_mode();
     __shared__ double red[4];
     double s = 0.0;
     for (int b = threadIdx.x; b < nb; b += 256) s += (double)partial[b];
@@ -560,6 +577,7 @@ __global__ __launch_bounds__(256) void clip_inplace_coef_kernel(const float* __r
     }
 }
 __global__ __launch_bounds__(256) void scale_inplace_kernel(float* __restrict__ g, size_t n4, const float* __restrict__ coef) {
+    leaf_fp16_sat_mode();
     const float c = coef[0];
     if (c == 1.f) return;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
@@ -576,6 +594,7 @@ __global__ __launch_bounds__(256) void scale_inplace_kernel(float* __restrict__ 
 // that the non-finite guard of the optimizer step skips the step on THIS rank and, through the gradient all-reduce, on every rank.
 struct SatArgs { const uint16_t* buf[5]; unsigned long long n8[5]; };   // element counts in units of 8 (16-byte chunks)
 __global__ __launch_bounds__(256) void sat_check16_kernel(SatArgs a, float* __restrict__ scaler, float* __restrict__ poison) {
+    leaf_fp16_sat_mode();
     unsigned hit = 0;
 #pragma unroll
     for (int b = 0; b < 5; ++b) {
@@ -603,6 +622,7 @@ namespace {
 // dst = src * scale[0]  (un-scaling of the loss-scaled gradient stream: d loss / d delta)
 __global__ __launch_bounds__(256) void scale_copy_kernel(const float* __restrict__ src, const float* __restrict__ scale,
                                                          float* __restrict__ dst, size_t n4) {
+    leaf_fp16_sat_mode();
     const float sc = scale[0];
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         float4 v = ((const float4*)src)[i];
@@ -630,6 +650,7 @@ __device__ __forceinline__ float linf_update(float x, float g, float alpha, floa
 
 __global__ __launch_bounds__(256) void pgd_step_kernel(float* __restrict__ delta, const float* __restrict__ grad, RowMap map,
                                                        int d, float alpha, float eps, int norm_l2) {
+    leaf_fp16_sat_mode();
     __shared__ float red[4];
     const int sq = map.s0 + blockIdx.x;
     const size_t base = (size_t)seq_row(map, sq) * d;

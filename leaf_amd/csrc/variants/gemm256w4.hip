@@ -30,6 +30,7 @@ __device__ __forceinline__ int lds_off_w4(int row, int chunk) { return row * 128
 
 template <class TT, int EPI>
 __global__ __launch_bounds__(256, 1) void gemm_nt256_w4_kernel(GemmArgs p) {
+    leaf_fp16_sat_mode();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -83,6 +83,7 @@ __device__ __forceinline__ u32x4 cvt8(u32x4 v) {
 // instantiation faulted.  The LDS-DMA form below has no such registers.)
 template <class XT, class GT>
 __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(WgradArgs a) {
+    leaf_fp16_sat_mode();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     // XCD-aware order: blocks that share an XCD (blockIdx % 8) take a contiguous range of tiles, so the tiles that re-read one
@@ -229,6 +230,7 @@ __device__ __forceinline__ int swz(int row) { return 2 * ((row & 3) | (((row >> 
 
 template <class GT>
 __global__ __launch_bounds__(256, 2) void wgrad_tn_dma_kernel(WgradArgs a) {
+    leaf_fp16_sat_mode();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
