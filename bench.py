@@ -551,7 +551,7 @@ def main():
                                     f"the reference's text attack): k={args.k_adv} steps, {args.pgd_norm} eps={args.pgd_eps} "
                                     f"alpha={args.pgd_alpha}, B={B} per GPU, seq=77"),
                        "attack": args.attack, "split_blocks": args.split_blocks,
-                       "residual_stream": ("16-bit copy + remainder byte (2^-19 per store) in the forward-only passes; fp32 in the training forward / backward"
+                       "residual_stream": ("16-bit copy + block-scaled e4m3 remainder byte (2^-16 per store) in the forward-only passes; fp32 in the training forward / backward"
                                            if compact else "fp32"), "accum_freq": args.accum_freq, "baseline_config_index": args.config or None, "workload_key": wkey,
                        "global_batch": B * world, "seq_len": cfg.context_length, "rho": args.rho, "k": args.k_adv,
                        "parallelism": f"dp{world}", "candidate_forwards_per_step_per_gpu": 2 * args.rho * args.k_adv * B},

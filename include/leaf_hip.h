@@ -318,8 +318,8 @@ int leaf_op_gemm_ld(int dtype, int epi, const void* A, int lda, const void* B, i
 int leaf_op_gemm_resid_ln(int dtype, const void* A, const void* B, float* C, const float* bias, void* x16, void* stat, int M, int N,
                           int K, leaf_stream_t s);
 /* The residual stream of the LN-folded forward-only passes in 16 + 8 bits (option 'compact_resid', default on): a residual value x is
- * held as x16 = 16-bit(x) -- the copy the next GEMM multiplies anyway -- and lo8 = the remainder x - x16 as a signed byte in 1/256ths of x16's unit in the last place, i.e.
- * to 2^-19 relative (fp16) in 3 bytes instead of an fp32 row beside the 16-bit copy (6 bytes).  leaf_op_gemm_resid_ln8: the producer above
+ * held as x16 = 16-bit(x) -- the copy the next GEMM multiplies anyway -- and lo8 = the remainder x - x16 as an e4m3 byte, block-scaled (four consecutive values share
+ * the power of two of their largest |x16|; v_cvt_scalef32_pk_fp8_f32 / _f32_fp8), i.e. to 2^-16 of that largest value (fp16) in 3 bytes instead of an fp32 row beside the 16-bit copy (6 bytes).  leaf_op_gemm_resid_ln8: the producer above
  * on that format, (x16, lo8) [M,N] updated IN PLACE, stat as above.  leaf_op_resid_pack / _unpack: the format itself, element-wise
  * (n % 4 == 0).  The reference's residual stream is fp32 (transformer.py:254-265); the difference is far inside the 16-bit operand
  * rounding of every GEMM (tests/test_gpu_kernels.py, test_compact_residual_*). */

@@ -86,47 +86,51 @@ __device__ __forceinline__ void unpack4(uint2 u, float (&o)[4]) {
 }
 
 // ---- Residual stream of the forward-only passes in 16 + 8 bits (api.hip "compact residual").  A residual value x is kept as
-// hi = the 16-bit copy the next GEMM multiplies anyway (x16) and lo8 = the remainder x - hi in 1/256ths of hi's unit in the last
-// place, a signed byte: x - hi is exact in fp32 and at most half an ulp of hi, so q = rne((x - hi) * 2^(8 + MANT - e)) lies in
-// [-128, 128] (e = hi's binary exponent, MANT = 10 for fp16, 7 for bf16; clamped to +-127) and x comes back to 2^-(MANT + 9)
-// relative -- 2^-19 for fp16, against fp32's 2^-24 and the 2^-11 of every GEMM operand -- from 3 bytes instead of the 6 of an
-// fp32 row beside its 16-bit copy.  Both scale factors are powers of two built from the exponent field of float(hi) (for hi = 0
-// and for fp16-subnormal hi the factors are off, the remainder then clamps or vanishes: |x| < 2^-14, an error below 2^-25).
+// hi = the 16-bit copy the next GEMM multiplies anyway (x16) and lo8 = its remainder x - hi (exact in fp32, at most half an ulp of
+// hi) as an fp8 e4m3 number in a BLOCK-SCALED format: the four values a lane holds (4 consecutive columns) share one power-of-two
+// scale -- the exponent of the largest |hi| among them, at least fp16's smallest normal -- and CDNA4's MX conversions do the rest:
+// v_cvt_scalef32_pk_fp8_f32 rounds two values to e4m3 (nearest-even) after dividing by the scale operand's power of two,
+// v_cvt_scalef32_pk_f32_fp8 multiplies it back (tools/scalef32_probe.hip).  With the remainder pre-multiplied by 2^(MANT + 7) the
+// largest one lands on 64, inside e4m3's top binade (steps of 4): every value of the chunk comes back to 2^-(MANT + 6) of the
+// chunk's LARGEST magnitude -- 2^-16 for fp16, against fp32's 2^-24 and the 2^-11 of every GEMM operand -- from 3 bytes instead
+// of the 6 of an fp32 row beside its 16-bit copy, for ~7 vector instructions per element (encode + decode).
 template <class TT> struct ResidLo;
-template <> struct ResidLo<F16> { static constexpr int mant = 10; };
-template <> struct ResidLo<BF16> { static constexpr int mant = 7; };
-// (returns the byte in bits 0-7 of a dword whose upper bits are the magic constant's: the caller picks byte 0)
-template <class TT>
-__device__ __forceinline__ unsigned resid_lo1(float x, float h) {
-    const unsigned e8 = __builtin_bit_cast(unsigned, h) & 0x7F800000u;
-    const float up = __builtin_bit_cast(float, ((unsigned)(254 + 8 + ResidLo<TT>::mant) << 23) - e8);      // 2^(8 + mant - e)
-    const float r = __builtin_amdgcn_fmed3f((x - h) * up, -127.f, 127.f);
-    // + 1.5 * 2^23: the sum's rounding IS round-to-nearest-even to an integer, which then sits in the low mantissa bits (two's complement)
-    return __builtin_bit_cast(unsigned, r + 12582912.f);
+template <> struct ResidLo<F16> { static constexpr float up = 131072.f, down = 1.f / 131072.f, floor = 6.103515625e-05f, xmax = 65520.f; };     // 2^17, 2^-14
+template <> struct ResidLo<BF16> { static constexpr float up = 16384.f, down = 1.f / 16384.f, floor = 1.1754943508222875e-38f, xmax = 3.0e38f; };  // 2^14, 2^-126
+// the chunk's scale operand: only its exponent field is used by the conversions
+__device__ __forceinline__ float resid_scale4(const float (&h)[4], float floor_) {
+    return __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(h[0]), __builtin_fabsf(h[1])), floor_),
+                           __builtin_fmaxf(__builtin_fabsf(h[2]), __builtin_fabsf(h[3])));
 }
-// four residual values + their packed 16-bit copy -> the four remainder bytes (one dword): byte 0 of each of the four results,
-// gathered by three byte permutes (v_perm_b32 selector: 0-3 = bytes of the second operand, 4-7 of the first)
+// four residual values + their packed 16-bit copy -> the four remainder bytes (one dword)
 template <class TT>
 __device__ __forceinline__ unsigned resid_lo4(float a, float b, float c, float d, uint2 hi) {
+    typedef short s16x2_t __attribute__((ext_vector_type(2)));
     float h[4];
     unpack4<TT>(hi, h);
-    const unsigned ab = __builtin_amdgcn_perm(resid_lo1<TT>(b, h[1]), resid_lo1<TT>(a, h[0]), 0x0c0c0400u);   // (0, 0, b, a)
-    const unsigned cd = __builtin_amdgcn_perm(resid_lo1<TT>(d, h[3]), resid_lo1<TT>(c, h[2]), 0x0c0c0400u);
-    return __builtin_amdgcn_perm(cd, ab, 0x05040100u);                                                           // (d, c, b, a)
-}
-template <class TT>
-__device__ __forceinline__ float resid_decode1(float h, int q) {
-    const unsigned e8 = __builtin_bit_cast(unsigned, h) & 0x7F800000u;
-    const float down = __builtin_bit_cast(float, e8 - ((unsigned)(8 + ResidLo<TT>::mant) << 23));         // 2^(e - 8 - mant)
-    return __builtin_fmaf((float)q, down, h);
+    const float sc = resid_scale4(h, ResidLo<TT>::floor);
+    // (a value beyond the 16-bit type's largest saturates hi; its remainder is cut at half an ulp of that largest: never NaN)
+    constexpr float xm = ResidLo<TT>::xmax;
+    a = __builtin_amdgcn_fmed3f(a, -xm, xm); b = __builtin_amdgcn_fmed3f(b, -xm, xm);
+    c = __builtin_amdgcn_fmed3f(c, -xm, xm); d = __builtin_amdgcn_fmed3f(d, -xm, xm);
+    const f32x2 r01 = (f32x2{a, b} - f32x2{h[0], h[1]}) * ResidLo<TT>::up;
+    const f32x2 r23 = (f32x2{c, d} - f32x2{h[2], h[3]}) * ResidLo<TT>::up;
+    s16x2_t w = {0, 0};
+    w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, r01.x, r01.y, sc, false);
+    w = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w, r23.x, r23.y, sc, true);
+    return __builtin_bit_cast(unsigned, w);
 }
 template <class TT>
 __device__ __forceinline__ float4 resid_decode4(uint2 hi, unsigned lo) {
     float h[4];
     unpack4<TT>(hi, h);
-    const int w = (int)lo;
-    return float4{resid_decode1<TT>(h[0], (int)(signed char)(w & 0xFF)), resid_decode1<TT>(h[1], (int)(signed char)((w >> 8) & 0xFF)),
-                  resid_decode1<TT>(h[2], (int)(signed char)((w >> 16) & 0xFF)), resid_decode1<TT>(h[3], w >> 24)};
+    const float sc = resid_scale4(h, ResidLo<TT>::floor);
+    const f32x2 r01 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(lo, sc, false);
+    const f32x2 r23 = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(lo, sc, true);
+    const f32x2 dn = f32x2{ResidLo<TT>::down, ResidLo<TT>::down};
+    const f32x2 x01 = __builtin_elementwise_fma(r01, dn, f32x2{h[0], h[1]});
+    const f32x2 x23 = __builtin_elementwise_fma(r23, dn, f32x2{h[2], h[3]});
+    return float4{x01.x, x01.y, x23.x, x23.y};
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -56,7 +56,7 @@ struct leaf_text {
     // s_qkv[3d], c_qkv[3d], s_fc[4d], c_fc[4d] per layer.
     int ln_fold = 1;          // option 'ln_fold' / LEAF_LN_FOLD=0: separate LayerNorm kernels instead
     // Residual stream of the LN-folded forward-only passes in 16 + 8 bits (common.h resid_lo4): the 16-bit copy the next GEMM
-    // multiplies anyway + a remainder byte per element (1/256ths of that copy's last place) instead of an fp32 row beside that copy -- the out-projection moves 8 d bytes
+    // multiplies anyway + a remainder byte per element (block-scaled e4m3, common.h resid_lo4) instead of an fp32 row beside that copy -- the out-projection moves 8 d bytes
     // per row instead of 12 d, c_proj 14 d instead of 18 d.  Option 'compact_resid' / LEAF_COMPACT_RESID=0: fp32 rows (also what the
     // split blocks of leaf_text_split_pack and widths the fp32 matrix-core projection does not take run on).
     int compact_resid = 1;

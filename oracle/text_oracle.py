@@ -487,24 +487,49 @@ def round_fp16(a: np.ndarray) -> np.ndarray:
 # ---- the 16 + 8-bit residual format of the engine's forward-only passes (leaf_amd/csrc/common.h resid_lo4 / resid_decode4; no
 # counterpart in the reference, whose residual stream is fp32, src/open_clip/transformer.py:254-265).  Test infrastructure: the
 # GPU suite holds the kernels to these byte-exact definitions.
+def e4m3_encode(v: np.ndarray) -> np.ndarray:
+    """fp32 -> OCP e4m3fn bytes (bias 7, three mantissa bits, subnormal step 2^-9, no inf), round-to-nearest-even; |v| <= 448."""
+    x = np.ascontiguousarray(v, dtype=F32)
+    u = x.view(np.uint32)
+    sign = ((u >> 24) & 0x80).astype(np.uint8)
+    mag = np.abs(x)
+    r = (u & np.uint32(0x7FFFFFFF)) + np.uint32(0x7FFFF) + ((u >> 20) & np.uint32(1))
+    normal = (((r >> 20) - np.uint32((127 - 7) << 3)) & np.uint32(0x7F)).astype(np.uint8)
+    sub = np.rint(np.minimum(mag, F32(2.0 ** -6)).astype(np.float64) * 512.0).astype(np.uint8)
+    return (np.where(mag < 2.0 ** -6, sub, normal) | sign).astype(np.uint8)
+
+
+def e4m3_decode(b: np.ndarray) -> np.ndarray:
+    b = np.asarray(b, dtype=np.uint8)
+    e, m = ((b >> 3) & 15).astype(np.int32), (b & 7).astype(np.float64)
+    mag = np.where(e == 0, m * 2.0 ** -9, (1.0 + m / 8.0) * np.exp2((e - 7).astype(np.float64)))
+    return np.where(b & 0x80, -mag, mag).astype(F32)
+
+
+def _resid_chunk_scale(hi: np.ndarray, mant: int) -> np.ndarray:
+    """the power of two the four values of a chunk share: 2^floor(log2(max(|hi| of the chunk, smallest normal)))"""
+    floor = F32(2.0 ** -14) if mant == 10 else F32(2.0 ** -126)
+    sc = np.maximum(np.abs(hi).reshape(-1, 4).max(-1), floor).astype(F32)
+    return (sc.view(np.uint32) & np.uint32(0x7F800000)).view(F32)
+
+
 def resid_pack(x: np.ndarray, mant: int = 10):
-    """x (fp32) -> (hi: fp16(x) saturated -- bf16(x) for mant = 7 --, as fp32 values; lo8: int8 remainder in 1/256ths of hi's unit
-    in the last place):
-    q = clip(rne((x - hi) * 2^(8 + mant - e)), -127, 127), e = the binary exponent of float(hi) (its fp32 exponent field, also for
-    fp16-subnormal hi and hi = 0 -- the same bit arithmetic as the kernel)."""
+    """x (fp32, size % 4 == 0, chunks of 4 consecutive values) -> (hi: fp16(x) saturated -- bf16(x) for mant = 7 --, as fp32 values;
+    lo8: e4m3((x - hi) * 2^(mant + 7) / chunk scale), the block-scaled remainder of common.h resid_lo4)."""
     x = np.ascontiguousarray(x, dtype=F32)
-    hi = np.clip(x, -65504.0, 65504.0).astype(np.float16).astype(F32) if mant == 10 else np.ascontiguousarray(round_bf16(x))
-    e8 = hi.view(np.uint32) & np.uint32(0x7F800000)
-    up = ((np.uint32((254 + 8 + mant) << 23) - e8) & np.uint32(0xFFFFFFFF)).astype(np.uint32).view(F32)
+    shape = x.shape
+    hi = (np.clip(x, -65504.0, 65504.0).astype(np.float16).astype(F32) if mant == 10 else np.ascontiguousarray(round_bf16(x))).reshape(-1)
+    xmax = F32(65520.0) if mant == 10 else F32(3.0e38)
+    d = ((np.clip(x.reshape(-1), -xmax, xmax) - hi).astype(F32) * F32(2.0 ** (mant + 7))).astype(F32)
+    pow2 = np.repeat(_resid_chunk_scale(hi, mant), 4)
     with np.errstate(over="ignore", invalid="ignore"):
-        r = ((x - hi).astype(F32) * up).astype(F32)
-    r = np.clip(np.nan_to_num(r, nan=0.0, posinf=127.0, neginf=-127.0), -127.0, 127.0)
-    return hi, np.rint(r).astype(np.int8)
+        lo8 = e4m3_encode((d / pow2).astype(F32))
+    return hi.reshape(shape), lo8.reshape(shape)
 
 
 def resid_unpack(hi: np.ndarray, lo8: np.ndarray, mant: int = 10) -> np.ndarray:
     hi = np.ascontiguousarray(hi, dtype=F32)
-    e8 = hi.view(np.uint32) & np.uint32(0x7F800000)
-    down = ((e8 - np.uint32((8 + mant) << 23)) & np.uint32(0xFFFFFFFF)).astype(np.uint32).view(F32)
-    with np.errstate(over="ignore", invalid="ignore"):
-        return (np.asarray(lo8, dtype=np.int8).astype(np.float64) * down.astype(np.float64) + hi.astype(np.float64)).astype(F32)
+    shape = hi.shape
+    pow2 = np.repeat(_resid_chunk_scale(hi.reshape(-1), mant), 4).astype(np.float64)
+    r = e4m3_decode(np.asarray(lo8).reshape(-1).view(np.uint8)).astype(np.float64) * pow2
+    return (r * 2.0 ** -(mant + 7) + hi.reshape(-1).astype(np.float64)).astype(F32).reshape(shape)

@@ -224,26 +224,29 @@ def test_fp16_operand_noise_of_the_tiny_config(golden_dir):
 
 def test_residual_16_8_format_properties(golden_dir):
     """The engine's 16 + 8-bit residual stream as the oracle states it (oracle.resid_pack / resid_unpack; the GPU suite holds the
-    kernels to these definitions byte for byte): exact on every fp16 value, within 2^-19 of x (2^-18 on a clamped tie) for fp16
-    normals, idempotent, finite for anything fp32 holds, and -- emulated inside the fp32 forward of the reference-generated tiny
-    fixture -- three orders of magnitude below the 1e-3 embedding gate."""
+    kernels to these definitions byte for byte): exact on every fp16 value, every value of a chunk of four within 2^-16 of the
+    chunk's largest magnitude, finite for anything fp32 holds, and -- emulated inside the fp32 forward of the reference-generated
+    tiny fixture -- two orders of magnitude below the 1e-3 embedding gate.  The e4m3 codec itself is checked against the bytes an
+    MI355X produced (tools/scalef32_probe.hip)."""
+    probe = np.float32([1, 3, 0.1, 17, 18, 19, 20, 100, 448, 0.001, 0.002, 0.0078125, 1.0625, 1.1875, 1.3125, 36, 44, 52, 60])
+    assert [int(b) for b in O.e4m3_encode(probe)] == [0x38, 0x44, 0x1D, 0x58, 0x59, 0x5A, 0x5A, 0x6C, 0x7E, 0x01, 0x01, 0x04, 0x38, 0x3A,
+                                                      0x3A, 0x61, 0x63, 0x65, 0x67]
+    assert np.array_equal(O.e4m3_decode(np.arange(0x7F, dtype=np.uint8))[[0x38, 0x44, 0x1D, 0x7E, 0x01, 0x04]],
+                          np.float32([1, 3, 0.1015625, 448, 2.0 ** -9, 2.0 ** -7]))
     rng = np.random.default_rng(3)
     h16 = rng.standard_normal(20000).astype(np.float16).astype(np.float32)
     hi, lo = O.resid_pack(h16)
-    assert np.array_equal(hi, h16) and not lo.any() and np.array_equal(O.resid_unpack(hi, lo), h16)
-    x = (rng.standard_normal(200000) * np.exp(rng.uniform(-9, 11, 200000))).astype(np.float32)
-    x = x[(np.abs(x) > 6.2e-5) & (np.abs(x) < 65504)]
+    assert np.array_equal(hi, h16) and not (lo & 0x7F).any() and np.array_equal(O.resid_unpack(hi, lo), h16)
+    x = np.clip((rng.standard_normal(200000) * np.exp(rng.uniform(-9, 11, 200000))).astype(np.float32), -65000, 65000)
     hi, lo = O.resid_pack(x)
     back = O.resid_unpack(hi, lo)
-    rel = np.abs(back.astype(np.float64) - x) / np.abs(x)
-    assert rel.max() <= 2.0 ** -18 and np.quantile(rel, 0.99) <= 2.0 ** -19      # (the 0.2 % with a remainder above 127.5 / 256 ulp clamp)
-    hi2, lo2 = O.resid_pack(back)
-    assert np.array_equal(hi2, hi) and np.array_equal(lo2, lo)
-    wild = np.float32([0, -0.0, 1e-30, 6e-8, 65519.9, 1e9, -3e38])
+    cmax = np.repeat(np.abs(x).reshape(-1, 4).max(-1), 4)
+    assert (np.abs(back.astype(np.float64) - x) / cmax).max() <= 2.0 ** -16
+    wild = np.float32([0, -0.0, 1e-30, 6e-8, 65519.9, 1e9, -3e38, 1.0])
     assert np.isfinite(O.resid_unpack(*O.resid_pack(wild))).all()
     z = np.load(os.path.join(golden_dir, "tiny_quickgelu.npz"))
     cfg = O.TextCfg(128, 2, 2, 64, quick_gelu=True)
     w = O.init_weights(cfg, seed=12)
     ref = O.encode_text(w, cfg, z["tokens"])
     got = O.encode_text(w, cfg, z["tokens"], resid=lambda a: O.resid_unpack(*O.resid_pack(a)))
-    assert rel_l2(ref, z["out"]) < 5e-6 and rel_l2(got, ref) < 5e-6
+    assert rel_l2(ref, z["out"]) < 5e-6 and rel_l2(got, ref) < 2e-5
