@@ -170,6 +170,69 @@ def dry_run(args):
         dist.destroy_process_group()
 
 
+def dp_bucket_summary(model):
+    """The gradient buckets GradReducer all-reduces, in issue order (leaf_amd/step.py:bucket_plan): which backward event releases
+    each one and its bytes.  Only the LAST one (embedding tables + every vector) cannot overlap the backward."""
+    from leaf_amd.step import bucket_plan
+    plan = bucket_plan(model.layout, model.n_params, model.cfg.layers)
+    return [{"released_by_block": int(ev) if ev < model.cfg.layers else "end of backward", "bytes": int(sum(n for _, n in ranges) * 4),
+             "collectives": int(sum(1 for _, n in ranges if n))} for ev, ranges in plan]
+
+
+XGMI_LINK_GBS_PER_DIRECTION = 76.8      # MI355X: 7 xGMI links per GPU x ~153 GB/s bidirectional each (the task's figures) = 76.8 GB/s per direction
+XGMI_LINKS = 7
+XGMI_PROTOCOL_EFF = 0.75                # ASSUMED share of the link rate a large RCCL ring sustains (no multi-GPU box to measure it)
+
+
+def exposed_collective_model(model, dev, R):
+    """What of the gradient reduction stays exposed on R GPUs: the last bucket.  MEASURED here: the time a one-rank RCCL group
+    needs for exactly that bucket's all-reduce calls (launch + RCCL's own kernel, no link traffic).  MODELLED: the link time of a
+    ring all-reduce over fully connected point-to-point xGMI -- RCCL builds min(R - 1, 7) link-disjoint rings, each bound by ONE
+    link direction: t = 2 (R - 1) / R * bytes / (rings * 76.8 GB/s * 0.75)."""
+    import torch
+    import torch.distributed as dist
+    from leaf_amd.step import bucket_plan
+    last = bucket_plan(model.layout, model.n_params, model.cfg.layers)[-1][1]
+    nbytes = sum(n for _, n in last) * 4
+    launch_ms, how, created = None, "not measured", False
+    try:
+        if not dist.is_initialized():
+            created = True
+            if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+                del os.environ["NCCL_DEBUG"]
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        if dist.get_backend() == "nccl" and model.grads is not None:
+            cur = torch.cuda.current_stream(dev)
+            saved = [model.grads[o:o + n].clone() for o, n in last]
+
+            def once():
+                for o, n in last:
+                    if n:
+                        dist.all_reduce(model.grads[o:o + n], op=dist.ReduceOp.SUM)
+            for _ in range(3):
+                once()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(cur)
+            for _ in range(20):
+                once()
+            e1.record(cur)
+            e1.synchronize()
+            launch_ms, how = e0.elapsed_time(e1) / 20, "one-rank RCCL group on this GPU, 20 repetitions of the bucket's all-reduce calls"
+            for (o, n), v in zip(last, saved):
+                model.grads[o:o + n].copy_(v)
+    except Exception as e:      # the model is still printed, without the measured part
+        how = f"not measured ({type(e).__name__}: {e})"
+    if created and dist.is_initialized():
+        dist.destroy_process_group()
+    rings = max(1, min(R - 1, XGMI_LINKS))
+    link_ms = 0.0 if R < 2 else 2 * (R - 1) / R * nbytes / (rings * XGMI_LINK_GBS_PER_DIRECTION * 1e9 * XGMI_PROTOCOL_EFF) * 1e3
+    return {"bucket_bytes": int(nbytes), "one_rank_rccl_ms_measured": launch_ms, "measured_how": how, "ranks": R, "rings_assumed": rings,
+            "link_GBs_per_direction": XGMI_LINK_GBS_PER_DIRECTION, "protocol_efficiency_assumed": XGMI_PROTOCOL_EFF,
+            "link_ms_model": link_ms, "exposed_ms_model": link_ms + (launch_ms or 0.0)}
+
+
 def rank_sim(args, model, frozen, sc, batch_for, dev, B):
     """the R-GPU step predicted from one GPU.  Data parallelism here = every rank searches and back-propagates its
     own B captions on the SAME weights, the gradients are summed, one AdamW.  That is what this loop executes, one rank after the
@@ -195,8 +258,8 @@ def rank_sim(args, model, frozen, sc, batch_for, dev, B):
                               prefix_reuse=not args.no_prefix_reuse, base_ready=ready, micro_index=r, optimizer_step=False)
             evs[r + 1].record(cur)
             rows.append(model.rows_scored - rows0)
-        get_reducer(model).finish()
-        model.adamw_step(sc.lr, (sc.beta1, sc.beta2), sc.eps, sc.wd, grad_scale=1.0)
+        scale = get_reducer(model).finish()         # 1.0 here: one process (main() refuses --rank-sim under a multi-rank launch)
+        model.adamw_step(sc.lr, (sc.beta1, sc.beta2), sc.eps, sc.wd, grad_scale=scale)
         model.pack()
         evs[R + 1].record(cur)
         if timed:
@@ -213,9 +276,10 @@ def rank_sim(args, model, frozen, sc, batch_for, dev, B):
     mean_r = [statistics.mean(x) for x in t]
     max_r = [max(x) for x in t]
     opt = statistics.mean(t_opt)
-    exposed = float(os.environ.get("LEAF_RANKSIM_EXPOSED_MS", "0.9"))     # last bucket of the overlapped all-reduce
     one_gpu = statistics.mean(mean_r) + opt
     n_gpu = statistics.mean(max_r) + opt
+    coll = exposed_collective_model(model, dev, R)
+    exposed = float(os.environ["LEAF_RANKSIM_EXPOSED_MS"]) if "LEAF_RANKSIM_EXPOSED_MS" in os.environ else coll["exposed_ms_model"]
     out = {"rank_sim": R, "steps": args.steps, "warmup": args.warmup, "B_per_rank": B, "model": args.model, "k": args.k_adv, "rho": args.rho,
            "batches": "fixed per rank" if args.fixed_batch else "new per (rank, step)",
            "ms_per_rank_step_mean": statistics.mean(mean_r), "ms_per_rank_step_by_rank": [statistics.mean(x[r] for x in t) for r in range(R)],
@@ -224,14 +288,17 @@ def rank_sim(args, model, frozen, sc, batch_for, dev, B):
            "rank_time_cv": statistics.mean(statistics.pstdev(x) / statistics.mean(x) for x in t),
            "scored_rows_per_rank_step_min_mean_max": [min(min(r_) for _, r_ in per_step), statistics.mean(statistics.mean(r_) for _, r_ in per_step),
                                                       max(max(r_) for _, r_ in per_step)],
-           "pred_eff_skew_only": one_gpu / n_gpu,
-           "exposed_collective_ms_assumed": exposed,
-           "pred_eff": one_gpu / (n_gpu + exposed),
-           "pred_samples_per_s_R_gpus": R * B / ((n_gpu + exposed) * 1e-3),
+           "pred_eff_skew_only": one_gpu / n_gpu,                       # MEASURED on this GPU: the headline of this mode
+           "exposed_collective": coll,
+           "exposed_collective_ms_used": exposed,
+           "pred_eff_with_collective_ESTIMATE": one_gpu / (n_gpu + exposed),
+           "pred_samples_per_s_R_gpus_ESTIMATE": R * B / ((n_gpu + exposed) * 1e-3),
            "samples_per_s_one_gpu_same_loop": B / (one_gpu * 1e-3),
            "note": "one GPU, ranks run one after another on the same weights (gradient sum, one AdamW = the R-rank step's arithmetic); "
                    "t_r = events around rank r's anchor + search + forward + backward; the anchor of rank r + 1 overlaps the tail of rank r "
-                   "as in the real step; exposed collective = an ESTIMATE (no multi-GPU box), override with LEAF_RANKSIM_EXPOSED_MS"}
+                   "as in the real step.  pred_eff_skew_only is measured; the collective term is a MODEL (measured one-rank RCCL launch "
+                   "time of the exposed bucket + its bytes over the stated xGMI link figures), never a measurement: "
+                   "override with LEAF_RANKSIM_EXPOSED_MS"}
     print(json.dumps(out), flush=True)
 
 
@@ -428,6 +495,8 @@ def main():
     base_lens = None if args.dense else True          # run_steps: None = dense rows, else the batch's own kept-row counts
     lib = _lib.lib()
     if args.rank_sim:
+        if world > 1:
+            raise SystemExit("--rank-sim predicts the R-GPU step from ONE process; it refuses a multi-rank launch (measure instead: --gpus N)")
         return rank_sim(args, model, frozen, sc, batch_for, dev, B)
     run_steps(args.warmup, base_lens, not args.no_prefix_reuse)
     from leaf_amd.step import get_reducer
@@ -537,6 +606,8 @@ def main():
             "metric": "adversarial text samples/sec", "value": value, "unit": "samples/s",
             "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps, "warmup": args.warmup,
             "host_threads_per_rank": args.host_threads,
+            "dp_gradient_buckets": {"overlap_with_backward": os.environ.get("LEAF_DP_OVERLAP", "1") != "0", "active": bool(use_dist),
+                                    "buckets_in_issue_order": dp_bucket_summary(model)},
             **({"per_rank": per_rank_summary(gathered)} if gathered is not None else {}),
             **({"rehearsal": f"gloo transport, {world} rank(s) on {ndev} device(s): functional rehearsal of the multi-rank step, "
                              "NOT the metric (RCCL, one device per rank, is)"} if rehearsal else {}),

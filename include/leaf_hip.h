@@ -91,6 +91,16 @@ int leaf_text_forward(leaf_text_t h, const float* params, const void* w16_fwd, c
                       const int32_t* seq_lens, const int32_t* cu_rows, int n_seq, float* out, int normalize, void* ws,
                       size_t ws_bytes, leaf_stream_t s);
 
+/* The same function in fp32-grade arithmetic ("precise" mode, leaf_amd/csrc/precise.hip): fp32 stored intermediates, the fp32
+ * MASTER weights (no 16-bit pack is read) and three MFMA passes of on-the-fly fp16 hi / lo splits per GEMM, fp32 LayerNorm /
+ * softmax / activation.  For embeddings that leave the engine (export, eval_textfare.py:119-141) and, optionally, the frozen
+ * model's anchor pass (utils_AT.py:296); B-caption sized work, about 8x the time per row of leaf_text_forward.  Same row-plan
+ * arguments (seq_lens host / cu_rows device, both NULL = dense). */
+size_t leaf_text_precise_workspace_bytes(leaf_text_t h, int n_seq);
+int leaf_text_forward_precise(leaf_text_t h, const float* params, const int32_t* tokens, const int32_t* seq_lens,
+                              const int32_t* cu_rows, int n_seq, float* out, int normalize, void* ws, size_t ws_bytes,
+                              leaf_stream_t s);
+
 /* one search stage of attack_text_leaf (utils_attacks.py:330-348 / 368-386,393): forward of B*rho candidates,
  * loss per objective against anchor [B,embed_dim], first-index arg-max over rho, gather of the winning rows.
  * loss (fp32 [B,rho]) and best_feat (fp32 [B,embed_dim]) may be NULL. */

@@ -34,6 +34,9 @@ _SIGS = {
     "leaf_text_stash_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
     "leaf_text_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                     C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "leaf_text_precise_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
+    "leaf_text_forward_precise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                            C.c_void_p, C.c_size_t, C.c_void_p]),
     "leaf_score_candidates": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -288,9 +288,32 @@ class LeafCLIPText:
         # pinned + non_blocking: a pageable H2D copy would make the host wait for all queued GPU work
         return C.c_void_p(lens.ctypes.data), torch.from_numpy(cu).pin_memory().to(self.device, non_blocking=True), lens
 
-    def encode_text(self, text, normalize: bool = False, seq_lens=None) -> torch.Tensor:
+    precise_ready = True      # leaf_text_forward_precise is part of this build (tests/row_error_census.py asks)
+
+    def encode_text(self, text, normalize: bool = False, seq_lens=None, precise: Optional[bool] = None) -> torch.Tensor:
+        """``precise`` (default: the model's ``precise_encode`` attribute, False): the fp32-grade forward of precise.hip -- fp32 stored
+        intermediates, fp32 master weights through three MFMA passes of fp16 hi / lo splits -- for embeddings that leave the engine
+        (export, eval_textfare) or the frozen model's anchors; ~1e-6 of the fp32 reference per row instead of ~9e-4, about 8x the
+        time per row.  The search's scoring passes always run the 16-bit arithmetic."""
         if len(text) == 0:      # an empty batch encodes to an empty [0, embed_dim] tensor, as the torch module's (model.py:269-284)
             return torch.empty(0, self.cfg.embed_dim, dtype=torch.float32, device=self.device)
+        if precise is None:
+            precise = getattr(self, "precise_encode", False)
+        if precise:
+            lens_p, cu, keep = self._row_plan(text, seq_lens)
+            t = self._tokens(text)
+            n = t.shape[0]
+            out = torch.empty(n, self.cfg.embed_dim, dtype=torch.float32, device=self.device)
+            need = self._lib.leaf_text_precise_workspace_bytes(self._h, n)
+            ws = self._ws.get("precise")
+            if ws is None or ws.numel() < need:
+                self._ws["precise"] = ws = None
+                with torch.cuda.device(self.device):
+                    self._ws["precise"] = ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            _lib.check(self._lib.leaf_text_forward_precise(self._h, _ptr(self.flat), _ptr(t), lens_p, _ptr(cu), n, _ptr(out),
+                                                           int(bool(normalize)), _ptr(ws), ws.numel(), self._stream()),
+                       "leaf_text_forward_precise")
+            return out
         if not self._packed:
             self.pack()
         lens_p, cu, keep = self._row_plan(text, seq_lens)

@@ -129,6 +129,54 @@ def test_eval_textfare_script(tmp_path, monkeypatch):
     assert len(out) == 1 and out[0].read_text().splitlines()[0] == "sentence,adv_sentence,textfare_clean,textfare_adv"
 
 
+def test_eval_textfare_per_sentence_replays_the_reference_loop(tmp_path, monkeypatch):
+    """``--per-sentence`` = the reference's loop order (eval_textfare.py:113-141, one attack_text_leaf call per
+    sentence): with the same numpy seed the RNG stream, the candidate strings and the adversarial sentences are the reference's own
+    (fixture: tests/golden/make_golden_eval.py ran the reference's loop body on two tiny models).  Decisions are fp-level arg-maxes;
+    where one flips, the engine's pick must be as good as the oracle's best within 16-bit noise (the margin rule of
+    test_attack_text_replays_reference_trace)."""
+    import json
+    import eval_textfare
+    from leaf_amd.tokenizer import SimpleTokenizer
+    from oracle import text_oracle as O
+    monkeypatch.chdir(tmp_path)
+    with open(os.path.join(os.path.dirname(__file__), "golden", "eval_per_sentence.json")) as f:
+        fx = json.load(f)
+    cfg = O.TextCfg(128, 2, 2, 64, quick_gelu=True)
+    w = O.init_weights(cfg, seed=fx["model_seed"])
+    tok = SimpleTokenizer()
+    matched = 0
+    for key, case in fx["cases"].items():
+        sents = [r["sentence"] for r in case["rows"]]
+        (tmp_path / "caps.txt").write_text("\n".join(sents) + "\n")
+        trace = []
+        rows = eval_textfare.main(["--model", fx["model"], "--texts", str(tmp_path / "caps.txt"), "--rho", str(case["rho"]), "--k", str(case["k"]),
+                                   "--n-test", str(len(sents)), "--seed", str(case["seed"]), "--per-sentence",
+                                   "--clean-seed", str(fx["clean_seed"]), "--robust-seed", str(fx["model_seed"])], trace=trace)
+        assert len(rows) == len(trace) == len(sents)
+        in_sync = True          # the global RNG is still where the reference's was at this sentence
+        for got, stages, ref in zip(rows, trace, case["rows"]):
+            assert abs(got["textfare_clean"] - ref["textfare_clean"]) < 5e-3 * ref["textfare_clean"]
+            if not in_sync:
+                continue
+            assert stages[0] == ref["stage_candidates"][0], "stage-1 candidates differ: RNG stream / loop order drift"
+            if got["adv_sentence"] == ref["adv_sentence"]:
+                assert stages == ref["stage_candidates"]
+                assert abs(got["textfare_adv"] - ref["textfare_adv"]) < 5e-3 * ref["textfare_adv"]
+                matched += 1
+                continue
+            # a near-tie flipped.  If it was the LAST stage's arg-max (all stages scored the reference's candidates), the engine's pick
+            # must be within 16-bit noise of the best candidate under the fp32 oracle; an earlier flip only counts against ``matched``
+            if stages == ref["stage_candidates"]:
+                anchor = O.encode_text(w, cfg, tok.encode_batch([got["sentence"]]))
+                loss_o = ((O.encode_text(w, cfg, tok.encode_batch(stages[-1])) - anchor) ** 2).sum(-1)
+                mine = ((O.encode_text(w, cfg, tok.encode_batch([got["adv_sentence"]])) - anchor) ** 2).sum(-1)[0]
+                assert mine >= loss_o.max() * (1 - 5e-3), (got["adv_sentence"], ref["adv_sentence"], mine, loss_o.max())
+            # with k > 1 a flipped decision changes the sentence length and with it the RNG consumption of what follows
+            in_sync = case["k"] == 1
+    assert matched >= 6, f"only {matched} of 8 sentences reproduce the reference's adversarial sentence"
+
+
 def test_train_cli_normalize_fare_and_grad_clip(tmp_path, monkeypatch):
     """The two optional flags of the reference trainer that change the training arithmetic (--normalize_fare,
     utils_AT.py:296,319; --grad-clip-norm, utils_AT.py:348-357) run end to end and bound the loss / keep it finite."""

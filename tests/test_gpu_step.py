@@ -173,3 +173,28 @@ def test_bench_fresh_batches_fixed_batch_and_rank_sim():
     assert sim["ms_max_over_ranks_mean"] >= sim["ms_per_rank_step_mean"] > 0 and sim["skew_ratio_max_over_mean"] >= 1.0
     assert 0.0 < sim["pred_eff"] <= sim["pred_eff_skew_only"] <= 1.0
     assert sim["scored_rows_per_rank_step_min_mean_max"][0] > 0
+
+
+def test_bench_two_ranks_on_rccl_when_the_box_has_two_gpus():
+    """the first contact of the multi-rank step with RCCL.  ``bench.py --gpus 2 --backend nccl`` (its own launcher:
+    torch.distributed.run, one rank per device, bucketed all-reduce behind the backward) on any box with >= 2 GPUs; the one-GPU test
+    boxes skip it.  ``torch.cuda.device_count()`` does not initialise the GPU in this process (the ranks are child processes)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL wants one device per rank); the one-GPU rehearsals are test_gpu_dp2.py and the test above")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LEAF_BENCH_FORCE_DIST", "LEAF_DP_OVERLAP")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "nccl", "--model", "tiny-test-quickgelu",
+                        "--batch", "16", "--rho", "8", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-dense-leg"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, p.stdout[-2000:]
+    out = json.loads(line[0])
+    assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and np.isfinite(out["loss"])
+    assert len(out["per_rank"]["ms_per_step"]) == 2 and out["dp_gradient_buckets"]["active"]

@@ -103,6 +103,36 @@ def test_handle_layout_and_errors_without_gpu():
     l.leaf_text_destroy(h)
 
 
+def test_every_kernel_sets_the_fp16_saturation_mode_first():
+    """ADVICE r5: F16::pack2 (common.h) leaves the +-65504 saturation to the hardware -- MODE.FP16_OVFL, which a wave only has after
+    ``leaf_fp16_sat_mode()``.  A kernel that forgets the call would turn an overflow into inf / NaN activations silently, so the
+    convention is linted: the first statement of EVERY ``__global__`` body under leaf_amd/csrc (product and variants) is that call."""
+    import glob
+
+    def close(s, i):               # index of the parenthesis that closes the one at s[i]
+        d = 0
+        while True:
+            d += {"(": 1, ")": -1}.get(s[i], 0)
+            if d == 0:
+                return i
+            i += 1
+    n, bad = 0, []
+    for f in sorted(glob.glob(os.path.join(ROOT, "leaf_amd", "csrc", "**", "*.hip"), recursive=True)):
+        s = open(f).read()
+        for m in re.finditer(r"__global__", s):
+            j = close(s, s.index("(", m.end()))                       # __launch_bounds__(...) or the parameter list
+            k = re.match(r"\s*void\s+\w+\s*", s[j + 1:])
+            if k:
+                j = close(s, s.index("(", j + 1 + k.end() - 1))
+            body = s[s.index("{", j) + 1:][:600]
+            body = re.sub(r"/\*.*?\*/", "", re.sub(r"//[^\n]*\n", "\n", body), flags=re.S)
+            n += 1
+            if not body.lstrip().startswith("leaf_fp16_sat_mode();"):
+                bad.append((os.path.relpath(f, ROOT), s[:m.start()].count("\n") + 1))
+    assert n >= 50, f"only {n} kernels found: the lint's pattern no longer matches the sources"
+    assert not bad, f"kernels that do not start with leaf_fp16_sat_mode(): {bad}"
+
+
 def test_product_has_no_oracle_or_cpu_fallback():
     """The product package must not import the oracle, and must refuse to run without a GPU."""
     import subprocess, sys
