@@ -63,11 +63,12 @@ def fwd_flops_per_seq(cfg, L=77):
     return cfg.layers * (24 * cfg.width ** 2 * L + 4 * L * L * cfg.width)
 
 
-def cpu_baseline(model_name, rho, k, b_cpu, seed, budget_s, gpu_encode=None):
+def cpu_baseline(model_name, rho, k, b_cpu, seed, budget_s, gpu_encode=None, parity_rows=512):
     """Plain PyTorch-CPU fp32 harness (own code, oracle/torch_cpu_harness.py) of the same step, dense, all usable cores.
-    ``gpu_encode`` (tokens -> features of the benchmark's start weights on the GPU): the same captions' embeddings are compared
-    with the harness's fp32 ones, so that every performance line carries its accuracy (``parity_rel_l2``; the oracle is the
-    checker here, outside the timed region)."""
+    ``gpu_encode`` (tokens -> features of the benchmark's start weights on the GPU): the embeddings of ``parity_rows`` rows (synthetic
+    captions + single-edit candidates of them, what the search scores) are compared with the harness's fp32 ones, so that every
+    performance line carries its accuracy (``parity_rel_l2``: batch figure, row quantiles, rows above 1e-3; the oracle is the checker
+    here, outside the timed region; the 12,928-row census is profiles/r06_row_error_census*.txt)."""
     import numpy as np
     from oracle import text_oracle as O
     from oracle import torch_cpu_harness as H
@@ -77,12 +78,21 @@ def cpu_baseline(model_name, rho, k, b_cpu, seed, budget_s, gpu_encode=None):
     parity = None
     if gpu_encode is not None:
         import torch
+        torch.set_num_threads(H.usable_cores())
+        nb = max(parity_rows // 8, 1)
+        pb = O.synthetic_tokens(nb, seed=seed)
+        rows_t = np.concatenate([pb, O.synthetic_candidates(pb, 7, seed=seed + 1).reshape(-1, pb.shape[1])])
+        L = int(rows_t.argmax(-1).max()) + 1                  # causal attention: cutting behind the longest EOT is exact
+        tower = H.TorchTextTower(w, cfg)
         with torch.no_grad():
-            ref = H.TorchTextTower(w, cfg).encode_text(torch.from_numpy(base.astype(np.int64))).numpy()
-        got = gpu_encode(base)
+            ref = np.concatenate([tower.encode_text(torch.from_numpy(rows_t[s:s + 128, :L].astype(np.int64))).numpy()
+                                  for s in range(0, rows_t.shape[0], 128)])
+        got = gpu_encode(rows_t)
         rows = np.linalg.norm(got - ref, axis=1) / np.linalg.norm(ref, axis=1)
-        parity = {"captions": int(b_cpu), "global": float(np.linalg.norm(got - ref) / np.linalg.norm(ref)), "row_max": float(rows.max()),
-                  "row_median": float(np.median(rows)), "tolerance": 1e-3,
+        parity = {"captions": int(rows_t.shape[0]), "global": float(np.linalg.norm(got - ref) / np.linalg.norm(ref)), "row_max": float(rows.max()),
+                  "row_median": float(np.median(rows)), "row_p99": float(np.quantile(rows, 0.99)), "rows_above_1e-3": int((rows > 1e-3).sum()),
+                  "tolerance": 1e-3,
+                  "rows": f"{nb} synthetic captions + 7 single-edit candidates each",
                   "against": "plain PyTorch CPU fp32 forward of the same start weights (oracle/torch_cpu_harness.py)"}
     r = H.time_step(w, cfg, base, lambda cur, rho_, s, pos: O.synthetic_candidates(cur, rho_, s, fixed_pos=pos), rho, k,
                     budget_s=budget_s)
@@ -319,6 +329,7 @@ def main():
     ap.add_argument("--no-prefix-reuse", action="store_true", help="recompute every kept row of every candidate")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    ap.add_argument("--parity-rows", type=int, default=512, help="rows of the line's parity_rel_l2 (GPU embeddings vs the PyTorch CPU fp32 forward)")
     ap.add_argument("--host-threads", type=int, default=0,
                     help="host threads per rank (torch CPU ops, the native tokenizer: LEAF_HOST_THREADS); default = usable cores // ranks on this node")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
@@ -326,9 +337,19 @@ def main():
                     help="take the per-launch HIP events of the live roofline on every N-th timed step (an event pair makes the queue wait for the "
                          "launch before it: 1.2 ms per 50-ms step when taken on all of them)")
     ap.add_argument("--dry", action="store_true", help="rendezvous rehearsal only (no GPU work); with --backend gloo runs on CPU")
-    ap.add_argument("--split-blocks", type=int, default=0,
-                    help="precision escape hatch (leaf_text_split_pack): hi + lo operand splits in the GEMMs of the first N blocks of the "
-                         "forward-only passes, on the attacked AND the frozen model; 0 = the shipped arithmetic (the metric)")
+    ap.add_argument("--precision", default=None, choices=["rowsafe", "fast"],
+                    help="arithmetic of the forward-only passes (leaf_amd.model.PRECISION_MODES).  rowsafe (DEFAULT, the metric): hi + lo "
+                         "operand splits in the GEMMs of the leading blocks that the census prices -- every row of the 12,928-row "
+                         "census within 1e-3 of fp32 (profiles/r06_row_error_census*.txt); fast: no split GEMM (rounds 1-5: batch 8.7e-4, "
+                         "1.1 %% of the rows above 1e-3)")
+    ap.add_argument("--split-blocks", type=int, default=None,
+                    help="A/B: hi + lo operand splits in ALL FOUR GEMMs of the first N blocks (the round-5 escape hatch) instead of the "
+                         "--precision mode")
+    ap.add_argument("--split-masks", default=None,
+                    help="A/B: comma-separated split mask per leading block (bit 0 QKV, 1 out_proj weights, 2 c_fc, 3 c_proj weights), "
+                         "e.g. 3,1 -- instead of the --precision mode")
+    ap.add_argument("--precise-anchor", action="store_true",
+                    help="A/B: the frozen model's anchor pass in the fp32-grade arithmetic (leaf_text_forward_precise) instead of the 16-bit one")
     ap.add_argument("--fp32-residual", action="store_true",
                     help="A/B: keep the residual stream of the forward-only passes as fp32 rows beside their 16-bit copy (option compact_resid = 0) "
                          "instead of the 16-bit copy + a remainder byte per element")
@@ -410,15 +431,20 @@ def main():
     frozen = LeafCLIPText(cfg, device=dev, dtype=args.dtype).copy_from(model)
     frozen.pack()
     model.pack()
-    if args.split_blocks:
+    if args.precision:
+        model.set_precision(args.precision)
+    if args.split_blocks is not None:
         model.set_split_blocks(args.split_blocks)
-        frozen.set_split_blocks(args.split_blocks)
+    if args.split_masks is not None:
+        model.set_split_masks([int(x) for x in args.split_masks.split(",") if x != ""])
     if args.fp32_residual:
         model.set_option("compact_resid", 0)
-        frozen.set_option("compact_resid", 0)
-    compact = not args.fp32_residual and not args.split_blocks and os.environ.get("LEAF_COMPACT_RESID") != "0"
+    frozen.copy_from(model)          # weights AND arithmetic (split blocks / policy, residual format)
+    frozen.pack()
+    compact = bool(model.arithmetic_tag()[0])
+    arith = model.precision_name()
     sc = StepConfig(rho=args.rho, k_adv=args.k_adv, lr=1e-5, wd=1e-4, attack=args.attack, pgd_eps=args.pgd_eps,
-                    pgd_alpha=args.pgd_alpha, pgd_norm=args.pgd_norm, accum_freq=args.accum_freq)
+                    pgd_alpha=args.pgd_alpha, pgd_norm=args.pgd_norm, accum_freq=args.accum_freq, precise_anchor=args.precise_anchor)
     # synthetic captions: SOT, U{8..40} ids, EOT, zero pad; a different shard per rank (seed + rank) and -- unless
     # --fixed-batch -- a different batch per step: the lengths are drawn on the host (the row plan needs them), the ids on the device
     # on a stream of their own, one step ahead of the step that consumes them
@@ -572,7 +598,7 @@ def main():
         # workload a PMC summary belongs to: tools/pmc_summary.py copies this key from the line of its own FETCH pass
         wkey = (f"{args.model}|B{B}|accum{args.accum_freq}|k{args.k_adv}|rho{args.rho}|{args.attack}|"
                 f"{'dense' if args.dense else 'trimmed'}|{'noprefix' if args.no_prefix_reuse else 'prefix'}|{'fixedbatch' if args.fixed_batch else 'freshbatch'}"
-                + (f"|split{args.split_blocks}" if args.split_blocks else "") + ("" if compact else "|fp32resid"))
+                + ("" if arith == "rowsafe" else "|" + arith) + ("" if compact else "|fp32resid") + ("|preciseanchor" if args.precise_anchor else ""))
         default_key = "ViT-L-14-quickgelu|B128|accum1|k1|rho50|leaf|trimmed|prefix|freshbatch"
         try:    # HBM bytes per launch of the dominant kernel from the committed PMC passes; only for the build AND workload they were taken on
             import glob
@@ -621,7 +647,7 @@ def main():
                                    (f"CLIP {args.model} text encoder, OPTIONAL embedding-space PGD mode (SURVEY 8a row a12, NOT "
                                     f"the reference's text attack): k={args.k_adv} steps, {args.pgd_norm} eps={args.pgd_eps} "
                                     f"alpha={args.pgd_alpha}, B={B} per GPU, seq=77"),
-                       "attack": args.attack, "split_blocks": args.split_blocks,
+                       "attack": args.attack, "precision": arith, "split_masks": list(model.split_masks),
                        "residual_stream": ("16-bit copy + block-scaled e4m3 remainder byte (2^-16 per store) in the forward-only passes; fp32 in the training forward / backward"
                                            if compact else "fp32"), "accum_freq": args.accum_freq, "baseline_config_index": args.config or None, "workload_key": wkey,
                        "global_batch": B * world, "seq_len": cfg.context_length, "rho": args.rho, "k": args.k_adv,
@@ -668,7 +694,8 @@ def main():
             oracle_name = args.model if args.model in ("ViT-L-14", "ViT-L-14-quickgelu", "ViT-H-14", "ViT-g-14", "ViT-bigG-14") else "ViT-L-14"
             same_weights = oracle_name == args.model          # the frozen model still holds the seed-1 start weights
             out["cpu_baseline"] = cpu_baseline(oracle_name, args.rho, args.k_adv, args.cpu_batch, seed=1234, budget_s=args.cpu_budget_s,
-                                               gpu_encode=(lambda t: frozen.encode_text(t).cpu().numpy()) if same_weights else None)
+                                               gpu_encode=(lambda t: frozen.encode_text(t).cpu().numpy()) if same_weights else None,
+                                               parity_rows=args.parity_rows)
             out["parity_rel_l2"] = out["cpu_baseline"].pop("parity_rel_l2")
         print(json.dumps(out), flush=True)
         if os.environ.get("LEAF_BENCH_JSON_OUT"):     # the PMC passes keep the line of THEIR run (tools/pmc_passes.sh): own algorithmic bytes

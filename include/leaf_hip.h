@@ -48,9 +48,10 @@ int leaf_text_set_chunk(leaf_text_t h, int seqs_per_chunk); /* sequences process
 /* options: "chunk" (as above), "last_layer_trim" (0/1, default 1: the last block's attention output, out-projection and
  * MLP are computed for the pooled EOT row only -- exact, every op after attention is row-wise), "compact_resid" (0/1, default 1:
  * the residual stream of the LN-folded forward-only passes as the 16-bit copy + a remainder byte per element instead of an fp32
- * row beside that copy -- see leaf_op_gemm_resid_ln8 below; 0, or LEAF_COMPACT_RESID=0, keeps fp32 rows; the split blocks of
- * leaf_text_split_pack always run on fp32 rows), and the A/B switches "streams", "ln_fold", "fuse_attn", "normalize_fare" */
+ * row beside that copy -- see leaf_op_gemm_resid_ln8 below; 0, or LEAF_COMPACT_RESID=0, keeps fp32 rows), and the A/B switches "streams", "ln_fold", "fuse_attn", "normalize_fare" */
 int leaf_text_set_option(leaf_text_t h, const char* name, int value);
+/* current value of an option of leaf_text_set_option (+ "split_blocks"); -1 = unknown name */
+int leaf_text_get_option(leaf_text_t h, const char* name);
 
 /* flat parameter layout */
 size_t leaf_text_param_count(leaf_text_t h);
@@ -65,16 +66,20 @@ int leaf_text_param_info(leaf_text_t h, int index, char* name, size_t name_len, 
 size_t leaf_text_w16_bytes(leaf_text_t h);
 int leaf_text_pack_weights(leaf_text_t h, const float* params, void* w16_fwd, void* w16_bwd, leaf_stream_t s);
 
-/* OPTIONAL precision escape hatch of the forward-only passes (encode_text, score_candidates*, forward_kv; the training forward is
- * untouched -- the reference trains under fp16 autocast, utils_AT.py:317-319): the four GEMMs of the first `blocks` transformer
- * blocks multiply hi + lo 16-bit splits of BOTH operands (x_hi W_hi + x_lo W_hi + x_hi W_lo in the fp32 accumulator, over a
- * three times longer K through the unchanged GEMM kernels; stored q|k|v / attention / hidden rows stay 16-bit).  The embedding's
- * error is made early: on the random-init ViT-L fixture blocks = 1 takes the worst row from 9.6e-4 to 8.3e-4,
- * blocks = 2 to 7.1e-4 (oracle emulation), at +13 % of the search's GEMM work per block.  `buf` (DEVICE, leaf_text_split_bytes(h,
- * blocks) bytes, caller-owned, must outlive the calls that use it) receives the split weight copies; call again after every
- * optimizer step (as leaf_text_pack_weights).  blocks = 0 (buf ignored) switches the mode off.  0 <= blocks <= layers - 1. */
+/* Split blocks: higher-precision GEMMs in the leading transformer blocks of the forward-only passes (encode_text, score_candidates*,
+ * forward_kv; the training forward is untouched -- the reference trains under fp16 autocast, utils_AT.py:317-319).  A split GEMM
+ * multiplies hi + lo 16-bit splits (x_hi W_hi + x_lo W_hi + x_hi W_lo in the fp32 accumulator, over a longer K through the unchanged
+ * GEMM kernels -- the fused QKV + attention launch included; stored q|k|v / attention / hidden rows stay 16-bit).  The embedding's
+ * error is made early (profiles/r06_precision_budget_sites.txt).  leaf_text_split_pack: all four GEMMs of the
+ * first `blocks` blocks (QKV / c_fc both operands, out_proj / c_proj weights).  leaf_text_split_pack_masks: one mask per block,
+ * bit 0 = QKV, bit 1 = out_proj, bit 2 = c_fc, bit 3 = c_proj -- leaf_amd's default arithmetic is such a mask list
+ * (leaf_amd/model.py PRECISION_MODES; profiles/r06_row_error_census*.txt).  Works on both residual-stream formats
+ * ("compact_resid").  `buf` (DEVICE, leaf_text_split_bytes(h, blocks) bytes, caller-owned, must outlive the calls that use it)
+ * receives the split weight copies; call again after every optimizer step (as leaf_text_pack_weights).  blocks = 0 (buf ignored)
+ * switches splits off.  0 <= blocks <= min(layers - 1, 64); needs option ln_fold = 1. */
 size_t leaf_text_split_bytes(leaf_text_t h, int blocks);
 int leaf_text_split_pack(leaf_text_t h, const float* params, int blocks, void* buf, leaf_stream_t s);
+int leaf_text_split_pack_masks(leaf_text_t h, const float* params, const int32_t* masks, int blocks, void* buf, leaf_stream_t s);
 
 /* workspace sizes (bytes): mode 0 = forward, 1 = score_candidates, 2 = train backward */
 size_t leaf_text_workspace_bytes(leaf_text_t h, int n_seq, int mode);
@@ -320,6 +325,9 @@ int leaf_op_gemm(int dtype, int epi, const void* A, const void* B, void* C, cons
 /* same with explicit row strides (elements) */
 int leaf_op_gemm_ld(int dtype, int epi, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias,
                     void* aux, int M, int N, int K, int act, float beta, int aux_f16, leaf_stream_t s);
+/* C32 += [A | A] B^T + bias: A [M, Ka] stored once and re-read along K = 2 Ka by the half-stage ring kernel (B [N, 2 Ka] = e.g. the
+ * [hi | lo] split of a weight: the out-projection of a split block); an error for launches that kernel does not take */
+int leaf_op_gemm_awrap(int dtype, const void* A, const void* B, float* C, const float* bias, int M, int N, int Ka, leaf_stream_t s);
 /* LayerNorm folded into the GEMMs of the forward-only passes (leaf_amd/csrc/lnfold.h; replaces the LayerNorm launches between
  * the GEMMs of transformer.py:254-265).  Producer: C32[M,N] += A B^T + bias, x16 = 16-bit copy of the result, stat = float2
  * [N/64][M] (sum, M2 = sum (x - group mean)^2) of each row's 64-column groups.  Finalize: rowstat[m] = (mean, rstd) merged from

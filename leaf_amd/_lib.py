@@ -22,6 +22,7 @@ _SIGS = {
     "leaf_text_destroy": (None, [C.c_void_p]),
     "leaf_text_set_chunk": (C.c_int, [C.c_void_p, C.c_int]),
     "leaf_text_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "leaf_text_get_option": (C.c_int, [C.c_void_p, C.c_char_p]),
     "leaf_text_set_grad_scaler": (C.c_int, [C.c_void_p, C.c_void_p]),
     "leaf_text_param_count": (C.c_size_t, [C.c_void_p]),
     "leaf_text_decay_count": (C.c_size_t, [C.c_void_p]),
@@ -76,6 +77,7 @@ _SIGS = {
                                   C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_void_p]),
     "leaf_text_split_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
     "leaf_text_split_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "leaf_text_split_pack_masks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "leaf_tok_create": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "leaf_tok_destroy": (None, [C.c_void_p]),
     "leaf_tok_encode_batch": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.c_void_p, C.c_int, C.c_int, C.c_void_p,
@@ -109,6 +111,7 @@ _SIGS = {
                                C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "leaf_op_gemm_ld": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                   C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
+    "leaf_op_gemm_awrap": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "leaf_op_gemm_resid_ln": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                         C.c_int, C.c_int, C.c_void_p]),
     "leaf_op_gemm_resid_ln8": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,

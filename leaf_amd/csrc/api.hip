@@ -111,11 +111,29 @@ extern "C" int leaf_text_set_option(leaf_text_t h, const char* name, int value) 
     if (!strcmp(name, "last_layer_trim")) { h->last_trim = value ? 1 : 0; return 0; }
     if (!strcmp(name, "streams")) { h->streams = value >= 2 ? 2 : 1; return 0; }
     if (!strcmp(name, "normalize_fare")) { h->normalize_fare = value ? 1 : 0; return 0; }
-    if (!strcmp(name, "ln_fold")) { h->ln_fold = (value && h->cfg.width % 64 == 0) ? 1 : 0; return 0; }
+    if (!strcmp(name, "ln_fold")) {
+        const int on = (value && h->cfg.width % 64 == 0) ? 1 : 0;
+        if (!on && h->split_blocks) { leaf_set_error("ln_fold = 0 with split blocks active: the split GEMMs are LN-folded (leaf_text_split_pack(.., 0, ..) first)"); return 1; }
+        h->ln_fold = on;
+        return 0;
+    }
     if (!strcmp(name, "fuse_attn")) { h->fuse_attn = value ? 1 : 0; return 0; }
     if (!strcmp(name, "compact_resid")) { h->compact_resid = value ? 1 : 0; return 0; }
     leaf_set_error("unknown option '%s'", name);
     return 1;
+}
+
+extern "C" int leaf_text_get_option(leaf_text_t h, const char* name) {
+    if (!h || !name) return -1;
+    if (!strcmp(name, "chunk")) return h->chunk;
+    if (!strcmp(name, "last_layer_trim")) return h->last_trim;
+    if (!strcmp(name, "streams")) return h->streams;
+    if (!strcmp(name, "normalize_fare")) return h->normalize_fare;
+    if (!strcmp(name, "ln_fold")) return h->ln_fold;
+    if (!strcmp(name, "fuse_attn")) return h->fuse_attn;
+    if (!strcmp(name, "compact_resid")) return h->compact_resid;
+    if (!strcmp(name, "split_blocks")) return h->split_blocks;
+    return -1;
 }
 
 extern "C" size_t leaf_text_param_count(leaf_text_t h) { return h->n_params; }
@@ -136,23 +154,33 @@ extern "C" size_t leaf_text_w16_bytes(leaf_text_t h) { return h->w16_total_bytes
 
 extern "C" size_t leaf_text_split_bytes(leaf_text_t h, int blocks) { return (h && blocks > 0) ? h->split_bytes(blocks) : 0; }
 
-extern "C" int leaf_text_split_pack(leaf_text_t h, const float* params, int blocks, void* buf, leaf_stream_t s_) {
+extern "C" int leaf_text_split_pack_masks(leaf_text_t h, const float* params, const int32_t* masks, int blocks, void* buf, leaf_stream_t s_) {
     if (!h) { leaf_set_error("null handle"); return 1; }
     if (blocks == 0) { h->split_blocks = 0; h->split_buf = nullptr; return 0; }
-    if (blocks < 0 || blocks > h->cfg.layers - 1) { leaf_set_error("split blocks %d out of range 0..%d", blocks, h->cfg.layers - 1); return 1; }
-    if (!params || !buf) { leaf_set_error("leaf_text_split_pack: params / buf is null"); return 1; }
+    if (blocks < 0 || blocks > h->cfg.layers - 1 || blocks > 64) { leaf_set_error("split blocks %d out of range 0..%d", blocks, h->cfg.layers - 1); return 1; }
+    if (!params || !buf || !masks) { leaf_set_error("leaf_text_split_pack: params / masks / buf is null"); return 1; }
+    if (!h->ln_fold) { leaf_set_error("leaf_text_split_pack: the split GEMMs exist in the LN-folded forward only (option ln_fold is 0)"); return 1; }
+    for (int l = 0; l < blocks; ++l)
+        if (masks[l] < 0 || masks[l] > 15) { leaf_set_error("split mask %d of block %d: bits 0..3 (QKV, out_proj, c_fc, c_proj)", masks[l], l); return 1; }
     hipStream_t s = (hipStream_t)s_;
     const int d = h->cfg.width, dt = h->fwd_dtype;
     h->split_blocks = blocks;
     h->split_buf = buf;
-    for (int l = 0; l < blocks; ++l) {
+    for (int l = 0; l < 64; ++l) h->split_mask[l] = l < blocks ? masks[l] : 0;
+    for (int l = 0; l < blocks; ++l) {      // only what the masks multiply
         const LayerOff& o = h->layer[l];
-        LEAF_TRY(leaf_launch_split_pack(params + o.qkv_w, params + o.ln1_w, (void*)h->split_qkv3(l), (float*)h->split_s_qkv(l), 3 * d, d, 1, dt, s));
-        LEAF_TRY(leaf_launch_split_pack(params + o.fc_w, params + o.ln2_w, (void*)h->split_fc3(l), (float*)h->split_s_fc(l), 4 * d, d, 1, dt, s));
-        LEAF_TRY(leaf_launch_split_pack(params + o.out_w, nullptr, (void*)h->split_out_lo(l), nullptr, d, d, 0, dt, s));
-        LEAF_TRY(leaf_launch_split_pack(params + o.proj_w, nullptr, (void*)h->split_proj_lo(l), nullptr, d, 4 * d, 0, dt, s));
+        if (h->split_qkv(l)) LEAF_TRY(leaf_launch_split_pack(params + o.qkv_w, params + o.ln1_w, (void*)h->split_qkv3(l), (float*)h->split_s_qkv(l), 3 * d, d, 1, dt, s));
+        if (h->split_fc(l)) LEAF_TRY(leaf_launch_split_pack(params + o.fc_w, params + o.ln2_w, (void*)h->split_fc3(l), (float*)h->split_s_fc(l), 4 * d, d, 1, dt, s));
+        if (h->split_out(l)) LEAF_TRY(leaf_launch_split_pack(params + o.out_w, nullptr, (void*)h->split_out2(l), nullptr, d, d, 2, dt, s));
+        if (h->split_proj(l)) LEAF_TRY(leaf_launch_split_pack(params + o.proj_w, nullptr, (void*)h->split_proj_lo(l), nullptr, d, 4 * d, 0, dt, s));
     }
     return 0;
+}
+
+extern "C" int leaf_text_split_pack(leaf_text_t h, const float* params, int blocks, void* buf, leaf_stream_t s) {
+    int32_t masks[64];
+    for (int l = 0; l < 64; ++l) masks[l] = 15;
+    return leaf_text_split_pack_masks(h, params, masks, blocks, buf, s);
 }
 
 extern "C" int leaf_text_pack_weights(leaf_text_t h, const float* params, void* w16_fwd, void* w16_bwd,
@@ -196,12 +224,12 @@ std::vector<ProfRec> g_prof;
 
 int leaf_gemm(int dtype, int epi, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias,
               void* aux, int M, int N, int K, int act, hipStream_t s, float beta, int aux_f16, const float* alpha,
-              const GemmLn* ln) {
+              const GemmLn* ln, int a_wrap) {
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.aux = aux;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.act = act; g.aux_f16 = aux_f16; g.beta = beta; g.stamps = nullptr; g.alpha = alpha; g.ngroup = 0;
-    g.ln_s = nullptr; g.rowstat = nullptr; g.stat_out = nullptr; g.x16 = nullptr; g.stat_ld = 0; g.ldx16 = 0; g.ln_eps = 0.f; g.stagger = 0;
+    g.ln_s = nullptr; g.rowstat = nullptr; g.stat_out = nullptr; g.x16 = nullptr; g.stat_ld = 0; g.ldx16 = 0; g.ln_eps = 0.f; g.stagger = 0; g.a_wrap = a_wrap;
     if (epi == EPI_LNFOLD_T || epi == EPI_LNFOLD_ACT_T || epi == EPI_RESID_LN || epi == EPI_RESID_LN8) {
         const bool fold = epi != EPI_RESID_LN && epi != EPI_RESID_LN8;
         if (!ln || (fold && (!ln->ln_s || !ln->rowstat || !bias)) || (!fold && (!ln->x16 || !ln->stat_out || N % 64 || ln->stat_ld < M))) {
@@ -384,15 +412,22 @@ int forward_chunk(const leaf_text* h, const float* P, const uint16_t* W, const i
     // optional higher-precision leading blocks (leaf_text_split_pack): hi + lo splits of both operands over a 3x longer K.  The
     // [rows, 3d] split copy of the fp32 residual rows lives in buffers that are dead at that point: the hidden buffer in front of
     // the QKV GEMM, the chunk's own q|k|v scratch in front of c_fc (these blocks run the two-kernel attention path).
-    const int nsplit = (fold && h->split_buf) ? h->split_blocks : 0;
+    const bool splits = fold && h->split_buf && h->split_blocks > 0;
+    auto sq = [&](int l) { return splits && h->split_qkv(l); };
+    auto sf = [&](int l) { return splits && h->split_fc(l); };
     // 16 + 8-bit residual stream (engine.h compact_resid): b.x holds the [rows, d] remainder bytes, b.x16 is the other half
-    const bool lo8 = fold && h->compact_resid && nsplit == 0 && leaf_project_rows_ok(d, c.embed_dim);
+    const bool lo8 = fold && h->compact_resid && leaf_project_rows_ok(d, c.embed_dim);
+    // [hi | lo | hi] copy of the current residual rows (fp32 rows, or the 16 + 8-bit stream) for a three-pass GEMM; block 0's QKV
+    // operand comes out of the embedding kernel (the exact fp32 sum is in its registers)
+    auto split_rows = [&](void* dst, int m) -> int {
+        return lo8 ? leaf_check(leaf_launch_split16_rows_lo8(b.x16, b.x, dst, m, d, dt, s), "split16_rows_lo8")
+                   : leaf_check(leaf_launch_split16_rows(b.x, dst, m, d, dt, s), "split16_rows");
+    };
     auto qkv_gemm = [&](int l, int m, const GemmLn& g, const void* xn) -> int {
         const LayerOff& o = h->layer[l];
         if (!fold) return leaf_gemm(dt, EPI_STORE_T, xn, d, W + h->w16_qkv(l), d, b.qkv, 3 * d, P + o.qkv_b, nullptr, m, 3 * d, d, 0, s);
         GemmLn q = g; q.ln_s = h->fold_s_qkv(W, l);
-        if (l < nsplit) {
-            LEAF_TRY(leaf_launch_split16_rows(b.x, b.hh, m, d, dt, s));
+        if (sq(l)) {     // b.hh holds [hi | lo | hi] of these rows (built by the caller)
             q.ln_s = h->split_s_qkv(l);
             return leaf_gemm(dt, EPI_LNFOLD_T, b.hh, 3 * d, h->split_qkv3(l), 3 * d, b.qkv, 3 * d, h->fold_c_qkv(W, l), nullptr, m, 3 * d,
                              3 * d, 0, s, 0.f, 0, nullptr, &q);
@@ -404,8 +439,8 @@ int forward_chunk(const leaf_text* h, const float* P, const uint16_t* W, const i
         const LayerOff& o = h->layer[l];
         if (!fold) return leaf_gemm(dt, EPI_ACT_T, xn, d, W + h->w16_fc(l), d, hid, 4 * d, P + o.fc_b, nullptr, m, 4 * d, d, c.activation, s);
         GemmLn q = g; q.ln_s = h->fold_s_fc(W, l);
-        if (l < nsplit) {
-            LEAF_TRY(leaf_launch_split16_rows(b.x, b_in.qkv, m, d, dt, s));
+        if (sf(l)) {     // scratch: the chunk's own q|k|v buffer (dead behind the attention)
+            if (split_rows(b_in.qkv, m)) return 1;
             q.ln_s = h->split_s_fc(l);
             return leaf_gemm(dt, EPI_LNFOLD_ACT_T, b_in.qkv, 3 * d, h->split_fc3(l), 3 * d, hid, 4 * d, h->fold_c_fc(W, l), nullptr, m, 4 * d,
                              3 * d, c.activation, s, 0.f, 0, nullptr, &q);
@@ -416,15 +451,17 @@ int forward_chunk(const leaf_text* h, const float* P, const uint16_t* W, const i
     // residual GEMM x += A W^T + bias; with folding (and a LayerNorm following) it also emits x16 / statistics
     // ... and the tiny finalize launch turns the [group][row] partials into (mean, rstd) per row for the consuming GEMM.
     // w_lo (split blocks): the A operand is a stored 16-bit tensor (exact as it is), so only the weights are split: x += A W_hi^T +
-    // bias, then x += A W_lo^T in a second launch, which is the one that emits x16 / statistics of the finished rows
+    // bias, then x += A W_lo^T in a second launch, which is the one whose x16 / statistics of the finished rows are read
     auto resid_gemm = [&](const void* A, int K, size_t w_off, const float* bias, float* x, int m, const GemmLn* g,
                           const uint16_t* w_lo = nullptr) -> int {
         const uint16_t* Wl = W + w_off;
+        const bool l8 = lo8 && x == b.x;
         if (w_lo) {
-            if (leaf_gemm(dt, EPI_RESID_F32, A, K, Wl, K, x, d, bias, nullptr, m, d, K, 0, s)) return 1;
+            if (l8) { if (leaf_gemm(dt, EPI_RESID_LN8, A, K, Wl, K, x, d, bias, nullptr, m, d, K, 0, s, 0.f, 0, nullptr, &ln)) return 1; }
+            else if (leaf_gemm(dt, EPI_RESID_F32, A, K, Wl, K, x, d, bias, nullptr, m, d, K, 0, s)) return 1;
             Wl = w_lo; bias = nullptr;
         }
-        if (lo8 && x == b.x) {
+        if (l8) {
             // (the last block's c_proj has no LayerNorm behind it: its statistics go to the chunk's buffers all the same, unread)
             if (leaf_gemm(dt, EPI_RESID_LN8, A, K, Wl, K, x, d, bias, nullptr, m, d, K, 0, s, 0.f, 0, nullptr, &ln)) return 1;
             return g ? leaf_check(leaf_launch_ln_finalize(ln.stat_out, ln.stat_ld, m, d / 64, ln.eps, const_cast<float2*>(ln.rowstat), s), "ln_finalize") : 0;
@@ -433,9 +470,32 @@ int forward_chunk(const leaf_text* h, const float* P, const uint16_t* W, const i
         if (leaf_gemm(dt, EPI_RESID_LN, A, K, Wl, K, x, d, bias, nullptr, m, d, K, 0, s, 0.f, 0, nullptr, g)) return 1;
         return leaf_check(leaf_launch_ln_finalize(g->stat_out, g->stat_ld, m, d / 64, g->eps, const_cast<float2*>(g->rowstat), s), "ln_finalize");
     };
+    // out-projection of a split block: x += [A | A] [W_hi | W_lo]^T + bias in ONE launch over K = 2d (the residual stream is
+    // read-modify-written once).  The half-stage ring kernel re-reads A itself (GemmArgs::a_wrap); launches too small for it multiply
+    // a duplicated copy of A (scratch: the chunk's own q|k|v buffer, dead behind the attention) -- the same operands in the same k
+    // order, so a row's bits do not depend on which of the two ran.
+    auto out_gemm = [&](int l, const void* A, float* x, int m, const GemmLn* g) -> int {
+        const LayerOff& o = h->layer[l];
+        if (!(splits && h->split_out(l))) return resid_gemm(A, d, h->w16_out(l), P + o.out_b, x, m, g);
+        const bool l8 = lo8 && x == b.x;
+        const int epi = l8 ? EPI_RESID_LN8 : (fold && g) ? EPI_RESID_LN : EPI_RESID_F32;
+        const GemmLn* gl = l8 ? &ln : g;
+        GemmArgs probe{};
+        probe.M = m; probe.N = d; probe.K = 2 * d; probe.lda = d; probe.ldb = 2 * d; probe.ldc = d; probe.ldx16 = gl ? gl->ldx16 : 0; probe.a_wrap = d / 64;
+        const bool ring = d % 64 == 0 && leaf_gemm_family(probe, epi) == 4;
+        const void* A2 = A;
+        if (!ring) {
+            LEAF_TRY(leaf_launch_dup_cols16(A, b_in.qkv, m, d, s));
+            A2 = b_in.qkv;
+        }
+        if (leaf_gemm(dt, epi, A2, ring ? d : 2 * d, h->split_out2(l), 2 * d, x, d, P + o.out_b, nullptr, m, d, 2 * d, 0, s, 0.f, 0, nullptr,
+                      epi == EPI_RESID_F32 ? nullptr : gl, ring ? d / 64 : 0)) return 1;
+        if (epi == EPI_RESID_F32 || (l8 && !g)) return 0;
+        return leaf_check(leaf_launch_ln_finalize(gl->stat_out, gl->stat_ld, m, d / 64, gl->eps, const_cast<float2*>(gl->rowstat), s), "ln_finalize");
+    };
     if (fold) {
         LEAF_TRY(leaf_launch_embed_fold(tokens, P + h->tok_emb, P + h->pos_emb, b.x, b.x16, b.stat, rows, rows, cs, map, d,
-                                        c.vocab_size, dt, s, nullptr, lo8));
+                                        c.vocab_size, dt, s, nullptr, lo8, sq(0) ? b.hh : nullptr));
         LEAF_TRY(leaf_launch_ln_finalize(b.stat, rows, rows, d / 64, c.ln_eps, b.rowstat, s));
     }
     else
@@ -450,24 +510,32 @@ int forward_chunk(const leaf_text* h, const float* P, const uint16_t* W, const i
         // QKV GEMM -> attention in one launch (qkv_attn.hip): q|k|v stay on chip, b.a receives the attention output.  In the fused
         // first stage the captions' q|k|v rows -- which their candidates' attention reads as cached prefix and the second stage
         // reads again -- come from a small GEMM of their own straight into the cache (the same bits as from any other kernel).
-        const bool fused_attn = kv.attn_tiles > 0 && l >= nsplit;     // split blocks: QKV GEMM (3x K) + attention as two kernels
+        // a split QKV block multiplies [hi | lo | hi] rows (b.hh) with the [hi | hi | lo] weights over K = 3d: through the same fused
+        // launch when it takes that K, else as QKV GEMM + attention kernel
+        const bool q3 = sq(l);
+        const bool fused_attn = kv.attn_tiles > 0 && (!q3 || leaf_qkv_attn_eligible(d, c.heads, c.context_length, 3 * d, kv.attn_max_len));
+        if (q3 && l > 0 && split_rows(b.hh, rows)) return 1;      // (block 0: written by the embedding kernel)
+        const void* qA = q3 ? (const void*)b.hh : ln.x16;
+        const uint16_t* qB = q3 ? h->split_qkv3(l) : W + h->w16_fold_qkv(l);
+        const float* qS = q3 ? h->split_s_qkv(l) : h->fold_s_qkv(W, l);
+        const int qK = q3 ? 3 * d : d;
         if (fused_attn) {
             if (kv.kv_self_rows) {
                 // only the K and V thirds: nothing ever reads a caption's q rows from the cache (its own attention runs inside the
                 // fused launch below, from LDS) -- weight rows [d, 3d) into cache columns [d, 3d) of the [rows, 3d] layout
                 uint16_t* dst = kv.kv_copy + (size_t)l * kv.kv_stride;
-                GemmLn q = ln; q.ln_s = h->fold_s_qkv(W, l) + d;
-                if (leaf_gemm(dt, EPI_LNFOLD_T, ln.x16, d, W + h->w16_fold_qkv(l) + (size_t)d * d, d, dst + d, 3 * d, h->fold_c_qkv(W, l) + d,
-                              nullptr, (int)kv.kv_self_rows, 2 * d, d, 0, s, 0.f, 0, nullptr, &q)) return 1;
+                GemmLn q = ln; q.ln_s = qS + d;
+                if (leaf_gemm(dt, EPI_LNFOLD_T, qA, qK, qB + (size_t)d * qK, qK, dst + d, 3 * d, h->fold_c_qkv(W, l) + d,
+                              nullptr, (int)kv.kv_self_rows, 2 * d, qK, 0, s, 0.f, 0, nullptr, &q)) return 1;
                 kvl = dst;
             }
             const bool trim = last && h->last_trim && out;
             if (trim) LEAF_TRY(leaf_launch_eot_positions(tokens, b.eot, cs, map, s));
             if (last && !out) break;
             QkvAttnArgs qa;
-            qa.A = ln.x16; qa.B = W + h->w16_fold_qkv(l); qa.bias = h->fold_c_qkv(W, l); qa.ln_s = h->fold_s_qkv(W, l);
+            qa.A = qA; qa.B = qB; qa.bias = h->fold_c_qkv(W, l); qa.ln_s = qS;
             qa.rowstat = ln.rowstat; qa.out = b.a; qa.kv_base = kvl; qa.eot_pos = trim ? b.eot : nullptr; qa.tile_seq = b.tile_seq;
-            qa.map = map; qa.M = rows; qa.K = d; qa.lda = d; qa.ldb = d; qa.heads = c.heads; qa.d = d; qa.n_tiles = kv.attn_tiles;
+            qa.map = map; qa.M = rows; qa.K = qK; qa.lda = qK; qa.ldb = qK; qa.heads = c.heads; qa.d = d; qa.n_tiles = kv.attn_tiles;
             qa.n_seq = cs; qa.kv_ld = 3 * d; qa.stamps = nullptr;
             leaf_qkv_attn_lds_plan(kv.attn_max_len, &qa.ncap, &qa.caprows);
             if (leaf_qkv_attn(qa, dt, s)) return 1;
@@ -532,11 +600,11 @@ int forward_chunk(const leaf_text* h, const float* P, const uint16_t* W, const i
             return 0;
         }
         if (!fused_attn) LEAF_TRY(leaf_launch_attention_fwd(b.qkv, kvl, b.a, cs, map, c.heads, d, dt, s, nullptr, max_len));
-        if (resid_gemm(b.a, d, h->w16_out(l), P + o.out_b, b.x, rows, &ln, l < nsplit ? h->split_out_lo(l) : nullptr)) return 1;
+        if (out_gemm(l, b.a, b.x, rows, &ln)) return 1;
         if (!fold) LEAF_TRY(leaf_launch_layernorm(b.x, P + o.ln2_w, P + o.ln2_b, c.ln_eps, b.a, rows, d, dt, s));
         if (fc_gemm(l, rows, ln, b.a, b.hh)) return 1;
         if (resid_gemm(b.hh, 4 * d, h->w16_proj(l), P + o.proj_b, b.x, rows, last ? nullptr : &ln,   // ln_final runs on the pooled rows
-                       l < nsplit ? h->split_proj_lo(l) : nullptr)) return 1;
+                       (splits && h->split_proj(l)) ? h->split_proj_lo(l) : nullptr)) return 1;
     }
     if (out && leaf_project_rows_ok(d, c.embed_dim)) {
         // same op sequence as the trimmed path (bit-identical features): gather the pooled rows, LN, fp32 projection.
@@ -817,6 +885,13 @@ extern "C" int leaf_op_gemm_ld(int dtype, int epi, const void* A, int lda, const
                                const float* bias, void* aux, int M, int N, int K, int act, float beta, int aux_f16,
                                leaf_stream_t s) {
     return leaf_gemm(dtype, epi, A, lda, B, ldb, C, ldc, bias, aux, M, N, K, act, (hipStream_t)s, beta, aux_f16);
+}
+// C32 += [A | A] B^T + bias over K = 2 Ka with A stored once as [M, Ka] (GemmArgs::a_wrap: the half-stage ring kernel re-reads the A
+// panel; fails for launches that kernel does not take) -- the out-projection of a split block; the parity tests hold it to the
+// launch on a materialised [A | A]
+extern "C" int leaf_op_gemm_awrap(int dtype, const void* A, const void* B, float* C, const float* bias, int M, int N, int Ka, leaf_stream_t s) {
+    if (Ka % 64) { leaf_set_error("gemm_awrap: Ka %% 64"); return 1; }
+    return leaf_gemm(dtype, EPI_RESID_F32, A, Ka, B, 2 * Ka, C, N, bias, nullptr, M, N, 2 * Ka, 0, (hipStream_t)s, 0.f, 0, nullptr, nullptr, Ka / 64);
 }
 // LN folding (lnfold.h): the producing residual GEMM (C32 += A B^T + bias, x16 = 16-bit(C32), stat[N/64][M] = (sum, M2)) ...
 extern "C" int leaf_op_gemm_resid_ln(int dtype, const void* A, const void* B, float* C, const float* bias, void* x16, void* stat,

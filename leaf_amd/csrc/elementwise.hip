@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void embed_fold_kernel(const float* __restrict
                                                          const float* __restrict__ tok_emb, const float* __restrict__ pos_emb,
                                                          float* __restrict__ x_out, u16* __restrict__ x16,
                                                          float2* __restrict__ stat, int stat_ld, int rows, int n_seq, RowMap map,
-                                                         int d, int vocab) {
+                                                         int d, int vocab, u16* __restrict__ split3) {
     leaf_fp16_sat_mode();
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -128,6 +128,13 @@ __global__ __launch_bounds__(256) void embed_fold_kernel(const float* __restrict
             if constexpr (LO8) *(unsigned*)((unsigned char*)x_out + (size_t)row * d + 4 * c) = resid_lo4<TT>(v.x, v.y, v.z, v.w, hi);
             else *(float4*)(xo + 4 * c) = v;
             *(uint2*)(x16 + (size_t)row * d + 4 * c) = hi;
+            if (split3) {       // [hi | lo | hi] of the exact fp32 row: the A operand of block 0's three-pass QKV GEMM (api.hip, split blocks)
+                float hf[4];
+                unpack4<TT>(hi, hf);
+                const uint2 lo = pack4<TT>(v.x - hf[0], v.y - hf[1], v.z - hf[2], v.w - hf[3]);
+                uint2* o = (uint2*)(split3 + (size_t)row * (3 * d)) + c;
+                o[0] = hi; o[nq] = lo; o[2 * nq] = hi;
+            }
         }
         const float gs = row16_sum(lnfold_sum4(v.x, v.y, v.z, v.w));
         const float gq = row16_sum(lnfold_dev4(v.x, v.y, v.z, v.w, gs * (1.0f / 64.0f)));
@@ -481,10 +488,10 @@ hipError_t leaf_launch_embed_ln(const int32_t* tokens, const float* tok_emb, con
 
 hipError_t leaf_launch_embed_fold(const int32_t* tokens, const float* tok_emb, const float* pos_emb, float* x, void* x16,
                                   float2* stat, int stat_ld, int rows, int n_seq, RowMap map, int d, int vocab, int dtype,
-                                  hipStream_t s, const float* delta, bool lo8) {
+                                  hipStream_t s, const float* delta, bool lo8, void* split3) {
     if (d % 64 || d > 256 * MAXCH) return hipErrorInvalidValue;
     dim3 grid((rows + 3) / 4), blk(256);
-#define LEAF_EF(TT, L8) hipLaunchKernelGGL((embed_fold_kernel<TT, L8>), grid, blk, 0, s, delta, tokens, tok_emb, pos_emb, x, (u16*)x16, stat, stat_ld, rows, n_seq, map, d, vocab)
+#define LEAF_EF(TT, L8) hipLaunchKernelGGL((embed_fold_kernel<TT, L8>), grid, blk, 0, s, delta, tokens, tok_emb, pos_emb, x, (u16*)x16, stat, stat_ld, rows, n_seq, map, d, vocab, (u16*)split3)
     if (dtype == LEAF_F16) { if (lo8) LEAF_EF(F16, true); else LEAF_EF(F16, false); }
     else { if (lo8) LEAF_EF(BF16, true); else LEAF_EF(BF16, false); }
 #undef LEAF_EF
@@ -638,8 +645,27 @@ __global__ __launch_bounds__(256) void split16_rows_kernel(const float* __restri
     }
 }
 
+// the same from the 16 + 8-bit residual stream (common.h resid_lo4): hi = the 16-bit copy as it is, lo = 16-bit(decoded remainder)
+template <class TT>
+__global__ __launch_bounds__(256) void split16_rows_lo8_kernel(const u16* __restrict__ x16, const unsigned char* __restrict__ lo8,
+                                                               u16* __restrict__ out, size_t n4, int d4) {
+    leaf_fp16_sat_mode();
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const size_t r = i / d4;
+        const int c = (int)(i - r * d4);
+        const uint2 hi = ((const uint2*)x16)[i];
+        const float4 v = resid_decode4<TT>(hi, ((const unsigned*)lo8)[i]);
+        float h[4];
+        unpack4<TT>(hi, h);
+        const uint2 lo = pack4<TT>(v.x - h[0], v.y - h[1], v.z - h[2], v.w - h[3]);
+        uint2* o = (uint2*)(out + r * (size_t)(12 * d4)) + c;
+        o[0] = hi; o[d4] = lo; o[2 * d4] = hi;
+    }
+}
+
 // one workgroup per weight row n: W'[n, k] = g[k] * W[n, k] (g == nullptr: W itself) split into hi / lo;
-// triple != 0: out row = [hi | hi | lo] (3 K elements) and s[n] = sum_k (hi + lo) in fp32; triple == 0: out row = lo only (K elements)
+// triple == 1: out row = [hi | hi | lo] (3 K elements) and s[n] = sum_k (hi + lo) in fp32; triple == 0: out row = lo only (K elements);
+// triple == 2: out row = [hi | lo] (2 K elements: the B operand of an [A | A] product, GemmArgs::a_wrap)
 template <class TT>
 __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict__ W, const float* __restrict__ g, u16* __restrict__ out,
                                                          float* __restrict__ srow, int K, int triple) {
@@ -647,7 +673,7 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict
     __shared__ float red[256];
     const int n = blockIdx.x;
     const float* w = W + (size_t)n * K;
-    u16* o = out + (size_t)n * (triple ? 3 * K : K);
+    u16* o = out + (size_t)n * (triple == 1 ? 3 * K : triple == 2 ? 2 * K : K);
     float acc = 0.f;
     for (int k = threadIdx.x; k < K; k += 256) {
         const float v = g ? g[k] * w[k] : w[k];
@@ -655,10 +681,11 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict
         const float hf = TT::to_f32(hi);
         const typename TT::elem lo = TT::from_f32(v - hf);
         const u16 hb = __builtin_bit_cast(u16, hi), lb = __builtin_bit_cast(u16, lo);
-        if (triple) { o[k] = hb; o[K + k] = hb; o[2 * K + k] = lb; acc += hf + TT::to_f32(lo); }
+        if (triple == 1) { o[k] = hb; o[K + k] = hb; o[2 * K + k] = lb; acc += hf + TT::to_f32(lo); }
+        else if (triple == 2) { o[k] = hb; o[K + k] = lb; }
         else o[k] = lb;
     }
-    if (triple) {
+    if (triple == 1) {
         red[threadIdx.x] = acc;
         __syncthreads();
         for (int st = 128; st > 0; st >>= 1) {
@@ -676,6 +703,37 @@ hipError_t leaf_launch_split16_rows(const float* x, void* out, int rows, int d, 
     const int grid = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
     if (dtype == LEAF_F16) hipLaunchKernelGGL((split16_rows_kernel<F16>), dim3(grid), dim3(256), 0, s, x, (u16*)out, n4, d / 4);
     else hipLaunchKernelGGL((split16_rows_kernel<BF16>), dim3(grid), dim3(256), 0, s, x, (u16*)out, n4, d / 4);
+    return hipGetLastError();
+}
+
+// out[r, :] = [x[r, :] | x[r, :]] (16-bit rows, d % 8 == 0): the materialised [A | A] operand of the launches too small for the
+// kernel that re-reads A itself (GemmArgs::a_wrap)
+namespace {
+__global__ __launch_bounds__(256) void dup_cols16_kernel(const uint4* __restrict__ x, uint4* __restrict__ out, size_t n8, int d8) {
+    leaf_fp16_sat_mode();
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const size_t r = i / d8;
+        const int c = (int)(i - r * d8);
+        const uint4 v = x[i];
+        uint4* o = out + r * (size_t)(2 * d8) + c;
+        o[0] = v; o[d8] = v;
+    }
+}
+}  // namespace
+hipError_t leaf_launch_dup_cols16(const void* x, void* out, int rows, int d, hipStream_t s) {
+    if (d % 8 || rows < 1) return hipErrorInvalidValue;
+    const size_t n8 = (size_t)rows * (d / 8);
+    const int grid = (int)((n8 + 255) / 256 < 4096 ? (n8 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(dup_cols16_kernel, dim3(grid), dim3(256), 0, s, (const uint4*)x, (uint4*)out, n8, d / 8);
+    return hipGetLastError();
+}
+
+hipError_t leaf_launch_split16_rows_lo8(const void* x16, const void* lo8, void* out, int rows, int d, int dtype, hipStream_t s) {
+    if (d % 4 || rows < 1) return hipErrorInvalidValue;
+    const size_t n4 = (size_t)rows * (d / 4);
+    const int grid = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+    if (dtype == LEAF_F16) hipLaunchKernelGGL((split16_rows_lo8_kernel<F16>), dim3(grid), dim3(256), 0, s, (const u16*)x16, (const unsigned char*)lo8, (u16*)out, n4, d / 4);
+    else hipLaunchKernelGGL((split16_rows_lo8_kernel<BF16>), dim3(grid), dim3(256), 0, s, (const u16*)x16, (const unsigned char*)lo8, (u16*)out, n4, d / 4);
     return hipGetLastError();
 }
 

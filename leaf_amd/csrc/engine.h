@@ -72,18 +72,28 @@ struct leaf_text {
     const float* fold_s_fc(const void* w16, int l) const { return fold_aux(w16, l) + 6 * cfg.width; }
     const float* fold_c_fc(const void* w16, int l) const { return fold_aux(w16, l) + 10 * cfg.width; }
     // ---- optional higher-precision leading blocks (leaf_text_split_pack): hi + lo operand splits for the four GEMMs of blocks
-    // [0, split_blocks) of the forward-only passes.  Caller-owned buffer: per block 26 d^2 16-bit elements -- QKV' [3d][3d] and
-    // c_fc' [4d][3d] as [hi | hi | lo] of the gamma-scaled weights, the lo halves of out_proj [d][d] and c_proj [d][4d] -- then
-    // (256-B aligned) per block the fp32 row sums s_qkv[3d], s_fc[4d] of hi + lo.
+    // [0, split_blocks) of the forward-only passes.  Caller-owned buffer: per block 27 d^2 16-bit elements -- QKV' [3d][3d] and
+    // c_fc' [4d][3d] as [hi | hi | lo] of the gamma-scaled weights, out_proj as [hi | lo] [d][2d] (ONE launch against [A | A]:
+    // GemmArgs::a_wrap), the lo half of c_proj [d][4d] (a second launch) -- then (256-B aligned) per block the fp32 row sums
+    // s_qkv[3d], s_fc[4d] of hi + lo.
     int split_blocks = 0;
     const void* split_buf = nullptr;
-    size_t split_block_elems() const { return (size_t)26 * cfg.width * cfg.width; }
+    // WHICH GEMMs of those blocks run on splits: one mask per block (leaf_text_split_pack_masks), bit 0 = QKV (both operands, three
+    // passes), bit 1 = out_proj (weights, two passes), bit 2 = c_fc (both operands), bit 3 = c_proj (weights); leaf_text_split_pack =
+    // 15 for every block.  profiles/r06_precision_budget_sites.txt and the census price the choices.
+    int split_mask[64] = {};
+    bool split_on(int l) const { return split_buf && l < split_blocks && l < 64; }
+    bool split_qkv(int l) const { return split_on(l) && (split_mask[l] & 1); }
+    bool split_out(int l) const { return split_on(l) && (split_mask[l] & 2); }
+    bool split_fc(int l) const { return split_on(l) && (split_mask[l] & 4); }
+    bool split_proj(int l) const { return split_on(l) && (split_mask[l] & 8); }
+    size_t split_block_elems() const { return (size_t)27 * cfg.width * cfg.width; }
     size_t split_aux_byte_off(int n) const { return ((size_t)n * split_block_elems() * 2 + 255) / 256 * 256; }
     size_t split_bytes(int n) const { return split_aux_byte_off(n) + (size_t)n * 7 * cfg.width * 4; }
     const uint16_t* split_qkv3(int l) const { return (const uint16_t*)split_buf + (size_t)l * split_block_elems(); }
     const uint16_t* split_fc3(int l) const { return split_qkv3(l) + (size_t)9 * cfg.width * cfg.width; }
-    const uint16_t* split_out_lo(int l) const { return split_fc3(l) + (size_t)12 * cfg.width * cfg.width; }
-    const uint16_t* split_proj_lo(int l) const { return split_out_lo(l) + (size_t)cfg.width * cfg.width; }
+    const uint16_t* split_out2(int l) const { return split_fc3(l) + (size_t)12 * cfg.width * cfg.width; }
+    const uint16_t* split_proj_lo(int l) const { return split_out2(l) + (size_t)2 * cfg.width * cfg.width; }
     const float* split_s_qkv(int l) const { return (const float*)((const char*)split_buf + split_aux_byte_off(split_blocks)) + (size_t)l * 7 * cfg.width; }
     const float* split_s_fc(int l) const { return split_s_qkv(l) + 3 * cfg.width; }
 };
@@ -102,7 +112,7 @@ struct GemmLn {
 };
 int leaf_gemm(int dtype, int epi, const void* A, int lda, const void* B, int ldb, void* C, int ldc, const float* bias,
               void* aux, int M, int N, int K, int act, hipStream_t s, float beta = 0.f, int aux_f16 = 0,
-              const float* alpha = nullptr, const GemmLn* ln = nullptr);
+              const float* alpha = nullptr, const GemmLn* ln = nullptr, int a_wrap = 0);
 int leaf_qkv_attn(const QkvAttnArgs& a, int dtype, hipStream_t s);   // leaf_launch_qkv_attn + profiler accounting
 void leaf_set_error(const char* fmt, ...);
 int leaf_check(hipError_t e, const char* what);

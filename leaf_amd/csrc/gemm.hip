@@ -359,6 +359,7 @@ hipError_t leaf_launch_gemm(const GemmArgs& p_in, int dtype, int epi, hipStream_
     if (use_w4 < 0) { const char* e = getenv("LEAF_GEMM_W4"); use_w4 = (e && e[0] == '1') ? 1 : 0; }
     if (use_w4 && fam == 4 && leaf_gemm256w4_eligible(p, epi)) return leaf_launch_gemm256w4(p, dtype, epi, s);
 #endif
+    if (p.a_wrap && fam != 4) return hipErrorInvalidValue;      // only the half-stage ring kernel re-reads A (the caller duplicates it otherwise)
     if (fam == 4) return leaf_launch_gemm256h(p, dtype, epi, s);
     if (fam == 6) return leaf_launch_gemm64(p, dtype, epi, s);
     return dtype == LEAF_F16 ? launch_t<F16>(p, epi, s) : launch_t<BF16>(p, epi, s);

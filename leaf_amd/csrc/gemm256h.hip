@@ -104,7 +104,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
 #endif
     // piece q (0..3) of half-stage u: u even = A panel of K tile u/2, u odd = B panel
     // (so = byte offset of the ring slot that half-stage lands in, kt = its K tile)
-#define ISSUE_A(so, kt, q) DMA16(A + (size_t)((kt) * (BK * 2)) + ((q) == 0 ? a0 : (q) == 1 ? a1 : (q) == 2 ? a2 : a3), smem + (so) + piece + (q) * 1024)
+    // (A's k offset wraps after awrap K tiles -- GemmArgs::a_wrap, [A | A] operands; awrap >= nt otherwise: two scalar instructions per tile)
+    const int awrap = p.a_wrap > 0 ? p.a_wrap : 0x7fffffff;
+#define AKT(kt) ((kt) >= awrap ? (kt) - awrap : (kt))
+#define ISSUE_A(so, kt, q) DMA16(A + (size_t)(AKT(kt) * (BK * 2)) + ((q) == 0 ? a0 : (q) == 1 ? a1 : (q) == 2 ? a2 : a3), smem + (so) + piece + (q) * 1024)
 #define ISSUE_B(so, kt, q) DMA16(B + (size_t)((kt) * (BK * 2) + (q) * bstep) + b0, smem + (so) + piece + (q) * 1024)
 #define ISSUE_HALF_A(so, kt) ISSUE_A(so, kt, 0); ISSUE_A(so, kt, 1); ISSUE_A(so, kt, 2); ISSUE_A(so, kt, 3);
 #define ISSUE_HALF_B(so, kt) ISSUE_B(so, kt, 0); ISSUE_B(so, kt, 1); ISSUE_B(so, kt, 2); ISSUE_B(so, kt, 3);
@@ -592,6 +595,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_half_kernel(GemmArgs p) {
 #undef ADV
 #undef DMA16
 #undef ISSUE_A
+#undef AKT
 #undef ISSUE_B
 #undef ISSUE_HALF_A
 #undef ISSUE_HALF_B
@@ -709,7 +713,9 @@ bool leaf_gemm256h_eligible(const GemmArgs& p, int epi) {
     const bool fits32 = (unsigned long long)p.M * p.lda * 2ull < (1ull << 32) && (unsigned long long)p.N * p.ldb * 2ull < (1ull << 32);
     // EPI_RESID_LN8 addresses its 16-bit rows and remainder bytes by 32-bit byte offsets too
     const bool fits8 = epi != EPI_RESID_LN8 || ((unsigned long long)p.M * p.ldx16 * 2ull < (1ull << 32) && (unsigned long long)p.M * p.ldc < (1ull << 32));
-    return p.N % BN == 0 && tiles >= g_min_tiles && p.K % BK == 0 && p.K >= 4 * BK && p.ldc % 8 == 0 && fits32 && fits8;
+    // a_wrap: A is [M, 64 a_wrap], read K / (64 a_wrap) times (at most twice: one wrap per tile walk)
+    const bool wrap_ok = p.a_wrap == 0 || (p.a_wrap > 0 && p.K == 2 * BK * p.a_wrap && p.lda >= BK * p.a_wrap);
+    return p.N % BN == 0 && tiles >= g_min_tiles && p.K % BK == 0 && p.K >= 4 * BK && p.ldc % 8 == 0 && fits32 && fits8 && wrap_ok;
 }
 
 hipError_t leaf_launch_gemm256h(const GemmArgs& p, int dtype, int epi, hipStream_t s) {

@@ -52,6 +52,10 @@ struct GemmArgs {
     int stat_ld, ldx16;
     float ln_eps;
     int stagger;  // gemm128pp.hip: start delay (x 2,048 cycles) of the second workgroup of each CU in the first round
+    // A operand re-read along K (gemm256h.hip only; leaf_launch_gemm refuses it elsewhere): after a_wrap K tiles of 64 the A panel's k
+    // offset restarts at 0, i.e. the kernel multiplies [A | A | ...] [M, K] against B [N, K] with A stored ONCE as [M, 64 a_wrap].
+    // 0 = off.  The out-projection of a split block: [A | A] x [W_hi | W_lo]^T in one launch (api.hip).
+    int a_wrap;
 };
 
 hipError_t leaf_launch_gemm(const GemmArgs& p, int dtype, int epi, hipStream_t s);
@@ -111,7 +115,7 @@ hipError_t leaf_launch_layernorm(const float* x, const float* g, const float* b,
 // lo8: x is the [rows, d] byte matrix of remainders of the 16 + 8-bit residual stream (common.h resid_lo4), no fp32 row is written
 hipError_t leaf_launch_embed_fold(const int32_t* tokens, const float* tok_emb, const float* pos_emb, float* x, void* x16,
                                   float2* stat, int stat_ld, int rows, int n_seq, RowMap map, int d, int vocab, int dtype,
-                                  hipStream_t s, const float* delta = nullptr, bool lo8 = false);
+                                  hipStream_t s, const float* delta = nullptr, bool lo8 = false, void* split3 = nullptr);
 // rowstat[m] = (mean, rstd) of row m from the [ngroups][ld] (sum, M2) partials (Chan merge, lnfold.h)
 hipError_t leaf_launch_ln_finalize(const float2* stat, int ld, int rows, int ngroups, float eps, float2* rowstat, hipStream_t s);
 // gamma-scaled 16-bit QKV / c_fc weights W'[n,:] = 16-bit(g * W[n,:]) of ALL layers and their vectors s[n] = sum W'[n,:],
@@ -137,6 +141,8 @@ hipError_t leaf_launch_copy_bytes(const void* src, void* dst, size_t bytes, hipS
 // optional higher-precision blocks (hi + lo operand splits over a 3x longer K): out[rows, 3 d] = [hi | lo | hi] of x[rows, d];
 // weight rows W'[n,:] = (g .* W)[n,:] as [hi | hi | lo] + s[n] = sum (hi + lo) (triple), or the lo halves alone
 hipError_t leaf_launch_split16_rows(const float* x, void* out, int rows, int d, int dtype, hipStream_t s);
+hipError_t leaf_launch_dup_cols16(const void* x, void* out, int rows, int d, hipStream_t s);
+hipError_t leaf_launch_split16_rows_lo8(const void* x16, const void* lo8, void* out, int rows, int d, int dtype, hipStream_t s);
 hipError_t leaf_launch_split_pack(const float* W, const float* g, void* out, float* srow, int N, int K, int triple, int dtype, hipStream_t s);
 // fp32 -> 16-bit straight copy (weight packing)
 hipError_t leaf_launch_cast(const float* src, void* dst, size_t n, int dtype, hipStream_t s);

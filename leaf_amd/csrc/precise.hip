@@ -266,6 +266,11 @@ int precise_chunk(const leaf_text* h, const float* P, const int32_t* tokens, int
         if (pgemm(2, b.hid, P + o.proj_w, b.x, P + o.proj_b, rows, d, 4 * d, 0, s)) return 1;
     }
     LEAF_TRY(hipGetLastError());
+    if (!leaf_project_rows_ok(d, c.embed_dim)) {       // widths the fp32 matrix-core projection does not take (the d = 128 test config): fp32 VALU
+        LEAF_TRY(leaf_launch_pool_project(b.x, tokens, P + h->lnf_w, P + h->lnf_b, c.ln_eps, P + h->text_proj, out, nullptr, nullptr, cs, map,
+                                          d, c.embed_dim, normalize, s));
+        return 0;
+    }
     LEAF_TRY(leaf_launch_eot_positions(tokens, b.eot, cs, map, s));
     LEAF_TRY(leaf_launch_gather_rows(b.x, b.eot, b.xg, cs, map, d, s));
     LEAF_TRY(leaf_launch_project_rows(b.xg, P + h->lnf_w, P + h->lnf_b, c.ln_eps, P + h->text_proj, b.scr, out, cs, d, c.embed_dim, normalize, s));
@@ -289,8 +294,8 @@ extern "C" int leaf_text_forward_precise(leaf_text_t h, const float* params, con
     if ((seq_lens == nullptr) != (cu_rows == nullptr)) { leaf_set_error("seq_lens (host) and cu_rows (device) go together"); return 1; }
     const leaf_text_cfg& c = h->cfg;
     const int ctx = c.context_length, d = c.width;
-    if (ctx > PCTX || d % 64 || d > 2048 || !leaf_project_rows_ok(d, c.embed_dim)) {
-        leaf_set_error("precise forward: unsupported shape (ctx <= 96, width %% 64 == 0, width <= 2048, embed_dim %% 128 == 0)");
+    if (ctx > PCTX || d % 64 || d > 2048) {
+        leaf_set_error("precise forward: unsupported shape (ctx <= 96, width %% 64 == 0, width <= 2048)");
         return 1;
     }
     hipStream_t s = (hipStream_t)s_;

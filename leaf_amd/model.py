@@ -65,6 +65,10 @@ def get_config(name: str) -> TextConfig:
 
 
 _DTYPES = {"bf16": 0, "fp16": 1}
+# arithmetic of the forward-only passes: split masks per leading block (LeafCLIPText.set_split_masks: bit 0 QKV, 1 out_proj weights,
+# 2 c_fc, 3 c_proj weights)
+PRECISION_MODES = {"rowsafe": (3, 2, 2, 2), "fast": ()}
+PRECISION_DEFAULT = "rowsafe"
 _OBJ = {"l2": 0, "negl2": 1, "dissim": 2, "sim": 3}
 
 
@@ -120,6 +124,14 @@ class LeafCLIPText:
         self.rows_scored = 0      # packed rows handed to the scoring passes so far (host-side count; bench.py reports it per rank)
         if trainable:
             self.enable_training()
+        # default arithmetic of the forward-only passes: LEAF_PRECISION=rowsafe (default) | fast
+        self.split_masks = ()
+        self._split_buf = None
+        mode = os.environ.get("LEAF_PRECISION", PRECISION_DEFAULT)
+        if mode not in PRECISION_MODES:
+            raise ValueError(f"LEAF_PRECISION={mode}: one of {sorted(PRECISION_MODES)}")
+        if PRECISION_MODES[mode] and self._lib.leaf_text_get_option(self._h, b"ln_fold"):
+            self.set_precision(mode)
 
     def __del__(self):
         try:
@@ -134,6 +146,8 @@ class LeafCLIPText:
         chunk pipeline of the forward-only passes), 'normalize_fare' (training forward / backward on normalised features),
         'compact_resid' (1 default: the residual stream of the forward-only passes as the 16-bit copy + an 8-bit remainder per
         element instead of fp32 rows; 0 = fp32 rows)."""
+        if name == "ln_fold" and not value and getattr(self, "split_masks", ()):
+            self.set_split_masks(())          # the split GEMMs exist in the LN-folded forward only: switching folding off switches them off
         _lib.check(self._lib.leaf_text_set_option(self._h, name.encode(), int(value)), "leaf_text_set_option")
         return self
 
@@ -224,30 +238,69 @@ class LeafCLIPText:
         out.update(self.extra_state)
         return out
 
-    def set_split_blocks(self, blocks: int):
-        """Precision escape hatch of the forward-only passes (include/leaf_hip.h, leaf_text_split_pack): the four GEMMs of the
-        first ``blocks`` transformer blocks multiply hi + lo 16-bit splits of both operands (three MFMA passes through the
-        unchanged kernels; those blocks run the two-kernel attention path).  0 switches it off.  ``pack()`` refreshes the split
-        weight copies after every optimizer step.  Costs about +13 % of the search's GEMM work per block; on the random-init ViT-L
-        fixture the worst embedding row goes 9.6e-4 -> 8.3e-4 (1 block) -> 7.1e-4 (2 blocks)."""
-        blocks = int(blocks)
-        if blocks < 0 or blocks > self.cfg.layers - 1:
-            raise ValueError(f"split blocks {blocks} out of range 0..{self.cfg.layers - 1}")
-        self.split_blocks = blocks
+    def set_split_masks(self, masks):
+        """Higher-precision GEMMs in the leading blocks of the forward-only passes (include/leaf_hip.h, leaf_text_split_pack_masks):
+        ``masks[l]`` says which GEMMs of block l multiply hi + lo 16-bit splits (more MFMA passes through the unchanged kernels):
+        bit 0 = QKV (both operands), 1 = out_proj (weights), 2 = c_fc (both operands), 3 = c_proj (weights).  ``PRECISION_MODES``
+        names the lists that matter: 'rowsafe' (the DEFAULT: every one of the census's 12,928 ViT-L search rows within 1e-3 of the
+        fp32 reference, profiles/r06_row_error_census*.txt) and 'fast' (no split: rounds 1-5, batch 8.7e-4, 1.1 % of the rows above
+        1e-3).  ``pack()`` refreshes the split weight copies after every optimizer step."""
+        masks = [int(x) for x in masks]
+        while masks and masks[-1] == 0:
+            masks.pop()
+        if len(masks) > self.cfg.layers - 1 or any(x < 0 or x > 15 for x in masks):
+            raise ValueError(f"split masks {masks}: at most {self.cfg.layers - 1} blocks, values 0..15")
+        self.split_masks = tuple(masks)
         self._split_buf = None
-        if blocks:
+        if masks:
             with torch.cuda.device(self.device):
-                self._split_buf = torch.empty(self._lib.leaf_text_split_bytes(self._h, blocks), dtype=torch.uint8, device=self.device)
+                self._split_buf = torch.empty(self._lib.leaf_text_split_bytes(self._h, len(masks)), dtype=torch.uint8, device=self.device)
         self._split_pack()
         return self
 
+    def set_split_blocks(self, blocks: int):
+        """All four GEMMs of the first ``blocks`` blocks on splits (rounds 4-5's escape hatch; 0 = none): ``set_split_masks([15] * blocks)``."""
+        blocks = int(blocks)
+        if blocks < 0 or blocks > self.cfg.layers - 1:
+            raise ValueError(f"split blocks {blocks} out of range 0..{self.cfg.layers - 1}")
+        return self.set_split_masks([15] * blocks)
+
+    @property
+    def split_blocks(self) -> int:
+        return len(getattr(self, "split_masks", ()))
+
+    def set_precision(self, mode: str):
+        """'rowsafe' (default) | 'fast' (no split GEMMs: the round-5 arithmetic) -- see ``set_split_masks``."""
+        if mode not in PRECISION_MODES:
+            raise ValueError(f"precision mode '{mode}': one of {sorted(PRECISION_MODES)}")
+        return self.set_split_masks(PRECISION_MODES[mode][:self.cfg.layers - 1])
+
+    def precision_name(self) -> str:
+        for k, v in PRECISION_MODES.items():
+            vv = list(v[:self.cfg.layers - 1])
+            while vv and vv[-1] == 0:
+                vv.pop()
+            if tuple(vv) == tuple(getattr(self, "split_masks", ())):
+                return k
+        return "masks" + "-".join(str(x) for x in self.split_masks)
+
+    def arithmetic_tag(self):
+        """What a K/V cache depends on besides the weights: a cache built under one setting must not be consumed under another
+        (the bit-exact prefix reuse would silently break)."""
+        return (int(self._lib.leaf_text_get_option(self._h, b"compact_resid")), tuple(getattr(self, "split_masks", ())))
+
     def _split_pack(self):
-        n = getattr(self, "split_blocks", 0)
-        _lib.check(self._lib.leaf_text_split_pack(self._h, _ptr(self.flat), n, _ptr(getattr(self, "_split_buf", None)), self._stream()),
-                   "leaf_text_split_pack")
+        masks = getattr(self, "split_masks", ())
+        arr = (C.c_int32 * max(len(masks), 1))(*masks)
+        _lib.check(self._lib.leaf_text_split_pack_masks(self._h, _ptr(self.flat), arr, len(masks), _ptr(getattr(self, "_split_buf", None)),
+                                                        self._stream()), "leaf_text_split_pack_masks")
 
     def copy_from(self, other: "LeafCLIPText"):
+        """Weights AND arithmetic of ``other`` (split blocks / policy, residual-stream format): a frozen copy must embed like its source."""
         self.flat.copy_(other.flat)
+        if tuple(getattr(other, "split_masks", ())) != tuple(getattr(self, "split_masks", ())):
+            self.set_split_masks(getattr(other, "split_masks", ()))
+        self.set_option("compact_resid", other.arithmetic_tag()[0])
         self.logit_scale = other.logit_scale.clone()
         self.extra_state = dict(other.extra_state)
         self._packed = False
@@ -257,7 +310,7 @@ class LeafCLIPText:
         """fp32 masters -> 16-bit MFMA operand copies (forward dtype; + transposed bf16 when training)."""
         _lib.check(self._lib.leaf_text_pack_weights(self._h, _ptr(self.flat), _ptr(self.w16), _ptr(self.w16_bwd),
                                                     self._stream()), "leaf_text_pack_weights")
-        if getattr(self, "split_blocks", 0):
+        if getattr(self, "split_masks", ()):
             self._split_pack()
         self._packed = True
 
@@ -362,7 +415,7 @@ class LeafCLIPText:
                                                   C.c_void_p(lens.ctypes.data), _ptr(cu_dev), n, _ptr(out), 0,
                                                   _ptr(kvbuf), kvbuf.numel(), _ptr(ws), ws.numel(), self._stream()),
                    "leaf_text_forward_kv")
-        cache = {"kv": kvbuf, "base_cu": cu_dev, "base_rows": int(cu[-1]), "lens": lens, "n": n}
+        cache = {"kv": kvbuf, "base_cu": cu_dev, "base_rows": int(cu[-1]), "lens": lens, "n": n, "arith": self.arithmetic_tag()}
         return (cache, out) if want_features else cache
 
     def score_candidates(self, tokens, anchor: torch.Tensor, rho: int, objective: str = "l2", want_features=True,
@@ -421,6 +474,9 @@ class LeafCLIPText:
         B = anchor.shape[0]
         if t.shape[0] != B * rho or kv["n"] != B or n != B * rho:
             raise ValueError("candidate rows / kv cache do not match B*rho")
+        if kv.get("arith", self.arithmetic_tag()) != self.arithmetic_tag():
+            raise ValueError(f"K/V cache built under arithmetic {kv['arith']} (compact_resid, split masks), "
+                             f"the model now runs {self.arithmetic_tag()}: rebuild the cache (encode_text_kv)")
         anchor = anchor.to(device=self.device, dtype=torch.float32).contiguous()
         idx = torch.empty(B, dtype=torch.int32, device=self.device)
         feat = torch.empty(B, self.cfg.embed_dim, dtype=torch.float32, device=self.device) if want_features else None
@@ -493,7 +549,7 @@ class LeafCLIPText:
             return None
         _lib.check(rc, "leaf_score_candidates_prefix_fused")
         self.rows_scored += int(cu[-1])
-        cache = {"kv": self._kv, "base_cu": cu_dev[:B + 1], "base_rows": base_rows, "lens": blens, "n": B}
+        cache = {"kv": self._kv, "base_cu": cu_dev[:B + 1], "base_rows": base_rows, "lens": blens, "n": B, "arith": self.arithmetic_tag()}
         return (idx, feat, cache, loss) if want_loss else (idx, feat, cache)
 
     # ------------------------------------------------------------------ training

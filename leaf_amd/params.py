@@ -117,6 +117,12 @@ def parse_args(args):
                    help="with --dictionary-tokenizer treebank: nltk's trained Punkt tables exported by tools/export_punkt_params.py, "
                         "so that sentences are split as nltk.word_tokenize splits them, without nltk")
     p.add_argument("--normalize_fare", default=False, action='store_true')
+    p.add_argument("--precise-anchor", default=False, action="store_true",
+                   help="(not in the reference) frozen model's anchor pass in fp32-grade arithmetic (leaf_text_forward_precise); default: "
+                        "the 16-bit arithmetic the candidates are scored in, as the reference computes both sides in one arithmetic")
+    p.add_argument("--arithmetic", default=None, choices=["rowsafe", "fast"],
+                   help="(not in the reference) arithmetic of the forward-only passes: rowsafe (default) keeps every embedding row within "
+                        "1e-3 of fp32; fast drops the split GEMMs (-4 %% step time, 1 %% of the rows above 1e-3)")
     p.add_argument("--custom_out_folder", type=str, default='')
     for flag, kw in _IGNORED:
         p.add_argument(flag, **kw)

@@ -44,6 +44,11 @@ class StepConfig:
     pgd_eps: float = 0.05
     pgd_alpha: float = 0.02
     pgd_norm: str = "linf"
+    # frozen model's anchor pass (utils_AT.py:296) in the fp32-grade arithmetic of precise.hip instead of the 16-bit arithmetic the
+    # candidates are scored in.  Off by default: the reference computes anchor and candidates in the SAME reduced arithmetic (TF32),
+    # and at equal weights the operand-rounding error common to both sides cancels in the search's ||f_cand - anchor||^2
+    # (profiles/r06_precise_anchor_ab.txt prices both)
+    precise_anchor: bool = False
 
 
 class SyntheticCandidates:
@@ -316,7 +321,7 @@ def train_step_tokens(model, frozen, base: torch.Tensor, cfg: StepConfig, seed: 
     if prev is not None and os.environ.get("LEAF_ANCHOR_AT", "tail") == "tail":
         side.wait_event(prev)
     with torch.cuda.stream(side):
-        anchor = frozen.encode_text(base, seq_lens=base_lens)
+        anchor = frozen.encode_text(base, seq_lens=base_lens, precise=cfg.precise_anchor)
         ready = torch.cuda.Event()
         ready.record(side)
     anchor.record_stream(cur)

@@ -479,7 +479,8 @@ def train_one_epoch_text_only(model, model_frozen, tokenizer, V, data, loss, epo
             # ordering (the frozen weights never change), which is what lets the anchor overlap the previous step's tail
             side.wait_stream(cur_stream)
         with torch.cuda.stream(side):
-            anchor = model_frozen.encode_text(tokenizer.encode_batch(texts), normalize=normalize_fare)
+            anchor = model_frozen.encode_text(tokenizer.encode_batch(texts), normalize=normalize_fare,
+                                              precise=bool(getattr(args, "precise_anchor", False)))
             anchor_ready = torch.cuda.Event()
             anchor_ready.record(side)
         anchor.record_stream(cur_stream)

@@ -66,30 +66,38 @@ def histogram(r, lo=None, hi=None, bins=20):
 
 
 MODES = {
-    # label: (compact_resid, split_blocks, precise)
-    "default(16+8 resid)": (1, 0, False),
-    "fp32 resid": (0, 0, False),
-    "split1": (0, 1, False),
-    "split2": (0, 2, False),
-    "precise": (0, 0, True),
+    # label: (compact_resid, split masks per leading block [bit 0 QKV, 1 out_proj w, 2 c_fc, 3 c_proj w], precise)
+    "rowsafe": (1, None, False),                 # the DEFAULT (leaf_amd.model.PRECISION_MODES), 16 + 8-bit stream
+    "rowsafe fp32 resid": (0, None, False),
+    "fast": (1, (), False),                      # rounds 1-5: no split GEMM, 16 + 8-bit stream
+    "fast fp32 resid": (0, (), False),
+    "split1": (1, (15,), False),                 # all four GEMMs of block 0
+    "split2": (1, (15, 15), False),
+    "precise": (0, (), True),
 }
+
+
+def mode_of(label):
+    """a MODES name, or 'm' + dash-separated masks (m3-1 = QKV + out_proj of block 0, QKV of block 1), optional suffix '/f32'"""
+    if label in MODES:
+        return MODES[label]
+    body, _, suf = label.partition("/")
+    return (0 if suf == "f32" else 1, tuple(int(x) for x in body[1:].split("-")), False)
 
 
 def gpu_rows(m, toks, mode, chunk=3200):
     import torch
-    compact, split, precise = MODES[mode]
+    from leaf_amd.model import PRECISION_MODES
+    compact, masks, precise = mode_of(mode)
     m.set_option("compact_resid", compact)
-    m.set_split_blocks(split)
+    m.set_split_masks((PRECISION_MODES["rowsafe"] if masks is None else masks)[:m.cfg.layers - 1])
     outs = []
     for s in range(0, toks.shape[0], chunk):
         t = toks[s:s + chunk]
-        if precise:
-            outs.append(m.encode_text(t, precise=True).cpu().numpy())
-        else:
-            outs.append(m.encode_text(t).cpu().numpy())
+        outs.append(m.encode_text(t, precise=precise).cpu().numpy())
     torch.cuda.synchronize()
-    m.set_split_blocks(0)
     m.set_option("compact_resid", 1)
+    m.set_precision("rowsafe")
     return np.concatenate(outs)
 
 
@@ -118,9 +126,10 @@ def main():
     ap.add_argument("--rows-other", type=int, default=2000)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "census"))
     ap.add_argument("--towers", default="L,Lerf,H,G")
-    ap.add_argument("--modes", default="default(16+8 resid),fp32 resid,split1")
+    ap.add_argument("--modes", default="rowsafe,fast,rowsafe fp32 resid,precise")
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--rho", type=int, default=50)
+    ap.add_argument("--ref-dir", default=None, help="re-use ref_<tower>.npy of an earlier census of the same rows (saves the CPU minutes)")
     args = ap.parse_args()
     from leaf_amd.model import create_model
     os.makedirs(args.out, exist_ok=True)
@@ -140,23 +149,27 @@ def main():
         cfg = O.CONFIGS[name]
         w = O.init_weights(cfg, seed=seed)
         m = create_model(name, seed=seed)
+        m.set_precision("fast")        # the row set is the one of profiles/r06_row_error_census.txt (stage 2 follows the round-5 arithmetic's winners)
         toks = search_rows(m, args.batch, args.rho, 1234) if kind == "search" else other_rows(args.rows_other, 11)
         log(f"== {name} (random init, seed {seed}): {toks.shape[0]} rows"
             + (f" = one configs[1] search: {args.batch} captions + 2 x {args.batch} x {args.rho} candidates" if kind == "search" else
                " (captions of 5..60 tokens + single-edit candidates)"))
         t0 = time.time()
-        ref = cpu_reference(w, cfg, toks, log=log)
-        log(f"   PyTorch CPU fp32 reference: {time.time() - t0:.0f} s on {H.usable_cores()} cores")
-        np.save(os.path.join(args.out, f"ref_{key}.npy"), ref)
+        ref_path = os.path.join(args.ref_dir or args.out, f"ref_{key}.npy")
+        if args.ref_dir and os.path.exists(ref_path) and np.load(ref_path).shape[0] == toks.shape[0]:
+            ref = np.load(ref_path)
+            log(f"   PyTorch CPU fp32 reference: re-used from {ref_path} (same seeded rows)")
+        else:
+            ref = cpu_reference(w, cfg, toks, log=log)
+            log(f"   PyTorch CPU fp32 reference: {time.time() - t0:.0f} s on {H.usable_cores()} cores")
+            np.save(os.path.join(args.out, f"ref_{key}.npy"), ref)
         for mode in modes:
-            if MODES[mode][2] and not hasattr(m, "precise_ready"):
-                continue
             got = gpu_rows(m, toks, mode)
             r = row_err(got, ref)
             s = summarize(r)
             s["global_rel_l2"] = float(np.linalg.norm(got.astype(np.float64) - ref) / np.linalg.norm(ref.astype(np.float64)))
             summary[f"{name}|{mode}"] = s
-            np.save(os.path.join(args.out, f"rows_{key}_{mode.split('(')[0].replace(' ', '_')}.npy"), r.astype(np.float32))
+            np.save(os.path.join(args.out, f"rows_{key}_{mode.replace(' ', '_')}.npy"), r.astype(np.float32))
             log(f"   -- {mode}: rows {s['rows']}  global {s['global_rel_l2']:.3e}  P50 {s['p50']:.3e}  P99 {s['p99']:.3e}  P99.9 {s['p999']:.3e}  "
                 f"max {s['max']:.3e}  rows > 1e-3: {s['rows_above_1e-3']}  rows > 9.5e-4: {s['rows_above_9.5e-4']}")
             log(histogram(r))

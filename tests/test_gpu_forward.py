@@ -402,11 +402,12 @@ def test_split_blocks_precision_escape_hatch(torch_mod, golden_dir):
     from leaf_amd.model import create_model
     z = np.load(os.path.join(golden_dir, "vitl_quickgelu.npz"))
     m = create_model("ViT-L-14-quickgelu", seed=1)
+    m.set_precision("fast")                    # no split GEMM at all (round 6: the DEFAULT is the priced policy-1 spend, tested below)
     toks = z["tokens"]
     base_out = m.encode_text(toks).cpu().numpy()
     rows = {0: row_rel_l2(base_out, z["out"])}
     for n in (1, 2):
-        m.set_split_blocks(n)
+        m.set_split_blocks(n)                  # all four GEMMs of the first n blocks
         rows[n] = row_rel_l2(m.encode_text(toks).cpu().numpy(), z["out"])
     print("[split blocks] worst / median row rel-L2:", {n: (f"{r.max():.3e}", f"{np.median(r):.3e}") for n, r in rows.items()})
     assert rows[0].max() < TOL_ROW
@@ -439,12 +440,14 @@ def test_split_blocks_precision_escape_hatch(torch_mod, golden_dir):
     changed = m.encode_text(toks).cpu().numpy()
     m.set_split_blocks(0)
     plain = create_model("ViT-L-14-quickgelu", seed=1)
+    plain.set_precision("fast")
     plain.params["transformer.resblocks.0.mlp.c_fc.weight"].mul_(1.01)
     ref2 = plain.encode_text(toks).cpu().numpy()
     assert rel_l2(changed, ref2) < 2e-3 and not np.array_equal(changed, ref2)
     assert np.array_equal(m.encode_text(toks).cpu().numpy(), ref2)
     # tiny config (2 layers: one split block, K = 3 x 128 through the small-launch kernels)
     t = _model("tiny-test-quickgelu", 12)
+    t.set_precision("fast")
     zt = np.load(os.path.join(golden_dir, "tiny_quickgelu.npz"))
     e0 = rel_l2(t.encode_text(zt["tokens"]).cpu().numpy(), zt["out"])
     t.set_split_blocks(1)
@@ -452,6 +455,60 @@ def test_split_blocks_precision_escape_hatch(torch_mod, golden_dir):
     assert e1 < e0 < TOL_GLOBAL
     with pytest.raises(ValueError):
         t.set_split_blocks(2)
+
+
+def test_default_arithmetic_is_the_priced_split_policy_and_keeps_every_exactness_property(torch_mod, golden_dir):
+    """Round 6: the DEFAULT arithmetic of the forward-only passes = 'rowsafe' (leaf_amd.model.PRECISION_MODES):
+    QKV of block 0 on hi + lo splits of both operands (through the fused QKV + attention launch, K = 3d) + the out-projection weights
+    of blocks 0-3 split, on the 16 + 8-bit residual stream.  Against the reference-generated ViT-L fixtures the worst row sits well
+    inside 1e-3 (the large-sample gate is tests/test_gpu_fullshape.py::test_row_error_census_gate), 'fast' gives the round-5 bits
+    back, a frozen copy inherits the arithmetic, a K/V cache is tied to the arithmetic it was built under, and dense == EOT-trimmed
+    == prefix reuse == fused caption pass bit for bit in BOTH residual formats."""
+    from leaf_amd.model import LeafCLIPText, create_model, get_config
+    z = np.load(os.path.join(golden_dir, "vitl_quickgelu.npz"))
+    m = create_model("ViT-L-14-quickgelu", seed=1)
+    from leaf_amd.model import PRECISION_MODES
+    assert m.split_masks == PRECISION_MODES["rowsafe"] and m.precision_name() == "rowsafe" and m.arithmetic_tag() == (1, PRECISION_MODES["rowsafe"])
+    toks = z["tokens"]
+    r_def = row_rel_l2(m.encode_text(toks).cpu().numpy(), z["out"])
+    fast = create_model("ViT-L-14-quickgelu", seed=1).set_precision("fast")
+    r_fast = row_rel_l2(fast.encode_text(toks).cpu().numpy(), z["out"])
+    print(f"[default arithmetic] rows max / median: rowsafe {r_def.max():.3e} / {np.median(r_def):.3e}   fast {r_fast.max():.3e} / {np.median(r_fast):.3e}")
+    assert r_def.max() < 8.8e-4 and np.median(r_def) < 0.88 * np.median(r_fast)
+    frozen = LeafCLIPText(get_config("ViT-L-14-quickgelu")).copy_from(fast)
+    assert frozen.arithmetic_tag() == fast.arithmetic_tag() == (1, ())
+    assert np.array_equal(frozen.encode_text(toks).cpu().numpy(), fast.encode_text(toks).cpu().numpy())
+    B, rho = 6, 50
+    base = O.synthetic_tokens(B, seed=61, min_len=20, max_len=50)
+    cand = O.synthetic_candidates(base, rho, seed=62)
+    flat = cand.reshape(-1, 77)
+    neq = cand != base[:, None, :]
+    pl = neq.argmax(-1)
+    pl[~neq.any(-1)] = 77
+    lens = np.repeat(base.argmax(-1) + 1, rho)
+    for compact in (1, 0):
+        m.set_option("compact_resid", compact)
+        anchor = m.encode_text(base) + 0.2
+        i0, f0, l0 = m.score_candidates(flat, anchor, rho, "l2", want_loss=True, seq_lens=lens)
+        kv = m.encode_text_kv(base)
+        i1, f1, l1 = m.score_candidates(flat, anchor, rho, "l2", want_loss=True, seq_lens=lens, prefix_lens=pl.reshape(-1), kv=kv)
+        assert torch_mod.equal(l0, l1) and torch_mod.equal(i0, i1) and torch_mod.equal(f0, f1), compact
+        fused = m.score_candidates_fused(torch_mod.from_numpy(base.astype(np.int32)).cuda(), (base.argmax(-1) + 1).astype(np.int32), flat, anchor,
+                                         rho, lens, pl.reshape(-1), want_features=True, want_loss=True)
+        assert fused is not None and torch_mod.equal(fused[0], i0) and torch_mod.equal(fused[1], f0) and torch_mod.equal(fused[3], l0), compact
+        m.trim_rows = False
+        i2, f2, l2 = m.score_candidates(flat, anchor, rho, "l2", want_loss=True)
+        m.trim_rows = True
+        assert torch_mod.equal(l0, l2) and torch_mod.equal(i0, i2) and torch_mod.equal(f0, f2), compact
+        # a candidate row alone (small-launch kernels) = the same bits as inside the big pass
+        one = m.encode_text(flat[7:8]).cpu().numpy()[0]
+        allf = m.encode_text(flat).cpu().numpy()
+        assert np.array_equal(one, allf[7])
+    m.set_option("compact_resid", 1)
+    kv = m.encode_text_kv(base)
+    m.set_precision("fast")
+    with pytest.raises(ValueError, match="K/V cache built under arithmetic"):
+        m.score_candidates(flat, m.encode_text(base), rho, "l2", seq_lens=lens, prefix_lens=pl.reshape(-1), kv=kv)
 
 
 def test_compact_residual_stream_gate_and_exactness(torch_mod, golden_dir):

@@ -190,7 +190,11 @@ def test_scoring_passes_take_the_fused_launch(torch_mod):
         ms, fl, by = (C.c_double * ng)(), (C.c_double * ng)(), (C.c_double * ng)()
         rows, info, n = (C.c_int64 * ng)(), (C.c_int32 * (4 * ng))(), C.c_int(0)
         _lib.check(lib.leaf_prof_end_shapes(ms, fl, by, rows, info, ng, C.byref(n)), "prof")
-        return {((info[4 * i] % 1024) // 32, info[4 * i] % 16, info[4 * i + 1]): info[4 * i + 3] for i in range(n.value)}
+        out = {}       # (family, epilogue, N) -> launches, summed over K (block 0 of the default arithmetic multiplies K = 3d: split QKV)
+        for i in range(n.value):
+            key = ((info[4 * i] % 1024) // 32, info[4 * i] % 16, info[4 * i + 1])
+            out[key] = out.get(key, 0) + info[4 * i + 3]
+        return out
     on = families()
     assert on.get((8, 5, 3 * 768)) == m.cfg.layers and not any(f != 8 and e == 5 and N == 3 * 768 for (f, e, N) in on), on
     m.set_option("fuse_attn", 0)

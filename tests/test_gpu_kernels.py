@@ -304,6 +304,64 @@ def test_gemm_rows_do_not_depend_on_the_kernel(env, N, K):
         assert torch.equal(run(epi, M, act), run(epi, CH, act)), f"epilogue {epi} act {act}"
 
 
+@pytest.mark.parametrize("Ka,N", [(768, 768), (1024, 1024)])
+def test_gemm_that_rereads_its_a_panel_equals_the_launch_on_a_duplicated_panel(env, Ka, N):
+    """Round 6 (GemmArgs::a_wrap): the out-projection of a split block is x += [A | A] [W_hi | W_lo]^T in ONE launch; the half-stage
+    ring kernel restarts A's k offset after Ka / 64 tiles instead of reading a materialised [M, 2 Ka] copy.  Same operands, same k
+    order: BIT-identical to the plain launch on the duplicated panel -- whichever kernel that one runs in (big launch: the ring
+    kernel; chunks of 2,000 rows: the small-launch kernel, which is what the B-caption passes use)."""
+    lib, torch, dev = env
+    from leaf_amd import _lib
+    M, CH = 12000, 2000
+    rng = np.random.default_rng(Ka)
+    a16 = to16(rng.standard_normal((M, Ka), dtype=np.float32), "fp16", dev)
+    b16 = to16(rng.standard_normal((N, 2 * Ka), dtype=np.float32) * 0.05, "fp16", dev)
+    bias = torch.from_numpy(rng.standard_normal(N).astype(np.float32)).to(dev)
+    x0 = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).to(dev)
+    wrap = x0.clone()
+    _lib.check(lib.leaf_op_gemm_awrap(1, ptr(a16), ptr(b16), ptr(wrap), ptr(bias), M, N, Ka, stream()), "gemm_awrap")
+    a2 = torch.cat([a16, a16], 1).contiguous()
+    for rows in (M, CH):
+        outs = []
+        for r0 in range(0, M, rows):
+            c = x0[r0:r0 + rows].clone()
+            _lib.check(lib.leaf_op_gemm(1, 2, ptr(a2[r0:r0 + rows]), ptr(b16), ptr(c), ptr(bias), None, c.shape[0], N, 2 * Ka, 0, 0.0, 0, stream()), "gemm")
+            outs.append(c)
+        torch.cuda.synchronize()
+        assert torch.equal(wrap, torch.cat(outs)), rows
+    # fp32 check of the sum itself
+    ref = x0.double() + a2.double() @ b16.double().T + bias.double()
+    assert float((wrap.double() - ref).norm() / ref.norm()) < 1e-5
+    small = x0[:CH].clone()           # a launch the ring kernel does not take must be refused, not mis-computed
+    assert lib.leaf_op_gemm_awrap(1, ptr(a16), ptr(b16), ptr(small), ptr(bias), CH, N, Ka, stream()) != 0
+
+
+@pytest.mark.parametrize("M,K", [(12000, 768), (2000, 768), (500, 128)])
+def test_forward_gemm_outputs_saturate_at_fp16_max_in_every_kernel_family(env, M, K):
+    """ADVICE r5: F16::pack2 relies on MODE.FP16_OVFL (leaf_fp16_sat_mode at kernel entry) for the +-65504 saturation of every
+    16-bit store.  A product far beyond fp16's range must come out as +-65504 (0x7bff / 0xfbff), never inf / NaN, from the
+    half-stage ring kernel (12,000 rows), the small-launch ring kernel (2,000 rows) and the register-staged kernel (K = 128),
+    with the plain 16-bit-store epilogue and with the activation epilogue."""
+    lib, torch, dev = env
+    from leaf_amd import _lib
+    N = 768
+    a = torch.full((M, K), 200.0, dtype=torch.float16, device=dev)
+    a[1::2] = -200.0
+    b = torch.full((N, K), 200.0, dtype=torch.float16, device=dev)
+    bias = torch.zeros(N, dtype=torch.float32, device=dev)
+    for epi, act in ((0, 0), (1, 0)):
+        c = torch.zeros(M, N, dtype=torch.float16, device=dev)
+        _lib.check(lib.leaf_op_gemm(1, epi, ptr(a), ptr(b), ptr(c), ptr(bias), None, M, N, K, act, 0.0, 0, stream()), "gemm")
+        torch.cuda.synchronize()
+        bits = c.view(torch.int16)
+        assert bool(torch.isfinite(c).all()), (epi, M, K)
+        assert bool((bits[0::2] == 0x7bff).all()), (epi, M, K)
+        if epi == 0:
+            assert bool((bits[1::2] == -0x0401).all()), (epi, M, K)       # 0xfbff = -65504
+        else:
+            assert bool((c[1::2].float().abs() < 1e-3).all())             # GELU(-1e7) = -0
+
+
 def _fold_problem(rng, M, d, N, dev, torch):
     """A residual GEMM that PRODUCES a row (out_proj shape d x d) followed by the LN-folded consumer (N x d)."""
     A = rng.standard_normal((M, d), dtype=np.float32)

@@ -171,7 +171,10 @@ def test_bench_fresh_batches_fixed_batch_and_rank_sim():
     sim = run(["--rank-sim", "3", "--steps", "4", "--warmup", "1"])
     assert sim["rank_sim"] == 3 and len(sim["ms_per_rank_step_by_rank"]) == 3 and sim["steps"] == 4
     assert sim["ms_max_over_ranks_mean"] >= sim["ms_per_rank_step_mean"] > 0 and sim["skew_ratio_max_over_mean"] >= 1.0
-    assert 0.0 < sim["pred_eff"] <= sim["pred_eff_skew_only"] <= 1.0
+    assert 0.0 < sim["pred_eff_with_collective_ESTIMATE"] <= sim["pred_eff_skew_only"] <= 1.0
+    coll = sim["exposed_collective"]          # measured one-rank RCCL time of the exposed bucket + a stated link model
+    assert coll["bucket_bytes"] > 0 and coll["ranks"] == 3 and coll["link_ms_model"] > 0
+    assert coll["one_rank_rccl_ms_measured"] is None or coll["one_rank_rccl_ms_measured"] > 0
     assert sim["scored_rows_per_rank_step_min_mean_max"][0] > 0
 
 

@@ -117,6 +117,8 @@ def main(argv):
     if not args.pretrained and is_master(args):
         logging.warning("no --pretrained checkpoint: the text tower (and its frozen TextFARE anchor) start from seeded RANDOM weights")
     model = create_model(name, device=device, dtype=dtype, pretrained=args.pretrained or None, trainable=True, seed=args.seed)
+    if getattr(args, "arithmetic", None):
+        model.set_precision(args.arithmetic)
     random_seed(args.seed, args.rank)
     if is_master(args):
         with open(os.path.join(log_base, "params.txt"), "w") as f:
@@ -144,6 +146,7 @@ def main(argv):
     if args.resume and args.pretrained:
         from leaf_amd.checkpoint import load_checkpoint_file
         frozen.load_state_dict(load_checkpoint_file(args.pretrained))
+        frozen.set_split_masks(model.split_masks)
     else:
         if args.resume and is_master(args):
             # the reference re-creates model_frozen from the hub weights on every start (train_AT_text_only.py:439-465); without
