@@ -40,7 +40,7 @@ configure_runtime()   # HIP_FORCE_DEV_KERNARG=1, before the HIP runtime initiali
 
 PEAK_TFLOPS_16BIT = 2500.0  # MI355X dense bf16/fp16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_HBM_GBS = 8000.0       # HBM3E spec peak (same table; ~6.3 TB/s achievable)
-TRAFFIC_GLOB = "r05_traffic*.json"   # PMC summaries, one per workload (tools/pmc_passes.sh, tools/pmc_summary.py)
+TRAFFIC_GLOB = "r06_traffic*.json"   # PMC summaries, one per workload (tools/pmc_passes.sh, tools/pmc_summary.py)
 FAMILY = {0: "gemm_nt_kernel", 1: "gemm_nt256_kernel", 4: "gemm_nt256_half_kernel", 6: "gemm_nt64_ring_kernel", 7: "gemm_nt128pp_kernel",
           8: "qkv_attn_kernel"}
 EPI_NAMES = {0: "store16", 1: "act16", 2: "resid32", 3: "store32", 4: "actgrad16", 5: "lnfold16", 6: "lnfold_act16", 7: "resid32+x16+stats", 8: "resid16+8+stats"}
