@@ -199,6 +199,31 @@ def bucket_plan(layout, n_params: int, layers: int, min_bytes: int = 64 << 20):
     return plan
 
 
+def reduce_token_rows(table: torch.Tensor, my_tokens: torch.Tensor, cap: int, group=None) -> None:
+    """Data-parallel SUM of the token-embedding gradient ``table`` [vocab, d] that moves only the rows some rank touched
+    (LEAF_DP_SPARSE_EMBED=1).  A rank's gradient is non-zero in the rows of ITS captions' token ids only (a few
+    thousand of 49,408), yet the dense all-reduce ships the whole 152-MB table over point-to-point xGMI -- the one collective of
+    the step that cannot hide behind the backward.  Here every rank
+      1. flags its ids in a [vocab] int32 vector and all-reduces it with MAX (198 KB): the union of touched rows, identical everywhere;
+      2. takes the first ``cap`` ids of a stable descending sort of the flags -- the touched ids in ascending order, then untouched ones
+         (whose rows are zero on every rank: harmless filler) -- a FIXED-size, host-known selection (no device-to-host sync);
+      3. gathers those rows, all-reduces the [cap, d] block (SUM), scatters the sums back.
+    ``cap`` must bound the size of the union (the caller derives it from an all-reduced MAX of the per-rank token counts); row 0 is
+    always part of the selection (the fp16 backward's saturation poison lives in element [0, 0] and must reach every rank).
+    Same result as ``all_reduce(table)`` on the touched rows, untouched rows stay zero; standard collectives only."""
+    import torch.distributed as dist
+    vocab = table.shape[0]
+    cap = int(min(max(cap, 1), vocab))
+    flag = torch.zeros(vocab, dtype=torch.int32, device=table.device)
+    flag[my_tokens.reshape(-1).to(torch.int64).clamp_(0, vocab - 1)] = 1
+    flag[0] = 1
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    sel = torch.argsort(flag, descending=True, stable=True)[:cap]
+    block = table.index_select(0, sel)
+    dist.all_reduce(block, op=dist.ReduceOp.SUM, group=group)
+    table.index_copy_(0, sel, block)
+
+
 class GradReducer:
     """Data-parallel gradient mean overlapped with the backward.  The backward records one
     event per transformer block as soon as that block's gradients are final (leaf_textfare_backward_events); the weight
@@ -211,6 +236,11 @@ class GradReducer:
         self.model = model
         self.plan = bucket_plan(model.layout, model.n_params, model.cfg.layers)
         self.overlap = os.environ.get("LEAF_DP_OVERLAP", "1") != "0"
+        # LEAF_DP_SPARSE_EMBED=1 (opt-in: no multi-GPU box has run it): the token-embedding table of the exposed last bucket is
+        # reduced by touched rows (reduce_token_rows) instead of densely; needs the overlapped form and one micro-batch per step
+        self.sparse_embed = os.environ.get("LEAF_DP_SPARSE_EMBED", "0") == "1"
+        self._cap_host = None      # pinned [1] int64: all-reduced MAX of the per-rank token counts of the current step
+        self._cap_ev = None
         self.events = None
         self.comm = None
         self._launched = False
@@ -226,6 +256,26 @@ class GradReducer:
         for e in self.events:          # an event's handle exists only once it has been recorded
             e.record(torch.cuda.current_stream(dev))
 
+    def begin_step(self, n_tokens: int):
+        """Sparse embedding reduction only: all-reduce (MAX) this rank's token count of the step on the comm stream NOW -- it is long
+        finished when the backward's reduction needs it on the host to size its fixed [cap, d] block (no device-to-host wait then)."""
+        import torch.distributed as dist
+        if not (self.sparse_embed and _dp_active() and self.overlap):
+            return
+        if self.events is None:
+            self._setup()
+        dev = self.model.device
+        if self._cap_host is None:
+            self._cap_host = torch.zeros(1, dtype=torch.int64).pin_memory()
+            self._cap_ev = torch.cuda.Event()
+        src = torch.tensor([int(n_tokens)], dtype=torch.int64).pin_memory()     # (pinned + non_blocking: the host must not wait for the comm stream)
+        with torch.cuda.stream(self.comm):
+            t = src.to(dev, non_blocking=True)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            self._cap_host.copy_(t, non_blocking=True)
+            self._cap_ev.record(self.comm)
+        self._cap_pending = True
+
     def backward(self, feat, anchor, accum_scale: float = 1.0, last_micro: bool = True):
         """model.backward + (on the last micro-batch of an optimizer step) the bucketed reduction queued behind it."""
         import torch.distributed as dist
@@ -235,9 +285,19 @@ class GradReducer:
         if self.events is None:
             self._setup()
         loss = m.backward(feat, anchor, accum_scale=accum_scale, layer_events=self.events)
+        sparse = self.sparse_embed and getattr(self, "_cap_pending", False) and accum_scale == 1.0
         for ev_idx, ranges in self.plan:
             self.comm.wait_event(self.events[ev_idx])
             with torch.cuda.stream(self.comm):
+                if sparse and ev_idx == m.cfg.layers:
+                    # the exposed bucket: the token-embedding table by touched rows, the rest of the bucket densely
+                    off_t, shape_t = m.layout["token_embedding.weight"]
+                    n_t = shape_t[0] * shape_t[1]
+                    self._cap_ev.synchronize()
+                    self._cap_pending = False
+                    cap = dist.get_world_size() * (int(self._cap_host[0]) + 1)
+                    reduce_token_rows(m.grads[off_t:off_t + n_t].view(shape_t), m._train_tokens, cap)
+                    ranges = [(o, c) for (o, c) in _minus(ranges, off_t, n_t)]
                 for off, numel in ranges:
                     if numel:
                         dist.all_reduce(m.grads[off:off + numel], op=dist.ReduceOp.SUM)
@@ -275,6 +335,21 @@ class GradReducer:
         return tot
 
 
+def _minus(ranges, off, n):
+    """``ranges`` ([(offset, numel)]) without the span [off, off + n)"""
+    out = []
+    for o, c in ranges:
+        lo, hi = o, o + c
+        if hi <= off or lo >= off + n:
+            out.append((o, c))
+            continue
+        if lo < off:
+            out.append((lo, off - lo))
+        if hi > off + n:
+            out.append((off + n, hi - (off + n)))
+    return out
+
+
 def reduce_buckets(flat: torch.Tensor, plan) -> None:
     """The collectives of GradReducer without streams / events (CPU rehearsal under gloo, tests/test_dp_gloo.py)."""
     import torch.distributed as dist
@@ -303,6 +378,9 @@ def train_step_tokens(model, frozen, base: torch.Tensor, cfg: StepConfig, seed: 
     stream waits for everything queued so far (always safe).  ``optimizer_step``: None = after the last micro-batch of
     ``cfg.accum_freq`` (the trainer's rule); False = never (the caller reduces / steps itself: bench.py --rank-sim)."""
     model.eval()
+    if _dp_active():      # (sparse embedding reduction: the per-rank token count travels now, section 6; a no-op otherwise)
+        n_tok = int(np.asarray(base_lens).sum()) if base_lens is not None else base.shape[0] * base.shape[1]
+        get_reducer(model).begin_step(n_tok)
     # The frozen model's anchor forward depends on nothing but the captions and the FROZEN weights: it runs on a side stream and the
     # search waits for it right before its first scoring call.  The side stream also waits for the PREVIOUS step's search
     # (LEAF_ANCHOR_AT=tail, the default): the host runs a stage ahead of the device, and without that ordering the anchor's ~85 small

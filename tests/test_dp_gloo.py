@@ -138,3 +138,52 @@ def test_bucketed_reduction_equals_the_flat_allreduce(tmp_path):
     port, out = _free_port(), str(tmp_path / "bk")
     mp.spawn(_bucket_worker, args=(2, port, out), nprocs=2, join=True)
     assert torch.load(out + ".0")["equal"] and torch.load(out + ".1")["equal"]
+
+
+def _sparse_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from leaf_amd.step import _minus, reduce_token_rows
+    vocab, d, B, ctx = 4000, 24, 6, 77
+    g = torch.Generator().manual_seed(500 + rank)
+    toks = torch.zeros(B, ctx, dtype=torch.int32)
+    n_mine = 0
+    for b in range(B):
+        L = int(torch.randint(3, 40, (1,), generator=g))
+        toks[b, :L] = torch.randint(1, vocab, (L,), generator=g, dtype=torch.int32)
+        n_mine += L
+    toks[0, 1] = 77                    # a token every rank has, and (below) the poison element in row 0
+    table = torch.zeros(vocab, d)
+    ids = toks.reshape(-1).long().unique()
+    table[ids] = torch.randn(len(ids), d, generator=g)
+    table[0] = 0.0
+    if rank == 1:
+        table[0, 0] = float("nan")     # the saturation poison of ONE rank must reach every rank
+    dense = table.clone()
+    dist.all_reduce(dense)
+    nmax = torch.tensor([n_mine])
+    dist.all_reduce(nmax, op=dist.ReduceOp.MAX)
+    sparse = table.clone()
+    reduce_token_rows(sparse, toks, world * (int(nmax) + 1))
+    same = bool(torch.equal(torch.nan_to_num(dense, nan=7.0), torch.nan_to_num(sparse, nan=7.0))) if world == 2 else \
+        bool(torch.allclose(torch.nan_to_num(dense, nan=7.0), torch.nan_to_num(sparse, nan=7.0), rtol=1e-6, atol=1e-6))
+    tiny = table.clone()               # a cap below the union would drop rows: the bound is the caller's duty, here it is checked that a generous one is harmless
+    reduce_token_rows(tiny, toks, vocab + 10)
+    torch.save({"same": same, "nan_everywhere": bool(torch.isnan(sparse[0, 0])), "full_cap_same": bool(torch.allclose(torch.nan_to_num(tiny, nan=7.0),
+                torch.nan_to_num(dense, nan=7.0), rtol=1e-6, atol=1e-6)), "minus": _minus([(0, 100), (200, 50)], 10, 30)}, f"{out}.{rank}")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_token_row_reduction_equals_the_dense_allreduce(tmp_path, world):
+    """LEAF_DP_SPARSE_EMBED (leaf_amd.step.reduce_token_rows): reducing the token-embedding gradient by the rows
+    some rank touched -- MAX all-reduce of id flags, a fixed-size stable selection, SUM all-reduce of the gathered block -- gives what the
+    dense all-reduce of the whole table gives (bit for bit at two ranks), and a NaN one rank planted in element [0, 0] (the fp16
+    backward's saturation poison) reaches every rank."""
+    port, out = _free_port(), str(tmp_path / "sp")
+    mp.spawn(_sparse_worker, args=(world, port, out), nprocs=world, join=True)
+    for r in range(world):
+        res = torch.load(f"{out}.{r}")
+        assert res["same"] and res["nan_everywhere"] and res["full_cap_same"], (r, res)
+        assert res["minus"] == [(0, 10), (40, 60), (200, 50)]

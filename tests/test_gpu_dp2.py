@@ -30,10 +30,10 @@ def _inputs(name, n):
     return toks, lens
 
 
-def _worker(rank, world, port, name, n, overlap, out):
+def _worker(rank, world, port, name, n, overlap, out, sparse=0):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LEAF_DP_OVERLAP="1" if overlap else "0")
+                      LEAF_DP_OVERLAP="1" if overlap else "0", LEAF_DP_SPARSE_EMBED=str(sparse))
     import torch
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -49,7 +49,8 @@ def _worker(rank, world, port, name, n, overlap, out):
     feat = m.forward_train(toks[sl], seq_lens=lens[sl])
     m.zero_grad()
     red = get_reducer(m)
-    assert red.overlap == bool(overlap)
+    assert red.overlap == bool(overlap) and red.sparse_embed == bool(sparse)
+    red.begin_step(int(lens[sl].sum()))          # (a no-op unless the sparse embedding reduction is on)
     loss = red.backward(feat, anchor[sl].contiguous())
     scale = red.finish()
     torch.cuda.synchronize()
@@ -114,6 +115,38 @@ def test_two_ranks_overlapped_equals_flat_and_the_concatenated_batch(tmp_path, n
         assert torch.equal(a0["grads"][off:off + numel], b0["grads"][off:off + numel])
     print("2 ranks vs concatenated batch: worst per-tensor grad rel-L2", worst)
     assert worst < 1e-5
+
+
+def test_two_ranks_sparse_embedding_reduction_equals_the_dense_one(tmp_path):
+    """LEAF_DP_SPARSE_EMBED=1 (opt-in): the exposed last bucket reduces the token-embedding gradient by touched rows
+    (id flags all-reduced with MAX, a fixed-size selection, SUM all-reduce of the gathered rows) and the rest of the bucket densely.
+    Two ranks on this GPU (gloo transport): every rank ends with the same gradient and weights, equal to the dense overlapped form
+    (embedding table to the re-association noise of its atomic scatter between separate runs, everything else bit for bit)."""
+    import torch
+    import torch.multiprocessing as mp
+    name, n = "ViT-L-14-quickgelu", 6
+    res = {}
+    for sparse in (1, 0):
+        out = str(tmp_path / f"s{sparse}")
+        mp.spawn(_worker, args=(2, _free_port(), name, n, 1, out, sparse), nprocs=2, join=True)
+        res[sparse] = [torch.load(out + ".0"), torch.load(out + ".1")]
+    a0, a1 = res[1]
+    d0, _ = res[0]
+    assert torch.equal(a0["grads"], a1["grads"]) and torch.equal(a0["flat"], a1["flat"])
+    sys.path.insert(0, ROOT)
+    from leaf_amd.model import get_config
+    from leaf_amd.step import bucket_plan
+    from tests.test_dp_gloo import _layout_for
+    layout, n_params = _layout_for(get_config(name))
+    off_t, shape_t = layout["token_embedding.weight"]
+    n_t = shape_t[0] * shape_t[1]
+    tok_s, tok_d = a0["grads"][off_t:off_t + n_t], d0["grads"][off_t:off_t + n_t]
+    assert float(tok_d.norm()) > 0 and float((tok_s - tok_d).norm() / tok_d.norm()) < 1e-6
+    assert int((tok_s.view(shape_t).abs().sum(-1) > 0).sum()) == int((tok_d.view(shape_t).abs().sum(-1) > 0).sum())     # same touched rows
+    rest_s, rest_d = a0["grads"][off_t + n_t:], d0["grads"][off_t + n_t:]
+    assert float((rest_s - rest_d).norm() / rest_d.norm()) < 1e-6
+    for off, numel in [r for ev, rs in bucket_plan(layout, n_params, get_config(name).layers)[:-1] for r in rs]:      # block weights: bit for bit
+        assert torch.equal(a0["grads"][off:off + numel], d0["grads"][off:off + numel])
 
 
 def _micro_clip_run(m, toks, lens, anchor, rows_of_micro, max_norm):
