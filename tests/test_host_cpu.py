@@ -100,6 +100,19 @@ def test_handle_layout_and_errors_without_gpu():
     assert total == 123650304 and len(set(seen)) == len(seen) == 12 * 12 + 5
     assert l.leaf_text_workspace_bytes(h, 6400, 1) > 6400 * 768 * 4
     assert l.leaf_text_param_info(h, 999, name, 128, None, None, None) != 0
+    # split masks (round 6): argument checks happen before anything touches the device
+    masks = (C.c_int32 * 4)(3, 2, 2, 2)
+    fake = C.c_void_p(64)                      # never dereferenced on these paths
+    assert l.leaf_text_split_bytes(h, 4) == ((4 * 27 * 768 * 768 * 2 + 255) // 256) * 256 + 4 * 7 * 768 * 4
+    assert l.leaf_text_split_pack_masks(h, fake, masks, 12, fake, None) != 0 and b"out of range" in l.leaf_last_error()
+    assert l.leaf_text_split_pack_masks(h, None, masks, 4, fake, None) != 0
+    bad_masks = (C.c_int32 * 2)(3, 16)
+    assert l.leaf_text_split_pack_masks(h, fake, bad_masks, 2, fake, None) != 0 and b"bits 0..3" in l.leaf_last_error()
+    assert l.leaf_text_split_pack_masks(h, fake, masks, 0, None, None) == 0 and l.leaf_text_get_option(h, b"split_blocks") == 0
+    assert l.leaf_text_set_option(h, b"ln_fold", 0) == 0
+    assert l.leaf_text_split_pack_masks(h, fake, masks, 4, fake, None) != 0 and b"LN-folded" in l.leaf_last_error()
+    assert l.leaf_text_get_option(h, b"compact_resid") == 1 and l.leaf_text_get_option(h, b"no_such_option") == -1
+    assert l.leaf_text_precise_workspace_bytes(h, 128) > 128 * 77 * 768 * 4 * 9
     l.leaf_text_destroy(h)
 
 
