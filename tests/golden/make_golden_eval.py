@@ -49,18 +49,16 @@ def main():
         rows = []
         np.random.seed(5)
         with torch.no_grad():
-            for sentence in SENTENCES:                    # the reference's loop body, eval_textfare.py:119-141, attack_name == 'leaf'
-                tokens_original = tokenizer([sentence])
-                original_clean_features = clean_model.encode_text(tokens_original, normalize=False)
-                original_features = model.encode_text(tokens_original, normalize=False)
+            for text in SENTENCES:                        # one attack call per sentence: the loop order of eval_textfare.py:113-141 (attack_name == 'leaf')
+                ids = tokenizer([text])
+                f_clean = clean_model.encode_text(ids, normalize=False)
+                f_model = model.encode_text(ids, normalize=False)
                 del log[:]
-                _, perturbed = utils_attacks.attack_text_leaf(model, spy, [sentence], original_features, "cpu", objective='l2', n=rho, k=k,
-                                                              V=V_DEFAULT, debug=False, constrain=False)
-                perturbed = perturbed[0]
-                text_features = model.encode_text(tokenizer([perturbed]), normalize=False)
-                rows.append(dict(sentence=sentence, adv_sentence=perturbed, stage_candidates=[list(c) for c in log],
-                                 textfare_clean=((original_clean_features - original_features) ** 2).sum().item(),
-                                 textfare_adv=((original_clean_features - text_features) ** 2).sum().item()))
+                _, adv = utils_attacks.attack_text_leaf(model, spy, [text], f_model, "cpu", objective='l2', n=rho, k=k, V=V_DEFAULT,
+                                                        debug=False, constrain=False)
+                f_adv = model.encode_text(tokenizer([adv[0]]), normalize=False)
+                rows.append(dict(sentence=text, adv_sentence=adv[0], stage_candidates=[list(c) for c in log],
+                                 textfare_clean=float(((f_clean - f_model) ** 2).sum()), textfare_adv=float(((f_clean - f_adv) ** 2).sum())))
         out[f"k{k}"] = dict(seed=5, k=k, rho=rho, rows=rows)
     with open(os.path.join(HERE, "eval_per_sentence.json"), "w") as f:
         json.dump(dict(clean_seed=12, model_seed=13, model="tiny-test-quickgelu", cases=out), f)
