@@ -129,6 +129,8 @@ def main():
     ap.add_argument("--modes", default="rowsafe,fast,rowsafe fp32 resid,precise")
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--rho", type=int, default=50)
+    ap.add_argument("--weight-seed", type=int, default=None, help="override the towers' weight seeds (default: 1 / 1 / 2 / 2, the benchmark's and the fixtures')")
+    ap.add_argument("--caption-seed", type=int, default=1234, help="seed of the synthetic captions / candidates")
     ap.add_argument("--ref-dir", default=None, help="re-use ref_<tower>.npy of an earlier census of the same rows (saves the CPU minutes)")
     args = ap.parse_args()
     from leaf_amd.model import create_model
@@ -146,11 +148,12 @@ def main():
     summary = {}
     for key in args.towers.split(","):
         name, seed, kind = towers[key]
+        seed = seed if args.weight_seed is None else args.weight_seed
         cfg = O.CONFIGS[name]
         w = O.init_weights(cfg, seed=seed)
         m = create_model(name, seed=seed)
         m.set_precision("fast")        # the row set is the one of profiles/r06_row_error_census.txt (stage 2 follows the round-5 arithmetic's winners)
-        toks = search_rows(m, args.batch, args.rho, 1234) if kind == "search" else other_rows(args.rows_other, 11)
+        toks = search_rows(m, args.batch, args.rho, args.caption_seed) if kind == "search" else other_rows(args.rows_other, 11 + args.caption_seed - 1234)
         log(f"== {name} (random init, seed {seed}): {toks.shape[0]} rows"
             + (f" = one configs[1] search: {args.batch} captions + 2 x {args.batch} x {args.rho} candidates" if kind == "search" else
                " (captions of 5..60 tokens + single-edit candidates)"))
