@@ -689,6 +689,25 @@ def main():
         if rank == 0:
             out["dense"] = {"value": B * n_dense / d_dt, "unit": "samples/s", "steps": n_dense, "ms_per_step": d_dt / n_dense * 1e3,
                             "note": "every sequence 77 rows, no prefix reuse (the reference's own amount of arithmetic)"}
+    # ---- fast-arithmetic leg: the same step without the split GEMMs (the rounds 1-5 arithmetic), same box, outside the timed region --
+    # what the default's per-row parity costs, readable from one line
+    if not args.no_dense_leg and not args.dense and args.attack == "leaf" and world == 1 and model.split_masks:
+        keep = model.split_masks
+        model.set_precision("fast")
+        frozen.set_precision("fast")          # (arithmetic only: the frozen model keeps its start weights -- the parity check below reads them)
+        n_fast = 10
+        run_steps(2, base_lens, not args.no_prefix_reuse)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_steps(n_fast, base_lens, not args.no_prefix_reuse)
+        torch.cuda.synchronize()
+        f_dt = time.perf_counter() - t1
+        model.set_split_masks(keep)
+        frozen.set_split_masks(keep)
+        if rank == 0:
+            out["fast_arithmetic"] = {"value": B * n_fast / f_dt, "unit": "samples/s", "steps": n_fast, "ms_per_step": f_dt / n_fast * 1e3,
+                                      "note": "no split GEMMs (--precision fast; weights as trained so far): batch rel-L2 8.7e-4 but 1.1 % of the "
+                                              "embedding rows above 1e-3 (profiles/r06_row_error_census.txt); NOT the metric"}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and args.attack == "leaf":
             oracle_name = args.model if args.model in ("ViT-L-14", "ViT-L-14-quickgelu", "ViT-H-14", "ViT-g-14", "ViT-bigG-14") else "ViT-L-14"
