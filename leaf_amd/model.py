@@ -341,8 +341,6 @@ class LeafCLIPText:
         # pinned + non_blocking: a pageable H2D copy would make the host wait for all queued GPU work
         return C.c_void_p(lens.ctypes.data), torch.from_numpy(cu).pin_memory().to(self.device, non_blocking=True), lens
 
-    precise_ready = True      # leaf_text_forward_precise is part of this build (tests/row_error_census.py asks)
-
     def encode_text(self, text, normalize: bool = False, seq_lens=None, precise: Optional[bool] = None) -> torch.Tensor:
         """``precise`` (default: the model's ``precise_encode`` attribute, False): the fp32-grade forward of precise.hip -- fp32 stored
         intermediates, fp32 master weights through three MFMA passes of fp16 hi / lo splits -- for embeddings that leave the engine
