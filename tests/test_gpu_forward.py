@@ -43,8 +43,10 @@ def test_encode_text_tiny_golden(torch_mod, golden_dir, name, seed, model):
     # d = 128: eight times fewer terms per dot product than ViT-L, so the per-row figure scatters more -- the FORMAT's own noise
     # exceeds 1e-3 here: the oracle's emulation of fp16 operands gives row max 9.1e-4 / 1.09e-3 on these two fixtures
     # (tests/test_oracle_golden.py::test_fp16_operand_noise_of_the_tiny_config; BASELINE.md section 4 says why d = 128 is exempt
-    # from north_star's per-row figure); measured on the GPU: 1.28e-3.  The BASELINE.json towers keep TOL_ROW.
-    assert row_rel_l2(out, z["out"]).max() < 1.4e-3
+    # from north_star's per-row figure); measured on the GPU: 1.28e-3 in the round-5 arithmetic, 7.0e-4 / 9.6e-4 on these two fixtures in
+    # the default ('rowsafe': block 0's QKV and out-projection on splits) -- 400 synthetic d = 128 rows still reach 1.27e-3, so the
+    # config stays exempt; this fixture is held to 1.1e-3.  The BASELINE.json towers keep TOL_ROW.
+    assert row_rel_l2(out, z["out"]).max() < 1.1e-3
     outn = m.encode_text(torch_mod.from_numpy(z["tokens"].astype(np.int64)), normalize=True).cpu().numpy()
     assert rel_l2(outn, z["out_norm"]) < TOL_GLOBAL
 
