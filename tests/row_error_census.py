@@ -131,6 +131,7 @@ def main():
     ap.add_argument("--rho", type=int, default=50)
     ap.add_argument("--weight-seed", type=int, default=None, help="override the towers' weight seeds (default: 1 / 1 / 2 / 2, the benchmark's and the fixtures')")
     ap.add_argument("--caption-seed", type=int, default=1234, help="seed of the synthetic captions / candidates")
+    ap.add_argument("--search-towers", default="L", help="towers (comma list) whose rows are one full search instead of --rows-other rows")
     ap.add_argument("--ref-dir", default=None, help="re-use ref_<tower>.npy of an earlier census of the same rows (saves the CPU minutes)")
     args = ap.parse_args()
     from leaf_amd.model import create_model
@@ -148,6 +149,7 @@ def main():
     summary = {}
     for key in args.towers.split(","):
         name, seed, kind = towers[key]
+        kind = "search" if key in args.search_towers.split(",") else "other"
         seed = seed if args.weight_seed is None else args.weight_seed
         cfg = O.CONFIGS[name]
         w = O.init_weights(cfg, seed=seed)
