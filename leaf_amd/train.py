@@ -493,6 +493,10 @@ def train_one_epoch_text_only(model, model_frozen, tokenizer, V, data, loss, epo
                 f.write("\n".join(f"{a}\t{b}" for a, b in zip(texts, adv_texts)) + "\n")
         adv_tokens = tokenizer.encode_batch(adv_texts)
         model.train()
+        if args.accum_freq == 1 and not micro_clip.active:
+            # (opt-in sparse reduction of the token-embedding gradient, LEAF_DP_SPARSE_EMBED=1: this rank's token count travels now;
+            # a no-op otherwise -- leaf_amd/step.py:GradReducer.begin_step)
+            get_reducer(model).begin_step(int(np.count_nonzero(np.asarray(adv_tokens))))
         feat = model.forward_train(adv_tokens, normalize=normalize_fare)
         data_time_m.update(time.time() - end)
         if micro_clip.active:

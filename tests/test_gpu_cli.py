@@ -350,3 +350,32 @@ def test_train_cli_from_tar_shards_with_and_without_the_reader_thread(tmp_path, 
     text = caplog.text
     assert text.count("Load (t):") >= 2 * (n // bs)
     assert "skipping shard" in text and "00000002.tar" in text and "00000003.tar" in text
+
+
+def test_train_cli_two_ranks_with_the_sparse_embedding_reduction(tmp_path):
+    """LEAF_DP_SPARSE_EMBED=1 through the trainer (one micro-batch per step, two ranks on this GPU, gloo): the replicas' weights are
+    identical after the epoch (the CLI all-gathers a checksum) -- the token-embedding gradient travelled by touched rows."""
+    import socket
+    import subprocess
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["LEAF_DP_SPARSE_EMBED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "--", os.path.join(root, "train_AT_text_only.py"), "--dist-backend", "gloo",
+           "--model", "tiny-test-quickgelu", "--dataset-type", "synthetic", "--train-num-samples", "64", "--batch-size", "8",
+           "--lr", "1e-4", "--wd", "1e-4", "--warmup", "2", "--rho", "6", "--k_adv", "1", "--seed", "5", "--epochs", "1",
+           "--custom_out_folder", "s_", "--logs", str(tmp_path / "logs"), "--name", "runs", "--log-every-n-steps", "1"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=tmp_path)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-4000:]
+    log = p.stdout + p.stderr
+    assert log.count("weights identical on 2 ranks") == 1, log[-3000:]
+    ck = torch.load(tmp_path / "results" / "s_text_only_k1_rho6_seed5" / "epoch_latest.pt", map_location="cpu", weights_only=False)
+    assert ck["epoch"] == 1 and float(ck["optimizer"]["state"][1]["step"]) == 4         # 64 / (8 * 2 ranks) = 4 steps
+    emb = ck["state_dict"]["token_embedding.weight"]
+    assert bool(torch.isfinite(emb).all())
