@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Per-row embedding error of the 16-bit forward on the BASELINE.json towers (north_star: rel-L2 <= 1e-3 per row): the two reference-generated
 ViT-L fixtures, and N synthetic captions per tower against the fp32 oracle (test infrastructure: oracle/ is only the checker here).
-  python tests/row_error_survey.py [N]"""
+  python tests/row_error_survey.py [N]
+
+Round 6: SUPERSEDED by tests/row_error_census.py (12,928 rows of one full search + 2,000 rows per other tower against the PyTorch-CPU fp32
+forward, per arithmetic variant) -- a 24-row maximum says little about a tight distribution's tail; kept as the quick look it is."""
 import os
 import sys
 
